@@ -1,0 +1,159 @@
+/*
+ * nemofilt - C ABI of the MI355X (gfx950) map-filtering + detection kernels.
+ *
+ * The reference (simonsobs/nemo) is pure Python and has no FFI for this path: the seam is the Python class
+ * protocol filters.MapFilter / photometry.findObjects.  This header is the boundary the
+ * MI355X-native Python classes in nemo_amd/ bind with ctypes (INTEGRATION.md shows the stub); each entry
+ * point cites the reference statement(s) it replaces (paths relative to the reference checkout).
+ *
+ * Conventions
+ *  - every pointer named *_d / documented "device" is a device (HBM) pointer owned by the caller; the library
+ *    allocates only plan tables (nf_plan_create) and never frees caller memory;
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream); all work is enqueued on it, and
+ *    the call returns without synchronising unless stated;
+ *  - maps are row-major [batch][H][W]; complex data is interleaved (re, im);
+ *  - return value: 0 on success, negative NF_ERR_* otherwise, with a message available from nf_last_error();
+ *    nothing is thrown across the boundary.
+ *  - `prec`, `*type` arguments: NF_F32 (0) or NF_F64 (1).
+ */
+#ifndef NEMOFILT_H
+#define NEMOFILT_H
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NF_F32 0
+#define NF_F64 1
+
+#define NF_IN_COMPLEX 0 /* complex of precision `prec`      */
+#define NF_IN_REAL64 1  /* real float64 (promoted)          */
+#define NF_IN_REAL32 2  /* real float32 (promoted)          */
+
+typedef struct nf_plan nf_plan;
+
+int nf_version(void);
+const char* nf_last_error(void);
+/* number of visible HIP devices, or negative error; selects nothing */
+int nf_device_count(void);
+
+/* FFT plan for one tile shape (twiddles, radix schedule, Bluestein chirps for lengths with a prime factor > 13,
+ * e.g. the 1031 x 1032 test tile of tests/configs/smallTestSurveyMaskHeader.txt:4-5).  Tables for a precision are
+ * built on first use.  The plan belongs to the device that is current when it is created. */
+int nf_plan_create(int H, int W, nf_plan** plan);
+int nf_plan_destroy(nf_plan* plan);
+
+/* enmap.fft (pixell), as used at nemo/filters.py:525,548,559,615,646,679,845: full complex 2-D DFT of
+ * `batch` maps.  Input may be real (promoted) or complex.  If apodY_d/apodX_d are non-NULL the real input is
+ * multiplied by the apodisation profiles first - enmap.apod, nemo/filters.py:525 - (axis 0 profile, then
+ * axis 1, each product rounded to the input dtype).  unitary != 0 divides by sqrt(H*W) as enmap.fft does. */
+int nf_fft2_forward(nf_plan* plan, int prec, const void* in_d, int inType, void* out_d, int batch,
+                    const double* apodY_d, const double* apodX_d, int unitary, void* stream);
+
+/* enmap.ifft (pixell), nemo/filters.py:662,847: backward DFT (plain sum; unitary != 0 divides by sqrt(H*W),
+ * unitary == 0 is normalize=False).  `work_d` is a complex scratch of the same size as `in_d` (may alias in_d
+ * if the input may be overwritten).  outType NF_IN_COMPLEX writes complex; NF_IN_REAL64 / NF_IN_REAL32 write
+ * the real part only (np.real(...), and .astype(np.float32) for REAL32). */
+int nf_fft2_inverse(nf_plan* plan, int prec, const void* in_d, void* work_d, void* out_d, int outType, int batch,
+                    int unitary, void* stream);
+
+/* nemo/filters.py:573: NP[i][j] = Re(F_i conj F_j) for all i, j;  F [N][npix] complex, NP [N][N][npix] real. */
+int nf_cross_power(int prec, const void* F_d, void* NP_d, int N, long long npix, void* stream);
+
+/* scipy.ndimage.gaussian_filter with mode='reflect' (nemo/filters.py:580 with sigma (3,3); nemo/maps.py:1380).
+ * wY_d / wX_d: normalised 1-D kernels of length 2*rad+1 (device, float64) for axis 0 / axis 1, as
+ * scipy builds them; tmp_d holds the axis-0 result in the map dtype. */
+int nf_gaussian_filter(int rtype, const void* in_d, void* tmp_d, void* out_d, int H, int W, int batch,
+                       const double* wY_d, int radY, const double* wX_d, int radX, void* stream);
+
+/* nemo/filters.py:621-627: filt[:, k] = inv(noiseCov[:, :, k]) . (w * |fSignal[:, k]|), float32; singular modes
+ * stay 0.  cov_d [N][N][npix] real (covType), S_d [N][npix] complex (sigType), w: N host doubles. */
+int nf_build_filter(int covType, int sigType, const void* cov_d, const void* S_d, const double* w, float* filt_d,
+                    int N, long long npix, void* stream);
+
+/* nemo/filters.py:847 (product with the filter).  sum != 0: G[npix] = sum_i F_i * filt_i (the frequency sum is
+ * moved in front of the inverse FFT, which is linear); sum == 0: G[N][npix] = F_i * filt_i per frequency
+ * (nemo/filters.py:662, for fRelWeights). */
+int nf_apply_filter(int prec, const void* F_d, const float* filt_d, void* G_d, int N, int sum, long long npix,
+                    void* stream);
+
+/* pixel-window multiplication inside enmap.apply_window (nemo/filters.py:100,644): F[b][y][x] *= wy[y]*wx[x]
+ * with wy = sinc(fftfreq(H))**pow, wx likewise (float64 device tables). */
+int nf_window_mul(int prec, void* F_d, const double* wy_d, const double* wx_d, int H, int W, int batch, void* stream);
+
+/* Template painter standing where pixell.pointsrcs.sim_objects stands (nemo/signals.py:681,691): float32 map of
+ * sign * float32(amp * profile(theta)); hav(theta) = A[y] + B[y]*C[x] (device tables), profile by linear
+ * interpolation on the log-uniform table r_d/prof_d (ntab entries, r[k] = r0*exp(k*dlnr)). */
+int nf_paint_radial(float* out_d, int H, int W, const double* A_d, const double* B_d, const double* C_d,
+                    const double* r_d, const double* prof_d, int ntab, double r0, double dlnr, double amp, double sign,
+                    void* stream);
+
+/* nemo/filters.py:853 + :714: out = float32 map * signalNorm * psMask, in float64 (vtype NF_F64: signalNorm is a
+ * float64 scalar, 'yc') or float32 (vtype NF_F32: 'uK').  psMask_d may be NULL. */
+int nf_scale_mask(int vtype, const float* in_d, void* out_d, double signalNorm, const unsigned char* psMask_d,
+                  long long n, void* stream);
+
+/* MapFilter.makeNoiseMap, grid mode (nemo/filters.py:407-478): local clipped RMS in ny x nx cells (edges as
+ * np.linspace(..., dtype=int), device int arrays of ny+1 / nx+1 entries), each widened by `overlap` pixels,
+ * with `numBins` weight-percentile bins per cell (quantiles: numBins host doubles = percentiles/100).
+ * weights_d: the median weight map (float32/float64).  work_d: nf_noise_workspace_bytes() bytes of device scratch. */
+size_t nf_noise_workspace_bytes(int ny, int nx, int numBins);
+int nf_noise_map(int vtype, const void* filtered_d, const void* weights_d, int wtype, float* rms_d, int H, int W,
+                 int ny, int nx, const int* yEdges_d, const int* xEdges_d, int overlap, int numBins,
+                 const double* quantiles, int estimator, void* work_d, size_t workBytes, void* stream);
+/* np.median over the frequency axis of N weight maps (nemo/filters.py:357-360); in_d [N][n] -> out_d [n]. */
+int nf_median_stack(int rtype, const void* in_d, void* out_d, int N, long long n, void* stream);
+
+/* ndimage.rank_filter(abs(m + (1 - psMask)), 0, size=(t, t)) > 0  (nemo/filters.py:735-736, 1139-1142);
+ * tmp_d, out_d: H*W bytes.  psMask_d may be NULL. */
+int nf_edge_check(int vtype, const void* filtered_d, const unsigned char* psMask_d, unsigned char* tmp_d,
+                  unsigned char* out_d, int H, int W, int size, void* stream);
+
+/* Tail of buildAndApply (nemo/filters.py:717-756 and :1112-1157): S/N map, survey/point-source/edge/apodisation
+ * masks.  filtered_d is updated in place; mulSurvey != 0 for the Fourier-space variant (nemo/filters.py:741).
+ * Mask inputs may be NULL (= all ones). */
+int nf_finalize(int vtype, void* filtered_d, const float* rms_d, const unsigned char* surveyMask_d,
+                const unsigned char* psMask_d, const unsigned char* edgeCheck_d, void* sn_d, float* rmsOut_d,
+                unsigned char* maskOut_d, int H, int W, int apodPix, int mulSurvey, void* stream);
+
+/* nemo/filters.py:99-101: data[ref == 0] = 0 after the pixel-window deconvolution. */
+int nf_restore_zeros(int vtype, void* data_d, const void* ref_d, long long n, void* stream);
+
+/* nemo/maps.py:1290: out = a - b. */
+int nf_subtract(int rtype, const void* a_d, const void* b_d, void* out_d, long long n, void* stream);
+
+/* scipy.ndimage.convolve(map_float32, kern2d) with mode='reflect' (nemo/filters.py:1193).  kernFlipped_d is the
+ * kernel already flipped on both axes (float64, kh x kw, odd sizes). */
+int nf_convolve2d(const float* in_d, float* out_d, int H, int W, const double* kernFlipped_d, int kh, int kw,
+                  void* stream);
+
+/* photometry.getObjectPositions, nemo/photometry.py:235-241: labels_d[H*W] int32 = scipy.ndimage.label numbering
+ * of (map > threshold) (negate != 0: of (-map > threshold), nemo/photometry.py:54-55); work_d: int32 scratch of
+ * H*W + H*W/1024 + 2 entries.  Synchronises the stream and returns the number of objects in *numObjects. */
+int nf_label_components(int vtype, const void* sn_d, double threshold, int negate, int* labels_d, int H, int W,
+                        int* work_d, int* numObjects, void* stream);
+
+/* nemo/photometry.py:243-246: per label id 0..numObjects a record of 6 doubles {count, sum v, sum v*y, sum v*x,
+ * max v, raster index of first max}; stats_d must hold (numObjects+1)*8 doubles (the tail is scratch). */
+int nf_object_stats(int vtype, const void* sn_d, int negate, const int* labels_d, int H, int W, int numObjects,
+                    double* stats_d, void* stream);
+
+/* ndarray.max() / np.argmax of a whole map (nemo/filters.py:661,684; nemo/filters.py:1017-1019,1198): out_d holds
+ * 4 doubles - [0] maximum, [1] flat index of its first occurrence, [2..3] scratch. */
+int nf_map_max(int vtype, const void* map_d, long long n, double* out_d, void* stream);
+
+/* nemo/photometry.py:69-73: isRing_d[id] = 1 if component id has > minRingPix pixels and its centre of mass is
+ * not one of its own pixels. */
+int nf_ring_flags(const int* ringLabels_d, const double* ringStats_d, int numRing, int minRingPix, int H, int W,
+                  unsigned char* isRing_d, void* stream);
+
+/* RectBivariateSpline(kx=3, ky=3)(y, x) (nemo/photometry.py:82-84,128; nemo/filters.py:654-657) at nPts points;
+ * yx_d: nPts pairs (y, x), out_d: nPts doubles; halfWin <= 34 (32 reproduces the whole-map fit to 1e-16). */
+int nf_spline_eval(int vtype, const void* map_d, int negate, int H, int W, const double* yx_d, int nPts, int halfWin,
+                   double* out_d, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,89 @@
+"""ctypes binding of libnemofilt.so (C ABI declared in include/nemofilt.h).
+
+The library is the product: there is no CPU fallback.  If it is missing, or no HIP device is usable,
+anything that needs to compute raises :class:`NemoFiltError` with the reason.
+"""
+import ctypes
+import os
+
+_here = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_here, "lib", "libnemofilt.so")
+
+NF_F32 = 0
+NF_F64 = 1
+IN_COMPLEX, IN_REAL64, IN_REAL32 = 0, 1, 2
+
+
+class NemoFiltError(RuntimeError):
+    pass
+
+
+_lib = None
+
+c_void_p = ctypes.c_void_p
+c_int = ctypes.c_int
+c_ll = ctypes.c_longlong
+c_double = ctypes.c_double
+c_size_t = ctypes.c_size_t
+
+# name -> (restype, argtypes); every symbol include/nemofilt.h declares
+SIGNATURES = {
+    'nf_version': (c_int, []),
+    'nf_last_error': (ctypes.c_char_p, []),
+    'nf_device_count': (c_int, []),
+    'nf_plan_create': (c_int, [c_int, c_int, ctypes.POINTER(c_void_p)]),
+    'nf_plan_destroy': (c_int, [c_void_p]),
+    'nf_fft2_forward': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    'nf_fft2_inverse': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    'nf_cross_power': (c_int, [c_int, c_void_p, c_void_p, c_int, c_ll, c_void_p]),
+    'nf_gaussian_filter': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p,
+                                   c_int, c_void_p]),
+    'nf_build_filter': (c_int, [c_int, c_int, c_void_p, c_void_p, ctypes.POINTER(c_double), c_void_p, c_int, c_ll, c_void_p]),
+    'nf_apply_filter': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_ll, c_void_p]),
+    'nf_window_mul': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    'nf_paint_radial': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_double,
+                                c_double, c_double, c_double, c_void_p]),
+    'nf_scale_mask': (c_int, [c_int, c_void_p, c_void_p, c_double, c_void_p, c_ll, c_void_p]),
+    'nf_noise_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
+    'nf_noise_map': (c_int, [c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                             c_int, c_int, ctypes.POINTER(c_double), c_int, c_void_p, c_size_t, c_void_p]),
+    'nf_median_stack': (c_int, [c_int, c_void_p, c_void_p, c_int, c_ll, c_void_p]),
+    'nf_edge_check': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    'nf_finalize': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                            c_int, c_int, c_int, c_void_p]),
+    'nf_restore_zeros': (c_int, [c_int, c_void_p, c_void_p, c_ll, c_void_p]),
+    'nf_subtract': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_ll, c_void_p]),
+    'nf_convolve2d': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
+    'nf_label_components': (c_int, [c_int, c_void_p, c_double, c_int, c_void_p, c_int, c_int, c_void_p,
+                                    ctypes.POINTER(c_int), c_void_p]),
+    'nf_object_stats': (c_int, [c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'nf_map_max': (c_int, [c_int, c_void_p, c_ll, c_void_p, c_void_p]),
+    'nf_ring_flags': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'nf_spline_eval': (c_int, [c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+}
+
+
+def load():
+    """Load libnemofilt.so (once) and declare every entry point."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NemoFiltError("HIP library %s is missing - build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                            "(make -C nemo_amd/csrc).  nemo_amd has no CPU fallback." % LIB_PATH)
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:
+        raise NemoFiltError("could not load %s: %s" % (LIB_PATH, e))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().nf_last_error()
+        raise NemoFiltError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else "?"))

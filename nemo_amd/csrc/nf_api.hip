@@ -1,0 +1,315 @@
+// extern "C" boundary of libnemofilt (declarations: include/nemofilt.h).
+#include "../../include/nemofilt.h"
+
+#include "nf_common.h"
+#include "nf_fft.h"
+#include "nf_kernels.h"
+
+#include <cmath>
+#include <cstring>
+#include <mutex>
+#include <new>
+
+static thread_local std::string g_lastError;
+
+void nf_set_error(const std::string& msg) { g_lastError = msg; }
+
+int nf_hip_fail(hipError_t e, const char* what) {
+    g_lastError = std::string(what) + ": " + hipGetErrorString(e);
+    return NF_ERR_HIP;
+}
+
+struct nf_plan {
+    int H, W;
+    bool haveF, haveD;
+    nf::Plan2D<float> pf;
+    nf::Plan2D<double> pd;
+    std::mutex mu;
+};
+
+namespace {
+
+int ensure_prec(nf_plan* p, int prec) {
+    std::lock_guard<std::mutex> lock(p->mu);
+    if (prec == NF_F32) {
+        if (!p->haveF) {
+            int rc = p->pf.init(p->H, p->W);
+            if (rc) return rc;
+            p->haveF = true;
+        }
+    } else if (prec == NF_F64) {
+        if (!p->haveD) {
+            int rc = p->pd.init(p->H, p->W);
+            if (rc) return rc;
+            p->haveD = true;
+        }
+    } else {
+        nf_set_error("precision must be NF_F32 or NF_F64");
+        return NF_ERR_ARG;
+    }
+    return NF_OK;
+}
+
+inline hipStream_t S(void* s) { return (hipStream_t)s; }
+
+}  // namespace
+
+extern "C" {
+
+int nf_version(void) { return 1; }
+
+const char* nf_last_error(void) { return g_lastError.c_str(); }
+
+int nf_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return nf_hip_fail(e, "hipGetDeviceCount");
+    return n;
+}
+
+int nf_plan_create(int H, int W, nf_plan** plan) {
+    if (!plan || H < 1 || W < 1) {
+        nf_set_error("nf_plan_create: bad arguments");
+        return NF_ERR_ARG;
+    }
+    nf_plan* p = new (std::nothrow) nf_plan();
+    if (!p) return NF_ERR_NOMEM;
+    p->H = H;
+    p->W = W;
+    p->haveF = p->haveD = false;
+    memset(&p->pf, 0, sizeof(p->pf));
+    memset(&p->pd, 0, sizeof(p->pd));
+    *plan = p;
+    return NF_OK;
+}
+
+int nf_plan_destroy(nf_plan* p) {
+    if (!p) return NF_OK;
+    if (p->haveF) p->pf.destroy();
+    if (p->haveD) p->pd.destroy();
+    delete p;
+    return NF_OK;
+}
+
+int nf_fft2_forward(nf_plan* p, int prec, const void* in, int inType, void* out, int batch, const double* apodY,
+                    const double* apodX, int unitary, void* stream) {
+    if (!p || !in || !out || batch < 1 || inType < 0 || inType > 2) {
+        nf_set_error("nf_fft2_forward: bad arguments");
+        return NF_ERR_ARG;
+    }
+    if ((apodY == nullptr) != (apodX == nullptr)) {
+        nf_set_error("nf_fft2_forward: give both apodisation tables or neither");
+        return NF_ERR_ARG;
+    }
+    int rc = ensure_prec(p, prec);
+    if (rc) return rc;
+    double scale = std::sqrt((double)p->H * (double)p->W);
+    if (prec == NF_F32) return p->pf.forward(in, inType, out, batch, apodY, apodX, unitary ? 1 : 0, scale, S(stream));
+    return p->pd.forward(in, inType, out, batch, apodY, apodX, unitary ? 1 : 0, scale, S(stream));
+}
+
+int nf_fft2_inverse(nf_plan* p, int prec, const void* in, void* work, void* out, int outType, int batch, int unitary,
+                    void* stream) {
+    if (!p || !in || !work || !out || batch < 1 || outType < 0 || outType > 2) {
+        nf_set_error("nf_fft2_inverse: bad arguments");
+        return NF_ERR_ARG;
+    }
+    int rc = ensure_prec(p, prec);
+    if (rc) return rc;
+    double scale = std::sqrt((double)p->H * (double)p->W);
+    if (prec == NF_F32) return p->pf.inverse(in, work, out, outType, batch, unitary ? 1 : 0, scale, S(stream));
+    return p->pd.inverse(in, work, out, outType, batch, unitary ? 1 : 0, scale, S(stream));
+}
+
+int nf_cross_power(int prec, const void* F, void* NP, int N, long long npix, void* stream) {
+    if (!F || !NP || N < 1 || npix < 1) {
+        nf_set_error("nf_cross_power: bad arguments");
+        return NF_ERR_ARG;
+    }
+    if (prec == NF_F32) return nf::cross_power<float>(F, NP, N, npix, S(stream));
+    return nf::cross_power<double>(F, NP, N, npix, S(stream));
+}
+
+int nf_gaussian_filter(int rtype, const void* in, void* tmp, void* out, int H, int W, int batch, const double* wY, int radY,
+                       const double* wX, int radX, void* stream) {
+    if (!in || !tmp || !out || !wY || !wX || H < 1 || W < 1 || batch < 1 || radY < 0 || radX < 0) {
+        nf_set_error("nf_gaussian_filter: bad arguments");
+        return NF_ERR_ARG;
+    }
+    return nf::gaussian_filter(rtype, in, tmp, out, H, W, batch, wY, radY, wX, radX, S(stream));
+}
+
+int nf_build_filter(int covType, int sigType, const void* cov, const void* Sg, const double* w, float* filt, int N,
+                    long long npix, void* stream) {
+    if (!cov || !Sg || !w || !filt || N < 1 || N > 6 || npix < 1) {
+        nf_set_error("nf_build_filter: bad arguments (1 <= N <= 6)");
+        return NF_ERR_ARG;
+    }
+    nf::WeightVec wv;
+    memset(&wv, 0, sizeof(wv));
+    for (int i = 0; i < N; ++i) wv.v[i] = w[i];
+    return nf::build_filter(covType, sigType, cov, Sg, wv, filt, N, npix, S(stream));
+}
+
+int nf_apply_filter(int prec, const void* F, const float* filt, void* G, int N, int sum, long long npix, void* stream) {
+    if (!F || !filt || !G || N < 1 || npix < 1) {
+        nf_set_error("nf_apply_filter: bad arguments");
+        return NF_ERR_ARG;
+    }
+    if (prec == NF_F32) return nf::apply_filter<float>(F, filt, G, N, sum, npix, S(stream));
+    return nf::apply_filter<double>(F, filt, G, N, sum, npix, S(stream));
+}
+
+int nf_window_mul(int prec, void* F, const double* wy, const double* wx, int H, int W, int batch, void* stream) {
+    if (!F || !wy || !wx || H < 1 || W < 1 || batch < 1) {
+        nf_set_error("nf_window_mul: bad arguments");
+        return NF_ERR_ARG;
+    }
+    if (prec == NF_F32) return nf::window_mul<float>(F, wy, wx, H, W, batch, S(stream));
+    return nf::window_mul<double>(F, wy, wx, H, W, batch, S(stream));
+}
+
+int nf_paint_radial(float* out, int H, int W, const double* A, const double* B, const double* C, const double* r,
+                    const double* prof, int ntab, double r0, double dlnr, double amp, double sign, void* stream) {
+    if (!out || !A || !B || !C || !r || !prof || ntab < 2 || H < 1 || W < 1 || !(dlnr > 0) || !(r0 > 0)) {
+        nf_set_error("nf_paint_radial: bad arguments");
+        return NF_ERR_ARG;
+    }
+    return nf::paint_radial(out, H, W, A, B, C, r, prof, ntab, r0, dlnr, amp, sign, S(stream));
+}
+
+int nf_scale_mask(int vtype, const float* in, void* out, double norm, const unsigned char* psMask, long long n, void* stream) {
+    if (!in || !out || n < 1) {
+        nf_set_error("nf_scale_mask: bad arguments");
+        return NF_ERR_ARG;
+    }
+    return nf::scale_mask(vtype, in, out, norm, psMask, n, S(stream));
+}
+
+size_t nf_noise_workspace_bytes(int ny, int nx, int numBins) {
+    nf::NoiseGrid g;
+    memset(&g, 0, sizeof(g));
+    g.ny = ny;
+    g.nx = nx;
+    g.numBins = numBins;
+    return nf::noise_workspace_bytes(g);
+}
+
+int nf_noise_map(int vtype, const void* filtered, const void* weights, int wtype, float* rms, int H, int W, int ny, int nx,
+                 const int* yEdges, const int* xEdges, int overlap, int numBins, const double* quantiles, int estimator,
+                 void* work, size_t workBytes, void* stream) {
+    if (!filtered || !weights || !rms || !yEdges || !xEdges || !work || ny < 1 || nx < 1 || overlap < 0 || numBins < 1 ||
+        numBins > 16 || (numBins > 1 && !quantiles)) {
+        nf_set_error("nf_noise_map: bad arguments");
+        return NF_ERR_ARG;
+    }
+    nf::NoiseGrid g;
+    memset(&g, 0, sizeof(g));
+    g.ny = ny;
+    g.nx = nx;
+    g.overlap = overlap;
+    g.numBins = numBins;
+    g.estimator = estimator;
+    g.yEdges = yEdges;
+    g.xEdges = xEdges;
+    for (int i = 0; i < numBins && quantiles; ++i) g.quantiles[i] = quantiles[i];
+    return nf::noise_map(vtype, filtered, weights, wtype, rms, H, W, g, work, workBytes, S(stream));
+}
+
+int nf_median_stack(int rtype, const void* in, void* out, int N, long long n, void* stream) {
+    if (!in || !out || N < 1 || N > 8 || n < 1) {
+        nf_set_error("nf_median_stack: bad arguments (1 <= N <= 8)");
+        return NF_ERR_ARG;
+    }
+    return nf::median_stack(rtype, in, out, N, n, S(stream));
+}
+
+int nf_edge_check(int vtype, const void* filtered, const unsigned char* psMask, unsigned char* tmp, unsigned char* out, int H,
+                  int W, int size, void* stream) {
+    if (!filtered || !tmp || !out || H < 1 || W < 1 || size < 1 || size > H || size > W) {
+        nf_set_error("nf_edge_check: bad arguments");
+        return NF_ERR_ARG;
+    }
+    return nf::edge_check(vtype, filtered, psMask, tmp, out, H, W, size, S(stream));
+}
+
+int nf_finalize(int vtype, void* filtered, const float* rms, const unsigned char* surveyMask, const unsigned char* psMask,
+                const unsigned char* edgeCheck, void* sn, float* rmsOut, unsigned char* maskOut, int H, int W, int apodPix,
+                int mulSurvey, void* stream) {
+    if (!filtered || !rms || !sn || !rmsOut || !maskOut || H < 1 || W < 1) {
+        nf_set_error("nf_finalize: bad arguments");
+        return NF_ERR_ARG;
+    }
+    return nf::finalize(vtype, filtered, rms, surveyMask, psMask, edgeCheck, sn, rmsOut, maskOut, H, W, apodPix, mulSurvey,
+                        S(stream));
+}
+
+int nf_restore_zeros(int vtype, void* data, const void* ref, long long n, void* stream) {
+    if (!data || !ref || n < 1) {
+        nf_set_error("nf_restore_zeros: bad arguments");
+        return NF_ERR_ARG;
+    }
+    return nf::restore_zeros(vtype, data, ref, n, S(stream));
+}
+
+int nf_subtract(int rtype, const void* a, const void* b, void* out, long long n, void* stream) {
+    if (!a || !b || !out || n < 1) {
+        nf_set_error("nf_subtract: bad arguments");
+        return NF_ERR_ARG;
+    }
+    return nf::subtract(rtype, a, b, out, n, S(stream));
+}
+
+int nf_convolve2d(const float* in, float* out, int H, int W, const double* kernFlipped, int kh, int kw, void* stream) {
+    if (!in || !out || !kernFlipped || H < 1 || W < 1 || kh < 1 || kw < 1 || in == out) {
+        nf_set_error("nf_convolve2d: bad arguments");
+        return NF_ERR_ARG;
+    }
+    return nf::convolve2d(in, out, H, W, kernFlipped, kh, kw, S(stream));
+}
+
+int nf_label_components(int vtype, const void* sn, double threshold, int negate, int* labels, int H, int W, int* work,
+                        int* numObjects, void* stream) {
+    if (!sn || !labels || !work || !numObjects || H < 1 || W < 1) {
+        nf_set_error("nf_label_components: bad arguments");
+        return NF_ERR_ARG;
+    }
+    return nf::label_components(vtype, sn, threshold, negate, labels, H, W, work, numObjects, S(stream));
+}
+
+int nf_object_stats(int vtype, const void* sn, int negate, const int* labels, int H, int W, int numObjects, double* stats,
+                    void* stream) {
+    if (!sn || !labels || !stats || H < 1 || W < 1 || numObjects < 0) {
+        nf_set_error("nf_object_stats: bad arguments");
+        return NF_ERR_ARG;
+    }
+    return nf::object_stats(vtype, sn, negate, labels, H, W, numObjects, stats, S(stream));
+}
+
+int nf_map_max(int vtype, const void* map, long long n, double* out, void* stream) {
+    if (!map || !out || n < 1) {
+        nf_set_error("nf_map_max: bad arguments");
+        return NF_ERR_ARG;
+    }
+    return nf::map_max(vtype, map, n, out, S(stream));
+}
+
+int nf_ring_flags(const int* ringLabels, const double* ringStats, int numRing, int minRingPix, int H, int W,
+                  unsigned char* isRing, void* stream) {
+    if (!ringLabels || !ringStats || !isRing || numRing < 0) {
+        nf_set_error("nf_ring_flags: bad arguments");
+        return NF_ERR_ARG;
+    }
+    return nf::ring_flags(ringLabels, ringStats, numRing, minRingPix, H, W, isRing, S(stream));
+}
+
+int nf_spline_eval(int vtype, const void* map, int negate, int H, int W, const double* yx, int nPts, int halfWin, double* out,
+                   void* stream) {
+    if (!map || (nPts > 0 && (!yx || !out)) || nPts < 0 || halfWin < 2) {
+        nf_set_error("nf_spline_eval: bad arguments");
+        return NF_ERR_ARG;
+    }
+    return nf::spline_eval(vtype, map, negate, H, W, yx, nPts, halfWin, out, S(stream));
+}
+
+}  // extern "C"

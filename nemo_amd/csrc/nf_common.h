@@ -1,0 +1,81 @@
+// Shared definitions for the nemofilt HIP kernels (gfx950 / MI355X only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#define NF_OK 0
+#define NF_ERR_ARG (-1)
+#define NF_ERR_HIP (-2)
+#define NF_ERR_SIZE (-3)
+#define NF_ERR_NOMEM (-4)
+
+#define NF_F32 0
+#define NF_F64 1
+
+void nf_set_error(const std::string& msg);
+int nf_hip_fail(hipError_t e, const char* what);
+
+#define NF_HIP(call)                                            \
+    do {                                                        \
+        hipError_t _e = (call);                                 \
+        if (_e != hipSuccess) return nf_hip_fail(_e, #call);    \
+    } while (0)
+
+#define NF_CHECK_LAUNCH(name)                                   \
+    do {                                                        \
+        hipError_t _e = hipGetLastError();                      \
+        if (_e != hipSuccess) return nf_hip_fail(_e, name);     \
+    } while (0)
+
+template <typename T>
+struct cpx {
+    T x, y;
+};
+template <>
+struct __attribute__((aligned(8))) cpx<float> {
+    float x, y;
+};
+template <>
+struct __attribute__((aligned(16))) cpx<double> {
+    double x, y;
+};
+
+template <typename T>
+__device__ __forceinline__ cpx<T> cmul(cpx<T> a, cpx<T> b) {
+    cpx<T> r;
+    r.x = a.x * b.x - a.y * b.y;
+    r.y = a.x * b.y + a.y * b.x;
+    return r;
+}
+template <typename T>
+__device__ __forceinline__ cpx<T> cadd(cpx<T> a, cpx<T> b) {
+    cpx<T> r;
+    r.x = a.x + b.x;
+    r.y = a.y + b.y;
+    return r;
+}
+template <typename T>
+__device__ __forceinline__ cpx<T> csub(cpx<T> a, cpx<T> b) {
+    cpx<T> r;
+    r.x = a.x - b.x;
+    r.y = a.y - b.y;
+    return r;
+}
+template <typename T>
+__device__ __forceinline__ cpx<T> cconj(cpx<T> a) {
+    cpx<T> r;
+    r.x = a.x;
+    r.y = -a.y;
+    return r;
+}
+// multiply by -i (forward DFT quarter turn)
+template <typename T>
+__device__ __forceinline__ cpx<T> cmulnegi(cpx<T> a) {
+    cpx<T> r;
+    r.x = a.y;
+    r.y = -a.x;
+    return r;
+}
+
+static inline int nf_div_up(long long a, long long b) { return (int)((a + b - 1) / b); }

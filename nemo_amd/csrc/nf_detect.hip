@@ -1,0 +1,463 @@
+// Detection kernels (K15-K17, K9): photometry.getObjectPositions / findObjects (nemo/photometry.py:59-75,
+// 81-84,128,213-248).
+//
+//  label_components  threshold (strict >) + 4-connected component labelling by union-find on pixel indices
+//                    (root = smallest raster index of the component), then consecutive numbering of the roots
+//                    in raster order - the numbering scipy.ndimage.label produces.
+//  object_stats      per label: pixel count, sum v, sum v*y, sum v*x (float64 atomics, aggregated over runs of
+//                    equal labels so a large component does not serialise on four addresses), maximum value and
+//                    the first raster position that attains it (ndimage.maximum_position).
+//  ring_flags        nemo/photometry.py:65-75: a component with > minRingPix pixels whose centre of mass does
+//                    not land on one of its own pixels is a ring.
+//  spline_eval       RectBivariateSpline(kx=ky=3, s=0)(y, x): the interpolating bicubic spline with not-a-knot
+//                    ends, evaluated from a +-halfWin pixel window (the influence of samples further away decays
+//                    as 0.268^k; at 32 pixels it is below 1e-18).  A window that touches
+//                    the true map edge applies the not-a-knot condition there, as FITPACK does.
+#include "nf_common.h"
+#include "nf_kernels.h"
+
+namespace nf {
+
+static inline int grid_for(long long n, int threads) {
+    long long g = (n + threads - 1) / threads;
+    if (g > 256 * 16) g = 256 * 16;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+template <typename VT>
+__device__ __forceinline__ bool is_fg(const VT* sn, long long p, VT thr, int negate) {
+    VT v = sn[p];
+    if (negate) v = v * (VT)-1;
+    return v > thr;
+}
+
+template <typename VT>
+__global__ void k_ccl_init(const VT* __restrict__ sn, VT thr, int negate, int* __restrict__ parent, long long n) {
+    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x)
+        parent[p] = is_fg<VT>(sn, p, thr, negate) ? (int)p : -1;
+}
+
+__device__ __forceinline__ int uf_find(const int* parent, int x) {
+    int p = parent[x];
+    while (p != x) {
+        x = p;
+        p = parent[x];
+    }
+    return x;
+}
+
+__device__ __forceinline__ void uf_union(int* parent, int a, int b) {
+    while (true) {
+        a = uf_find(parent, a);
+        b = uf_find(parent, b);
+        if (a == b) return;
+        if (a < b) {
+            int t = a;
+            a = b;
+            b = t;
+        }
+        int old = atomicMin(&parent[a], b);   // link the larger root under the smaller index
+        if (old == a) return;
+        a = old;
+    }
+}
+
+__global__ void k_ccl_merge(int* __restrict__ parent, int H, int W) {
+    const long long n = (long long)H * W;
+    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x) {
+        if (parent[p] < 0) continue;
+        int x = (int)(p % W);
+        if (x > 0 && parent[p - 1] >= 0) uf_union(parent, (int)p, (int)(p - 1));
+        if (p >= W && parent[p - W] >= 0) uf_union(parent, (int)p, (int)(p - W));
+    }
+}
+
+__global__ void k_ccl_flatten(int* __restrict__ parent, long long n) {
+    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x)
+        if (parent[p] >= 0) parent[p] = uf_find(parent, (int)p);
+}
+
+#define NF_SCAN_CHUNK 1024   // pixels per workgroup in the root-numbering passes (256 threads x 4)
+
+__global__ void k_count_roots(const int* __restrict__ parent, long long n, int* __restrict__ blockCounts) {
+    __shared__ int red[4];
+    long long base = (long long)blockIdx.x * NF_SCAN_CHUNK;
+    int c = 0;
+    for (int j = 0; j < 4; ++j) {
+        long long p = base + threadIdx.x * 4 + j;
+        if (p < n && parent[p] == (int)p) ++c;
+    }
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) blockCounts[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// exclusive scan of blockCounts (single workgroup, chunked); total written to blockCounts[nblocks]
+__global__ void k_scan_counts(int* __restrict__ blockCounts, int nblocks) {
+    __shared__ int tmp[1024];
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < nblocks; base += 1024) {
+        int i = base + threadIdx.x;
+        int v = (i < nblocks) ? blockCounts[i] : 0;
+        tmp[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            int t = (threadIdx.x >= off) ? tmp[threadIdx.x - off] : 0;
+            __syncthreads();
+            tmp[threadIdx.x] += t;
+            __syncthreads();
+        }
+        int incl = tmp[threadIdx.x];
+        if (i < nblocks) blockCounts[i] = carry + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) blockCounts[nblocks] = carry;
+}
+
+__global__ void k_number_roots(const int* __restrict__ parent, long long n, const int* __restrict__ blockOffsets,
+                               int* __restrict__ labels) {
+    __shared__ int waveTot[4];
+    long long base = (long long)blockIdx.x * NF_SCAN_CHUNK;
+    int flags[4], c = 0;
+    for (int j = 0; j < 4; ++j) {
+        long long p = base + threadIdx.x * 4 + j;
+        flags[j] = (p < n && parent[p] == (int)p) ? 1 : 0;
+        c += flags[j];
+    }
+    // exclusive prefix of c over the workgroup: wave scan + wave totals
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = c;
+    for (int off = 1; off < 64; off <<= 1) {
+        int t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) waveTot[wave] = incl;
+    __syncthreads();
+    int pre = incl - c;
+    for (int w = 0; w < wave; ++w) pre += waveTot[w];
+    int id = blockOffsets[blockIdx.x] + pre;
+    for (int j = 0; j < 4; ++j) {
+        long long p = base + threadIdx.x * 4 + j;
+        if (p < n && flags[j]) labels[p] = ++id;   // ids start at 1
+    }
+}
+
+__global__ void k_relabel(const int* __restrict__ parent, int* __restrict__ labels, long long n) {
+    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x) {
+        int r = parent[p];
+        if (r < 0)
+            labels[p] = 0;
+        else if (r != (int)p)
+            labels[p] = labels[r];
+    }
+}
+
+int label_components(int vtype, const void* sn, double threshold, int negate, int* labels, int H, int W, int* work,
+                     int* numObjects, hipStream_t s) {
+    const long long n = (long long)H * W;
+    if (n >= 2147483647LL) {
+        nf_set_error("label_components: map too large for 32-bit pixel indices");
+        return NF_ERR_SIZE;
+    }
+    int* parent = work;
+    const int nblocks = nf_div_up(n, NF_SCAN_CHUNK);
+    int* blockCounts = work + n;
+    dim3 g(grid_for(n, 256)), b(256);
+    if (vtype == NF_F64)
+        hipLaunchKernelGGL(k_ccl_init<double>, g, b, 0, s, (const double*)sn, threshold, negate, parent, n);
+    else  // a Python-float threshold compared against a float32 map is cast to float32 by numpy
+        hipLaunchKernelGGL(k_ccl_init<float>, g, b, 0, s, (const float*)sn, (float)threshold, negate, parent, n);
+    hipLaunchKernelGGL(k_ccl_merge, g, b, 0, s, parent, H, W);
+    hipLaunchKernelGGL(k_ccl_flatten, g, b, 0, s, parent, n);
+    hipLaunchKernelGGL(k_count_roots, dim3(nblocks), dim3(256), 0, s, parent, n, blockCounts);
+    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, s, blockCounts, nblocks);
+    hipLaunchKernelGGL(k_number_roots, dim3(nblocks), dim3(256), 0, s, parent, n, blockCounts, labels);
+    hipLaunchKernelGGL(k_relabel, g, b, 0, s, parent, labels, n);
+    NF_CHECK_LAUNCH("label_components");
+    NF_HIP(hipMemcpyAsync(numObjects, blockCounts + nblocks, sizeof(int), hipMemcpyDeviceToHost, s));
+    NF_HIP(hipStreamSynchronize(s));
+    return NF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// stats layout per label id (0 .. numObjects): [0] count [1] sum v [2] sum v*y [3] sum v*x [4] max v [5] argmax (raster)
+#define NF_STAT_STRIDE 6
+#define NF_RUN 8
+
+__device__ __forceinline__ void flush_run(double* stats, int id, double cnt, double sv, double svy, double svx) {
+    double* r = stats + (long long)id * NF_STAT_STRIDE;
+    unsafeAtomicAdd(&r[0], cnt);
+    unsafeAtomicAdd(&r[1], sv);
+    unsafeAtomicAdd(&r[2], svy);
+    unsafeAtomicAdd(&r[3], svx);
+}
+
+__device__ __forceinline__ unsigned long long ordered_key(double v) {
+    unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    return (b & 0x8000000000000000ULL) ? ~b : (b | 0x8000000000000000ULL);
+}
+
+template <typename VT>
+__global__ void k_object_sums(const VT* __restrict__ sn, int negate, const int* __restrict__ labels, int H, int W,
+                              double* __restrict__ stats, unsigned long long* __restrict__ maxKey) {
+    const int segsPerRow = (W + NF_RUN - 1) / NF_RUN;
+    const long long nseg = (long long)H * segsPerRow;
+    for (long long sidx = blockIdx.x * (long long)blockDim.x + threadIdx.x; sidx < nseg; sidx += (long long)gridDim.x * blockDim.x) {
+        int y = (int)(sidx / segsPerRow);
+        int x0 = (int)(sidx % segsPerRow) * NF_RUN;
+        int cur = 0;
+        double cnt = 0, sv = 0, svy = 0, svx = 0, mx = 0;
+        for (int j = 0; j < NF_RUN && x0 + j < W; ++j) {
+            long long p = (long long)y * W + x0 + j;
+            int id = labels[p];
+            if (id != cur) {
+                if (cur > 0) {
+                    flush_run(stats, cur, cnt, sv, svy, svx);
+                    atomicMax(&maxKey[cur], ordered_key(mx));
+                }
+                cur = id;
+                cnt = sv = svy = svx = 0;
+                mx = -INFINITY;
+            }
+            if (id > 0) {
+                double v = (double)sn[p];
+                if (negate) v = -v;
+                cnt += 1.0;
+                sv += v;
+                svy += v * (double)y;       // input * grid (float64), as ndimage.center_of_mass forms it
+                svx += v * (double)(x0 + j);
+                mx = fmax(mx, v);
+            }
+        }
+        if (cur > 0) {
+            flush_run(stats, cur, cnt, sv, svy, svx);
+            atomicMax(&maxKey[cur], ordered_key(mx));
+        }
+    }
+}
+
+template <typename VT>
+__global__ void k_object_argmax(const VT* __restrict__ sn, int negate, const int* __restrict__ labels, long long n,
+                                const unsigned long long* __restrict__ maxKey, unsigned long long* __restrict__ argmax) {
+    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x) {
+        int id = labels[p];
+        if (id <= 0) continue;
+        double v = (double)sn[p];
+        if (negate) v = -v;
+        if (ordered_key(v) == maxKey[id]) atomicMin(&argmax[id], (unsigned long long)p);
+    }
+}
+
+__global__ void k_stats_finish(double* __restrict__ stats, const unsigned long long* __restrict__ maxKey,
+                               const unsigned long long* __restrict__ argmax, int numObjects) {
+    for (int id = blockIdx.x * blockDim.x + threadIdx.x; id <= numObjects; id += gridDim.x * blockDim.x) {
+        unsigned long long k = maxKey[id];
+        unsigned long long b = (k & 0x8000000000000000ULL) ? (k & 0x7FFFFFFFFFFFFFFFULL) : ~k;
+        stats[(long long)id * NF_STAT_STRIDE + 4] = __longlong_as_double((long long)b);
+        stats[(long long)id * NF_STAT_STRIDE + 5] = (double)argmax[id];
+    }
+}
+
+// `stats` must hold (numObjects+1) * 6 doubles followed by 2 * (numObjects+1) uint64 of scratch
+int object_stats(int vtype, const void* sn, int negate, const int* labels, int H, int W, int numObjects, double* stats,
+                 hipStream_t s) {
+    const long long n = (long long)H * W;
+    const size_t nrec = (size_t)numObjects + 1;
+    unsigned long long* maxKey = (unsigned long long*)(stats + nrec * NF_STAT_STRIDE);
+    unsigned long long* argmax = maxKey + nrec;
+    NF_HIP(hipMemsetAsync(stats, 0, nrec * NF_STAT_STRIDE * sizeof(double) + nrec * sizeof(unsigned long long), s));
+    NF_HIP(hipMemsetAsync(argmax, 0xFF, nrec * sizeof(unsigned long long), s));
+    const long long nseg = (long long)H * ((W + NF_RUN - 1) / NF_RUN);
+    dim3 g(grid_for(nseg, 256)), b(256), gp(grid_for(n, 256));
+    if (vtype == NF_F64) {
+        hipLaunchKernelGGL(k_object_sums<double>, g, b, 0, s, (const double*)sn, negate, labels, H, W, stats, maxKey);
+        hipLaunchKernelGGL(k_object_argmax<double>, gp, b, 0, s, (const double*)sn, negate, labels, n, maxKey, argmax);
+    } else {
+        hipLaunchKernelGGL(k_object_sums<float>, g, b, 0, s, (const float*)sn, negate, labels, H, W, stats, maxKey);
+        hipLaunchKernelGGL(k_object_argmax<float>, gp, b, 0, s, (const float*)sn, negate, labels, n, maxKey, argmax);
+    }
+    hipLaunchKernelGGL(k_stats_finish, dim3(grid_for(nrec, 256)), dim3(256), 0, s, stats, maxKey, argmax, numObjects);
+    NF_CHECK_LAUNCH("object_stats");
+    return NF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// np.argmax / ndarray.max of a whole map (nemo/filters.py:661,684): maximum value and FIRST raster index attaining it.
+template <typename VT>
+__global__ void k_map_max(const VT* __restrict__ m, long long n, unsigned long long* __restrict__ key) {
+    double best = -INFINITY;
+    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x)
+        best = fmax(best, (double)m[p]);
+    for (int off = 32; off > 0; off >>= 1) best = fmax(best, __shfl_down(best, off, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(key, ordered_key(best));
+}
+template <typename VT>
+__global__ void k_map_argmax(const VT* __restrict__ m, long long n, const unsigned long long* __restrict__ key,
+                             unsigned long long* __restrict__ arg) {
+    const unsigned long long k = *key;
+    unsigned long long best = 0xFFFFFFFFFFFFFFFFULL;
+    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x)
+        if (ordered_key((double)m[p]) == k && (unsigned long long)p < best) best = (unsigned long long)p;
+    if (best != 0xFFFFFFFFFFFFFFFFULL) atomicMin(arg, best);
+}
+__global__ void k_map_max_finish(double* out) {
+    unsigned long long k = ((unsigned long long*)out)[2];
+    unsigned long long b = (k & 0x8000000000000000ULL) ? (k & 0x7FFFFFFFFFFFFFFFULL) : ~k;
+    out[0] = __longlong_as_double((long long)b);
+    out[1] = (double)((unsigned long long*)out)[3];
+}
+
+// out: 4 doubles on the device: [0] max value, [1] first index of the max, [2..3] scratch
+int map_max(int vtype, const void* m, long long n, double* out, hipStream_t s) {
+    unsigned long long* key = (unsigned long long*)out + 2;
+    unsigned long long* arg = key + 1;
+    NF_HIP(hipMemsetAsync(key, 0, sizeof(unsigned long long), s));
+    NF_HIP(hipMemsetAsync(arg, 0xFF, sizeof(unsigned long long), s));
+    dim3 g(grid_for(n, 256)), b(256);
+    if (vtype == NF_F64) {
+        hipLaunchKernelGGL(k_map_max<double>, g, b, 0, s, (const double*)m, n, key);
+        hipLaunchKernelGGL(k_map_argmax<double>, g, b, 0, s, (const double*)m, n, key, arg);
+    } else {
+        hipLaunchKernelGGL(k_map_max<float>, g, b, 0, s, (const float*)m, n, key);
+        hipLaunchKernelGGL(k_map_argmax<float>, g, b, 0, s, (const float*)m, n, key, arg);
+    }
+    hipLaunchKernelGGL(k_map_max_finish, dim3(1), dim3(1), 0, s, out);
+    NF_CHECK_LAUNCH("map_max");
+    return NF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+__global__ void k_ring_flags(const int* __restrict__ ringLabels, const double* __restrict__ ringStats, int numRing, int minRingPix,
+                             int H, int W, unsigned char* __restrict__ isRing) {
+    for (int id = blockIdx.x * blockDim.x + threadIdx.x; id <= numRing; id += gridDim.x * blockDim.x) {
+        unsigned char flag = 0;
+        if (id > 0) {
+            const double* r = ringStats + (long long)id * NF_STAT_STRIDE;
+            if (r[0] > (double)minRingPix) {
+                double y = r[2] / r[1], x = r[3] / r[1];
+                int iy = (int)y, ix = (int)x;   // Python int(): truncation
+                if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+                    if (ringLabels[(long long)iy * W + ix] != id) flag = 1;
+                }
+            }
+        }
+        isRing[id] = flag;
+    }
+}
+
+int ring_flags(const int* ringLabels, const double* ringStats, int numRing, int minRingPix, int H, int W, unsigned char* isRing,
+               hipStream_t s) {
+    hipLaunchKernelGGL(k_ring_flags, dim3(grid_for(numRing + 1, 256)), dim3(256), 0, s, ringLabels, ringStats, numRing, minRingPix,
+                       H, W, isRing);
+    NF_CHECK_LAUNCH("k_ring_flags");
+    return NF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// 1-D not-a-knot cubic spline through n >= 4 unit-spaced samples y[0..n-1] (stride `st`), evaluated at
+// position u in [0, n-1].  Second derivatives M: M_1 = d_1/6 and M_{n-2} = d_{n-2}/6 follow directly from the
+// not-a-knot conditions on a uniform grid; the interior is a constant (1,4,1) tridiagonal system.
+__device__ double nak_spline_eval(const double* y, int st, int n, double u, double* work /* n doubles */, const double* cp) {
+    // d_i = 6 (y_{i-1} - 2 y_i + y_{i+1})
+    auto d = [&](int i) { return 6.0 * (y[(i - 1) * st] - 2.0 * y[i * st] + y[(i + 1) * st]); };
+    double* M = work;
+    M[1] = d(1) / 6.0;
+    M[n - 2] = d(n - 2) / 6.0;
+    if (n > 4) {
+        // forward sweep over i = 2 .. n-3, cp[k] = modified super-diagonal for the k-th interior row
+        double prev = 0.0;
+        for (int i = 2; i <= n - 3; ++i) {
+            double rhs = d(i);
+            if (i == 2) rhs -= M[1];
+            if (i == n - 3) rhs -= M[n - 2];
+            int k = i - 2;
+            double denom = (k == 0) ? 4.0 : 4.0 - cp[k - 1];
+            double val = (k == 0) ? rhs / denom : (rhs - prev) / denom;
+            M[i] = val;
+            prev = val;
+        }
+        for (int i = n - 4; i >= 2; --i) M[i] -= cp[i - 2] * M[i + 1];
+    }
+    M[0] = 2.0 * M[1] - M[2];
+    M[n - 1] = 2.0 * M[n - 2] - M[n - 3];
+    int i = (int)floor(u);
+    if (i < 0) i = 0;
+    if (i > n - 2) i = n - 2;
+    double t = u - (double)i, t1 = 1.0 - t;
+    double y0 = y[i * st], y1 = y[(i + 1) * st];
+    return M[i] * t1 * t1 * t1 / 6.0 + M[i + 1] * t * t * t / 6.0 + (y0 - M[i] / 6.0) * t1 + (y1 - M[i + 1] / 6.0) * t;
+}
+
+#define NF_SPL_MAXN 72
+
+template <typename VT>
+__global__ void k_spline_eval(const VT* __restrict__ map, int negate, int H, int W, const double* __restrict__ yx, int halfWin,
+                              double* __restrict__ out) {
+    extern __shared__ __align__(16) unsigned char nf_smem[];
+    double* win = (double*)nf_smem;                         // [ny][nxp]
+    const double py = yx[2 * blockIdx.x], px = yx[2 * blockIdx.x + 1];
+    int iy = (int)floor(py), ix = (int)floor(px);
+    int y0 = max(0, iy - halfWin), y1 = min(H - 1, iy + 1 + halfWin);
+    int x0 = max(0, ix - halfWin), x1 = min(W - 1, ix + 1 + halfWin);
+    const int ny = y1 - y0 + 1, nx = x1 - x0 + 1;
+    const int nxp = nx + 1;
+    double* mwork = win + NF_SPL_MAXN * (NF_SPL_MAXN + 1);   // [ny][nxp] second-derivative scratch
+    double* colv = mwork + NF_SPL_MAXN * (NF_SPL_MAXN + 1);  // [ny]
+    double* cp = colv + NF_SPL_MAXN;                         // [NF_SPL_MAXN]
+    if (!(py >= 0.0 && py <= (double)(H - 1) && px >= 0.0 && px <= (double)(W - 1)) || ny < 4 || nx < 4) {
+        if (threadIdx.x == 0) out[blockIdx.x] = nan("");
+        return;
+    }
+    for (int i = threadIdx.x; i < ny * nx; i += blockDim.x) {
+        int r = i / nx, c = i % nx;
+        double v = (double)map[(long long)(y0 + r) * W + x0 + c];
+        win[r * nxp + c] = negate ? -v : v;
+    }
+    if (threadIdx.x == 0) {
+        double c = 0.25;
+        cp[0] = c;
+        for (int k = 1; k < NF_SPL_MAXN; ++k) {
+            c = 1.0 / (4.0 - c);
+            cp[k] = c;
+        }
+    }
+    __syncthreads();
+    for (int r = threadIdx.x; r < ny; r += blockDim.x)
+        colv[r] = nak_spline_eval(win + r * nxp, 1, nx, px - (double)x0, mwork + r * nxp, cp);
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = nak_spline_eval(colv, 1, ny, py - (double)y0, mwork, cp);
+}
+
+int spline_eval(int vtype, const void* map, int negate, int H, int W, const double* yx, int nPts, int halfWin, double* out,
+                hipStream_t s) {
+    if (nPts <= 0) return NF_OK;
+    if (2 * halfWin + 2 > NF_SPL_MAXN) {
+        nf_set_error("spline_eval: window too large");
+        return NF_ERR_ARG;
+    }
+    size_t lds = (size_t)(2 * NF_SPL_MAXN * (NF_SPL_MAXN + 1) + 2 * NF_SPL_MAXN) * sizeof(double);
+    static bool attr[2] = {false, false};
+    if (vtype == NF_F64) {
+        if (!attr[1]) {
+            NF_HIP(hipFuncSetAttribute((const void*)k_spline_eval<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr[1] = true;
+        }
+        hipLaunchKernelGGL(k_spline_eval<double>, dim3(nPts), dim3(128), lds, s, (const double*)map, negate, H, W, yx, halfWin, out);
+    } else {
+        if (!attr[0]) {
+            NF_HIP(hipFuncSetAttribute((const void*)k_spline_eval<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr[0] = true;
+        }
+        hipLaunchKernelGGL(k_spline_eval<float>, dim3(nPts), dim3(128), lds, s, (const float*)map, negate, H, W, yx, halfWin, out);
+    }
+    NF_CHECK_LAUNCH("k_spline_eval");
+    return NF_OK;
+}
+
+}  // namespace nf

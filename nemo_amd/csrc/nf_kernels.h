@@ -1,0 +1,62 @@
+// Internal C++ declarations of the non-FFT kernels' host launchers.
+#pragma once
+#include "nf_common.h"
+
+namespace nf {
+
+struct WeightVec {
+    double v[8];
+};
+
+// nf_pointwise.hip
+template <typename T>
+int cross_power(const void* F, void* NP, int N, long long npix, hipStream_t s);
+int build_filter(int covType, int sigType, const void* cov, const void* S, const WeightVec& w, float* filt, int N,
+                 long long npix, hipStream_t s);
+template <typename T>
+int apply_filter(const void* F, const float* filt, void* G, int N, int sum, long long npix, hipStream_t s);
+template <typename T>
+int window_mul(void* F, const double* wy, const double* wx, int H, int W, int batch, hipStream_t s);
+int paint_radial(float* out, int H, int W, const double* A, const double* B, const double* C, const double* r,
+                 const double* prof, int ntab, double r0, double dlnr, double amp, double sign, hipStream_t s);
+int scale_mask(int vtype, const float* in, void* out, double norm, const unsigned char* psMask, long long n, hipStream_t s);
+int finalize(int vtype, void* filtered, const float* rms, const unsigned char* surveyMask, const unsigned char* psMask,
+             const unsigned char* edgeCheck, void* snOut, float* rmsOut, unsigned char* maskOut, int H, int W, int apodPix,
+             int mulSurvey, hipStream_t s);
+int restore_zeros(int vtype, void* data, const void* ref, long long n, hipStream_t s);
+
+// nf_stencil.hip
+int gaussian_filter(int rtype, const void* in, void* tmp, void* out, int H, int W, int batch, const double* wY, int radY,
+                    const double* wX, int radX, hipStream_t s);
+int subtract(int rtype, const void* a, const void* b, void* out, long long n, hipStream_t s);
+int convolve2d(const float* in, float* out, int H, int W, const double* kernFlipped, int kh, int kw, hipStream_t s);
+int edge_check(int vtype, const void* filtered, const unsigned char* psMask, unsigned char* tmp, unsigned char* out, int H, int W,
+               int size, hipStream_t s);
+
+// nf_noise.hip
+struct NoiseGrid {
+    int ny, nx;          // number of cells per axis
+    int overlap;         // pixels added on each side of a cell
+    int numBins;
+    int estimator;       // 0: 3-sigma clipped std, 1: 68.3 percentile of |v|
+    const int* yEdges;   // device, ny+1
+    const int* xEdges;   // device, nx+1
+    double quantiles[16];  // percentile/100 of the lower edge of each weight bin (np.arange(0,100,100/numBins)/100)
+};
+int noise_map(int vtype, const void* filtered, const void* weights, int wtype, float* rms, int H, int W, const NoiseGrid& g,
+              void* cellStats, size_t cellStatsBytes, hipStream_t s);
+size_t noise_workspace_bytes(const NoiseGrid& g);
+int median_stack(int rtype, const void* in, void* out, int N, long long n, hipStream_t s);
+
+// nf_detect.hip
+int label_components(int vtype, const void* sn, double threshold, int negate, int* labels, int H, int W, int* work,
+                     int* numObjects, hipStream_t s);
+int object_stats(int vtype, const void* sn, int negate, const int* labels, int H, int W, int numObjects, double* stats,
+                 hipStream_t s);
+int map_max(int vtype, const void* m, long long n, double* out, hipStream_t s);
+int ring_flags(const int* ringLabels, const double* ringStats, int numRing, int minRingPix, int H, int W, unsigned char* isRing,
+               hipStream_t s);
+int spline_eval(int vtype, const void* map, int negate, int H, int W, const double* yx, int nPts, int halfWin, double* out,
+                hipStream_t s);
+
+}  // namespace nf

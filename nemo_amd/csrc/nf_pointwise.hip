@@ -1,0 +1,392 @@
+// Pointwise (per-pixel / per-Fourier-mode) kernels of the filter build and apply path.
+// All are single-pass streaming kernels: grid-stride loops, coalesced accesses, no LDS.
+//
+//  k_cross_power   K4   nemo/filters.py:573      NP_ij = Re(F_i conj F_j)
+//  k_build_filter  K6   nemo/filters.py:621-627  filt[:,k] = inv(noiseCov[:,:,k]) . (w |S[:,k]|)  -> float32
+//  k_apply_filter  K7   nemo/filters.py:847      G = sum_i F_i * filt_i   (sum moved before the IFFT by linearity)
+//  k_window_mul    K8   pixell enmap.apply_window (nemo/filters.py:100,644)
+//  k_paint_radial  K20  stands in for pixell sim_objects (nemo/signals.py:681,691)
+//  k_scale_mask         nemo/filters.py:853,714  filtered * signalNorm * psMask
+//  k_finalize      K11  nemo/filters.py:717-756 / :1112-1157
+#include "nf_common.h"
+#include "nf_kernels.h"
+
+namespace nf {
+
+static inline int grid_for(long long n, int threads) {
+    long long g = (n + threads - 1) / threads;
+    if (g > 256 * 16) g = 256 * 16;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void k_cross_power(const cpx<T>* __restrict__ F, T* __restrict__ NP, int N, long long npix) {
+    // NP layout [N][N][npix]; only j >= i computed, mirrored (the product is commutative bit for bit)
+    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < npix; p += (long long)gridDim.x * blockDim.x) {
+        for (int i = 0; i < N; ++i) {
+            cpx<T> a = F[(long long)i * npix + p];
+            for (int j = i; j < N; ++j) {
+                cpx<T> b = F[(long long)j * npix + p];
+                // np.real(a * conj(b)) = a.x*b.x + a.y*b.y, evaluated as numpy does: two products, one add
+                T v = a.x * b.x + a.y * b.y;
+                NP[((long long)i * N + j) * npix + p] = v;
+                if (j != i) NP[((long long)j * N + i) * npix + p] = v;
+            }
+        }
+    }
+}
+
+template <typename T>
+int cross_power(const void* F, void* NP, int N, long long npix, hipStream_t s) {
+    hipLaunchKernelGGL(k_cross_power<T>, dim3(grid_for(npix, 256)), dim3(256), 0, s, (const cpx<T>*)F, (T*)NP, N, npix);
+    NF_CHECK_LAUNCH("k_cross_power");
+    return NF_OK;
+}
+template int cross_power<float>(const void*, void*, int, long long, hipStream_t);
+template int cross_power<double>(const void*, void*, int, long long, hipStream_t);
+
+// ---------------------------------------------------------------------------------------------------
+// N x N inverse by LU with partial pivoting in the covariance precision T (np.linalg.inv -> LAPACK gesv),
+// then a float64 matrix-vector product with w*|S| (numpy promotes the f32 inverse to f64 in np.dot),
+// stored as float32.  A singular pivot leaves the mode at zero, like the reference's try/except.
+template <typename T, typename TS, int N>
+__global__ void k_build_filter(const T* __restrict__ cov, const cpx<TS>* __restrict__ S, nf::WeightVec w,
+                               float* __restrict__ filt, long long npix) {
+    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < npix; p += (long long)gridDim.x * blockDim.x) {
+        double rhs[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            cpx<TS> s = S[(long long)i * npix + p];
+            // np.abs(complex) = hypot; computed in the template precision TS, then promoted
+            TS mag = (sizeof(TS) == 4) ? (TS)hypotf((float)s.x, (float)s.y) : (TS)hypot((double)s.x, (double)s.y);
+            rhs[i] = w.v[i] * (double)mag;
+        }
+        float out[N];
+        if (N == 1) {
+            T a = cov[p];
+            if (a == (T)0) {
+                out[0] = 0.0f;
+            } else {
+                T inv = (T)1 / a;
+                out[0] = (float)((double)inv * rhs[0]);
+            }
+        } else {
+            T A[N][N], B[N][N];
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    A[i][j] = cov[((long long)i * N + j) * npix + p];
+                    B[i][j] = (i == j) ? (T)1 : (T)0;
+                }
+            bool singular = false;
+#pragma unroll
+            for (int c = 0; c < N; ++c) {
+                int piv = c;
+                T best = fabs(A[c][c]);
+#pragma unroll
+                for (int r = c + 1; r < N; ++r) {
+                    T v = fabs(A[r][c]);
+                    if (v > best) {
+                        best = v;
+                        piv = r;
+                    }
+                }
+                if (best == (T)0) singular = true;
+#pragma unroll
+                for (int r = c + 1; r < N; ++r) {
+                    if (r == piv) {
+#pragma unroll
+                        for (int j = 0; j < N; ++j) {
+                            T t = A[c][j];
+                            A[c][j] = A[r][j];
+                            A[r][j] = t;
+                            t = B[c][j];
+                            B[c][j] = B[r][j];
+                            B[r][j] = t;
+                        }
+                    }
+                }
+                T rp = (T)1 / A[c][c];
+#pragma unroll
+                for (int r = c + 1; r < N; ++r) {
+                    T f = A[r][c] * rp;
+#pragma unroll
+                    for (int j = 0; j < N; ++j) {
+                        if (j > c) A[r][j] -= f * A[c][j];
+                        B[r][j] -= f * B[c][j];
+                    }
+                }
+            }
+            // back substitution: X = U^-1 (L^-1 P I)
+#pragma unroll
+            for (int c = N - 1; c >= 0; --c) {
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    T v = B[c][j];
+#pragma unroll
+                    for (int k = c + 1; k < N; ++k) v -= A[c][k] * B[k][j];
+                    B[c][j] = v / A[c][c];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                double acc = 0.0;
+#pragma unroll
+                for (int j = 0; j < N; ++j) acc += (double)B[i][j] * rhs[j];
+                out[i] = singular ? 0.0f : (float)acc;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < N; ++i) filt[(long long)i * npix + p] = out[i];
+    }
+}
+
+template <typename T, typename TS>
+static int build_filter_n(const void* cov, const void* S, const WeightVec& w, float* filt, int N, long long npix, hipStream_t s) {
+    dim3 g(grid_for(npix, 256)), b(256);
+#define NF_BF(NN)                                                                                                   \
+    case NN:                                                                                                        \
+        hipLaunchKernelGGL((k_build_filter<T, TS, NN>), g, b, 0, s, (const T*)cov, (const cpx<TS>*)S, w, filt, npix); \
+        break;
+    switch (N) {
+        NF_BF(1)
+        NF_BF(2)
+        NF_BF(3)
+        NF_BF(4)
+        NF_BF(5)
+        NF_BF(6)
+        default:
+            nf_set_error("build_filter supports 1..6 frequencies");
+            return NF_ERR_ARG;
+    }
+#undef NF_BF
+    NF_CHECK_LAUNCH("k_build_filter");
+    return NF_OK;
+}
+
+int build_filter(int covType, int sigType, const void* cov, const void* S, const WeightVec& w, float* filt, int N,
+                 long long npix, hipStream_t s) {
+    if (covType == NF_F64 && sigType == NF_F32) return build_filter_n<double, float>(cov, S, w, filt, N, npix, s);
+    if (covType == NF_F64 && sigType == NF_F64) return build_filter_n<double, double>(cov, S, w, filt, N, npix, s);
+    if (covType == NF_F32 && sigType == NF_F32) return build_filter_n<float, float>(cov, S, w, filt, N, npix, s);
+    if (covType == NF_F32 && sigType == NF_F64) return build_filter_n<float, double>(cov, S, w, filt, N, npix, s);
+    nf_set_error("build_filter: bad dtype");
+    return NF_ERR_ARG;
+}
+
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void k_apply_filter(const cpx<T>* __restrict__ F, const float* __restrict__ filt, cpx<T>* __restrict__ G, int N,
+                               int sum, long long npix) {
+    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < npix; p += (long long)gridDim.x * blockDim.x) {
+        if (sum) {
+            T re = 0, im = 0;
+            for (int i = 0; i < N; ++i) {
+                cpx<T> f = F[(long long)i * npix + p];
+                T h = (T)filt[(long long)i * npix + p];
+                re += f.x * h;
+                im += f.y * h;
+            }
+            cpx<T> g;
+            g.x = re;
+            g.y = im;
+            G[p] = g;
+        } else {
+            for (int i = 0; i < N; ++i) {
+                cpx<T> f = F[(long long)i * npix + p];
+                T h = (T)filt[(long long)i * npix + p];
+                cpx<T> g;
+                g.x = f.x * h;
+                g.y = f.y * h;
+                G[(long long)i * npix + p] = g;
+            }
+        }
+    }
+}
+
+template <typename T>
+int apply_filter(const void* F, const float* filt, void* G, int N, int sum, long long npix, hipStream_t s) {
+    hipLaunchKernelGGL(k_apply_filter<T>, dim3(grid_for(npix, 256)), dim3(256), 0, s, (const cpx<T>*)F, filt, (cpx<T>*)G, N,
+                       sum, npix);
+    NF_CHECK_LAUNCH("k_apply_filter");
+    return NF_OK;
+}
+template int apply_filter<float>(const void*, const float*, void*, int, int, long long, hipStream_t);
+template int apply_filter<double>(const void*, const float*, void*, int, int, long long, hipStream_t);
+
+// ---------------------------------------------------------------------------------------------------
+// F[b][y][x] *= wy[y] * wx[x]   (window tables already raised to the requested power on the host, as
+// enmap.apply_window does: wy[:,None]**pow * wx[None,:]**pow, product formed first, in float64)
+template <typename T>
+__global__ void k_window_mul(cpx<T>* __restrict__ F, const double* __restrict__ wy, const double* __restrict__ wx, int H,
+                             int W, int batch) {
+    long long n = (long long)H * W * batch;
+    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x) {
+        long long q = p % ((long long)H * W);
+        int y = (int)(q / W), x = (int)(q % W);
+        double win = wy[y] * wx[x];
+        cpx<T> f = F[p];
+        // numpy in-place complex *= float64: computed in complex128, cast back to T
+        f.x = (T)((double)f.x * win);
+        f.y = (T)((double)f.y * win);
+        F[p] = f;
+    }
+}
+
+template <typename T>
+int window_mul(void* F, const double* wy, const double* wx, int H, int W, int batch, hipStream_t s) {
+    hipLaunchKernelGGL(k_window_mul<T>, dim3(grid_for((long long)H * W * batch, 256)), dim3(256), 0, s, (cpx<T>*)F, wy, wx, H,
+                       W, batch);
+    NF_CHECK_LAUNCH("k_window_mul");
+    return NF_OK;
+}
+template int window_mul<float>(void*, const double*, const double*, int, int, int, hipStream_t);
+template int window_mul<double>(void*, const double*, const double*, int, int, int, hipStream_t);
+
+// ---------------------------------------------------------------------------------------------------
+// Radial template painter.  hav = A[y] + B[y]*C[x]; theta = 2 asin(sqrt(hav)) by its series to h^5 (only
+// + * sqrt, with explicitly unfused roundings so the result is bit-identical to the numpy statement);
+// linear interpolation on the log-uniform table r[], prof[].
+__device__ __forceinline__ double theta_from_hav(double h) {
+    double s = __dsqrt_rn(h);
+    double poly = 945.0 / 42240.0;
+    poly = __dadd_rn(__dmul_rn(poly, h), 105.0 / 3456.0);
+    poly = __dadd_rn(__dmul_rn(poly, h), 15.0 / 336.0);
+    poly = __dadd_rn(__dmul_rn(poly, h), 3.0 / 40.0);
+    poly = __dadd_rn(__dmul_rn(poly, h), 1.0 / 6.0);
+    poly = __dadd_rn(__dmul_rn(poly, h), 1.0);
+    return __dmul_rn(__dmul_rn(2.0, s), poly);
+}
+
+__global__ void k_paint_radial(float* __restrict__ out, int H, int W, const double* __restrict__ A, const double* __restrict__ B,
+                               const double* __restrict__ C, const double* __restrict__ r, const double* __restrict__ prof,
+                               int ntab, double r0, double dlnr, double amp, float sign) {
+    long long n = (long long)H * W;
+    const double rlast = r[ntab - 1];
+    const double rfirst = r[0];
+    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x) {
+        int y = (int)(p / W), x = (int)(p % W);
+        double h = __dadd_rn(A[y], __dmul_rn(B[y], C[x]));
+        double th = theta_from_hav(h);
+        double val;
+        if (th < rfirst) {
+            val = prof[0];
+        } else if (th > rlast) {
+            val = 0.0;
+        } else if (th == rlast) {
+            val = prof[ntab - 1];
+        } else {
+            int j = (int)(log(th / r0) / dlnr);
+            if (j < 0) j = 0;
+            if (j > ntab - 2) j = ntab - 2;
+            while (j > 0 && r[j] > th) --j;            // guard against log() rounding at interval edges
+            while (j < ntab - 2 && r[j + 1] <= th) ++j;
+            double slope = __ddiv_rn(__dsub_rn(prof[j + 1], prof[j]), __dsub_rn(r[j + 1], r[j]));
+            val = __dadd_rn(__dmul_rn(slope, __dsub_rn(th, r[j])), prof[j]);
+        }
+        float v = (float)__dmul_rn(amp, val);
+        out[p] = (sign < 0.0f) ? v * -1.0f : v;
+    }
+}
+
+int paint_radial(float* out, int H, int W, const double* A, const double* B, const double* C, const double* r,
+                 const double* prof, int ntab, double r0, double dlnr, double amp, double sign, hipStream_t s) {
+    hipLaunchKernelGGL(k_paint_radial, dim3(grid_for((long long)H * W, 256)), dim3(256), 0, s, out, H, W, A, B, C, r, prof, ntab,
+                       r0, dlnr, amp, (float)sign);
+    NF_CHECK_LAUNCH("k_paint_radial");
+    return NF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// filtered(VT) = float32 map * signalNorm * psMask.  VT = double when signalNorm is a float64 scalar
+// ('yc' mode under numpy >= 2 promotion), float when it is a float32 scalar ('uK' mode).
+template <typename VT>
+__global__ void k_scale_mask(const float* __restrict__ in, VT* __restrict__ out, double norm, const unsigned char* __restrict__ psMask,
+                             long long n) {
+    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x) {
+        VT v = (VT)in[p] * (VT)norm;
+        if (psMask != nullptr) v = v * (VT)psMask[p];
+        out[p] = v;
+    }
+}
+
+int scale_mask(int vtype, const float* in, void* out, double norm, const unsigned char* psMask, long long n, hipStream_t s) {
+    dim3 g(grid_for(n, 256)), b(256);
+    if (vtype == NF_F64)
+        hipLaunchKernelGGL(k_scale_mask<double>, g, b, 0, s, in, (double*)out, norm, psMask, n);
+    else
+        hipLaunchKernelGGL(k_scale_mask<float>, g, b, 0, s, in, (float*)out, norm, psMask, n);
+    NF_CHECK_LAUNCH("k_scale_mask");
+    return NF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Tail of buildAndApply: S/N map, edge-check / survey / point-source / apodisation masks.
+//   SN = filtered / RMS where RMS > 0 (else filtered);  edge = edgeCheck (or 1)
+//   filtered' = filtered*edge [*surveyMask' if fourier variant];  surveyMask' = edge*surveyMask*psMask
+//   surveyMask'' = surveyMask' * apodMask;  SN' = SN*surveyMask'' (NaN -> 0);  RMS' = RMS*surveyMask''
+template <typename VT>
+__global__ void k_finalize(VT* __restrict__ filtered, const float* __restrict__ rms, const unsigned char* __restrict__ surveyMask,
+                           const unsigned char* __restrict__ psMask, const unsigned char* __restrict__ edgeCheck, VT* __restrict__ snOut,
+                           float* __restrict__ rmsOut, unsigned char* __restrict__ maskOut, int H, int W, int apodPix,
+                           int mulSurvey) {
+    long long n = (long long)H * W;
+    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x) {
+        int y = (int)(p / W), x = (int)(p % W);
+        VT f = filtered[p];
+        float r = rms[p];
+        VT sn = f;
+        if (r > 0.0f) sn = f / (VT)r;
+        unsigned char e = edgeCheck ? edgeCheck[p] : (unsigned char)1;
+        unsigned char sm = (unsigned char)(e * (surveyMask ? surveyMask[p] : 1) * (psMask ? psMask[p] : 1));
+        f = f * (VT)e;
+        if (mulSurvey) f = f * (VT)sm;
+        // apod(ones, w) == 1 only at distance >= w-1 from every edge
+        int ay = min(apodPix, H), ax = min(apodPix, W);
+        bool inside = (ay <= 0 || (y >= ay - 1 && y <= H - ay)) && (ax <= 0 || (x >= ax - 1 && x <= W - ax));
+        unsigned char fm = inside ? sm : (unsigned char)0;
+        sn = sn * (VT)fm;
+        if (sn != sn) sn = (VT)0;
+        filtered[p] = f;
+        snOut[p] = sn;
+        rmsOut[p] = r * (float)fm;
+        maskOut[p] = fm;
+    }
+}
+
+int finalize(int vtype, void* filtered, const float* rms, const unsigned char* surveyMask, const unsigned char* psMask,
+             const unsigned char* edgeCheck, void* snOut, float* rmsOut, unsigned char* maskOut, int H, int W, int apodPix,
+             int mulSurvey, hipStream_t s) {
+    dim3 g(grid_for((long long)H * W, 256)), b(256);
+    if (vtype == NF_F64)
+        hipLaunchKernelGGL(k_finalize<double>, g, b, 0, s, (double*)filtered, rms, surveyMask, psMask, edgeCheck, (double*)snOut,
+                           rmsOut, maskOut, H, W, apodPix, mulSurvey);
+    else
+        hipLaunchKernelGGL(k_finalize<float>, g, b, 0, s, (float*)filtered, rms, surveyMask, psMask, edgeCheck, (float*)snOut,
+                           rmsOut, maskOut, H, W, apodPix, mulSurvey);
+    NF_CHECK_LAUNCH("k_finalize");
+    return NF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// zero-restore after the pixel-window deconvolution (nemo/filters.py:99-101): out = (ref == 0) ? 0 : in
+template <typename VT>
+__global__ void k_restore_zeros(VT* __restrict__ data, const VT* __restrict__ ref, long long n) {
+    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x)
+        if (ref[p] == (VT)0) data[p] = (VT)0;
+}
+
+int restore_zeros(int vtype, void* data, const void* ref, long long n, hipStream_t s) {
+    dim3 g(grid_for(n, 256)), b(256);
+    if (vtype == NF_F64)
+        hipLaunchKernelGGL(k_restore_zeros<double>, g, b, 0, s, (double*)data, (const double*)ref, n);
+    else
+        hipLaunchKernelGGL(k_restore_zeros<float>, g, b, 0, s, (float*)data, (const float*)ref, n);
+    NF_CHECK_LAUNCH("k_restore_zeros");
+    return NF_OK;
+}
+
+}  // namespace nf

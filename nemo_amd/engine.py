@@ -1,0 +1,369 @@
+"""Device-side plumbing: torch owns HBM buffers and streams, every computation is a libnemofilt call.
+
+:class:`TileEngine` holds what is fixed for one tile shape (FFT plan, apodisation / pixel-window tables)
+and exposes one thin method per C-ABI entry point.  Nothing here computes on the CPU except the small
+1-D tables (apodisation profile, sinc window, Gaussian taps, noise-grid edges) that parametrise kernels.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import NF_F32, NF_F64, IN_COMPLEX, IN_REAL64, IN_REAL32, NemoFiltError, check
+
+_torch = None
+
+
+def torch():
+    global _torch
+    if _torch is None:
+        import torch as _t
+        _torch = _t
+    return _torch
+
+
+def require_gpu():
+    t = torch()
+    if not t.cuda.is_available():
+        raise NemoFiltError("no HIP device visible: nemo_amd runs on MI355X (gfx950) only and has no CPU fallback")
+    _lib.load()
+    return t.device('cuda', t.cuda.current_device())
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch().cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def to_dev(x, dtype=None):
+    """numpy array or torch tensor -> contiguous tensor on the current HIP device."""
+    t = torch()
+    dev = require_gpu()
+    if isinstance(x, t.Tensor):
+        out = x.to(dev)
+    else:
+        a = np.ascontiguousarray(x)
+        if a.dtype == np.bool_:
+            a = a.astype(np.uint8)
+        out = t.from_numpy(a).to(dev)
+    if dtype is not None and out.dtype != dtype:
+        out = out.to(dtype)
+    return out.contiguous()
+
+
+def prec_of(tensor):
+    t = torch()
+    if tensor.dtype in (t.float64, t.complex128):
+        return NF_F64
+    if tensor.dtype in (t.float32, t.complex64):
+        return NF_F32
+    raise NemoFiltError("unsupported dtype %s" % tensor.dtype)
+
+
+def gaussian_kernel1d(sigma, truncate=4.0):
+    """Taps exactly as scipy.ndimage.gaussian_filter1d builds them (order 0)."""
+    sd = float(sigma)
+    radius = int(truncate * sd + 0.5)
+    x = np.arange(-radius, radius + 1)
+    phi = np.exp(-0.5 / (sd * sd) * x ** 2)
+    return phi / phi.sum(), radius
+
+
+class TileEngine(object):
+    APOD_PIX = 20      # nemo/filters.py:195
+    _cache = {}
+
+    @classmethod
+    def get(cls, shape):
+        dev = require_gpu()
+        key = (int(shape[0]), int(shape[1]), dev.index)
+        if key not in cls._cache:
+            cls._cache[key] = TileEngine(shape)
+        return cls._cache[key]
+
+    def __init__(self, shape):
+        self.t = torch()
+        self.dev = require_gpu()
+        self.lib = _lib.load()
+        self.H, self.W = int(shape[0]), int(shape[1])
+        self.npix = self.H * self.W
+        plan = ctypes.c_void_p()
+        check(self.lib.nf_plan_create(self.H, self.W, ctypes.byref(plan)), "nf_plan_create")
+        self.plan = plan
+        # enmap.apod profile (pixell): 0.5*(1-cos(linspace(0, pi, w))) on both ends of each axis
+        tabs = []
+        for n in (self.H, self.W):
+            w = int(min(self.APOD_PIX, n))
+            a = np.ones(n, dtype=np.float64)
+            if w > 0:
+                prof = 0.5 * (1 - np.cos(np.linspace(0, np.pi, w)))
+                a[:w] *= prof
+                a[-w:] *= prof[::-1]
+            tabs.append(to_dev(a))
+        self.apodY, self.apodX = tabs
+        self._win = {}
+        self._gauss = {}
+        self._geom = {}
+
+    # ---- tables --------------------------------------------------------------------------------------------
+    def window(self, pow):
+        if pow not in self._win:
+            wy = np.sinc(np.fft.fftfreq(self.H)) ** pow
+            wx = np.sinc(np.fft.fftfreq(self.W)) ** pow
+            self._win[pow] = (to_dev(wy), to_dev(wx))
+        return self._win[pow]
+
+    def gauss_taps(self, sigma):
+        key = float(sigma)
+        if key not in self._gauss:
+            w, rad = gaussian_kernel1d(sigma)
+            self._gauss[key] = (to_dev(w), rad)
+        return self._gauss[key]
+
+    # ---- FFTs ----------------------------------------------------------------------------------------------
+    def fft(self, x, prec=None, apod=False, unitary=True):
+        """enmap.fft of [B,H,W] or [H,W]; real input is promoted to the complex type of ``prec``."""
+        t = self.t
+        x3 = x.reshape(-1, self.H, self.W)
+        if x3.is_complex():
+            inType = IN_COMPLEX
+            prec = prec_of(x3)
+        else:
+            inType = IN_REAL64 if x3.dtype == t.float64 else IN_REAL32
+            if prec is None:
+                prec = NF_F64 if x3.dtype == t.float64 else NF_F32
+        out = t.empty(x3.shape, dtype=t.complex128 if prec == NF_F64 else t.complex64, device=self.dev)
+        check(self.lib.nf_fft2_forward(self.plan, prec, ptr(x3), inType, ptr(out), x3.shape[0],
+                                       ptr(self.apodY) if apod else None, ptr(self.apodX) if apod else None,
+                                       1 if unitary else 0, stream_ptr()), "nf_fft2_forward")
+        return out.reshape(x.shape)
+
+    def ifft(self, X, out='complex', unitary=False, clobber=False):
+        """enmap.ifft; ``out`` in {'complex', 'f64', 'f32'} (the latter two keep the real part only)."""
+        t = self.t
+        X3 = X.reshape(-1, self.H, self.W)
+        prec = prec_of(X3)
+        work = X3 if clobber else t.empty_like(X3)
+        if out == 'complex':
+            res = t.empty_like(X3)
+            outType = IN_COMPLEX
+        elif out == 'f64':
+            res = t.empty(X3.shape, dtype=t.float64, device=self.dev)
+            outType = IN_REAL64
+        else:
+            res = t.empty(X3.shape, dtype=t.float32, device=self.dev)
+            outType = IN_REAL32
+        check(self.lib.nf_fft2_inverse(self.plan, prec, ptr(X3), ptr(work), ptr(res), outType, X3.shape[0],
+                                       1 if unitary else 0, stream_ptr()), "nf_fft2_inverse")
+        return res.reshape(X.shape)
+
+    # ---- Fourier-domain pointwise --------------------------------------------------------------------------
+    def cross_power(self, F):
+        t = self.t
+        N = F.shape[0]
+        prec = prec_of(F)
+        NP = t.empty((N, N, self.H, self.W), dtype=t.float64 if prec == NF_F64 else t.float32, device=self.dev)
+        check(self.lib.nf_cross_power(prec, ptr(F), ptr(NP), N, self.npix, stream_ptr()), "nf_cross_power")
+        return NP
+
+    def gaussian_filter(self, x, sigmaYX):
+        """scipy.ndimage.gaussian_filter(x, (sy, sx)), mode reflect, over the last two axes of [..., H, W]."""
+        t = self.t
+        x3 = x.reshape(-1, self.H, self.W)
+        wY, rY = self.gauss_taps(sigmaYX[0])
+        wX, rX = self.gauss_taps(sigmaYX[1])
+        tmp = t.empty_like(x3)
+        out = t.empty_like(x3)
+        check(self.lib.nf_gaussian_filter(prec_of(x3), ptr(x3), ptr(tmp), ptr(out), self.H, self.W, x3.shape[0],
+                                          ptr(wY), rY, ptr(wX), rX, stream_ptr()), "nf_gaussian_filter")
+        return out.reshape(x.shape)
+
+    def build_filter(self, noiseCov, fSignals, w):
+        t = self.t
+        N = fSignals.shape[0]
+        filt = t.empty((N, self.H, self.W), dtype=t.float32, device=self.dev)
+        warr = (ctypes.c_double * N)(*[float(v) for v in w])
+        check(self.lib.nf_build_filter(prec_of(noiseCov), prec_of(fSignals), ptr(noiseCov), ptr(fSignals), warr,
+                                       ptr(filt), N, self.npix, stream_ptr()), "nf_build_filter")
+        return filt
+
+    def apply_filter(self, F, filt, sum=True):
+        t = self.t
+        N = F.shape[0]
+        G = t.empty((self.H, self.W) if sum else (N, self.H, self.W), dtype=F.dtype, device=self.dev)
+        check(self.lib.nf_apply_filter(prec_of(F), ptr(F), ptr(filt), ptr(G), N, 1 if sum else 0, self.npix,
+                                       stream_ptr()), "nf_apply_filter")
+        return G
+
+    def window_mul_(self, F, pow):
+        wy, wx = self.window(pow)
+        F3 = F.reshape(-1, self.H, self.W)
+        check(self.lib.nf_window_mul(prec_of(F3), ptr(F3), ptr(wy), ptr(wx), self.H, self.W, F3.shape[0], stream_ptr()),
+              "nf_window_mul")
+        return F
+
+    def apply_window(self, m, pow):
+        """enmap.apply_window(m, pow): real [H,W] map in, real map of the same dtype out."""
+        F = self.fft(m, unitary=True)
+        self.window_mul_(F, pow)
+        return self.ifft(F, out='f64' if m.dtype == self.t.float64 else 'f32', unitary=True, clobber=True)
+
+    # ---- templates -----------------------------------------------------------------------------------------
+    def paint(self, geom, table):
+        """float32 template from a signals.RadialTable and the (A, B, C) haversine tables."""
+        t = self.t
+        key = id(geom)
+        if key not in self._geom:
+            self._geom = {key: tuple(to_dev(np.asarray(g, dtype=np.float64)) for g in geom)}
+        A, B, C = self._geom[key]
+        if not hasattr(table, '_dev'):
+            table._dev = (to_dev(table.r), to_dev(table.prof))
+        r, prof = table._dev
+        out = t.empty((self.H, self.W), dtype=t.float32, device=self.dev)
+        check(self.lib.nf_paint_radial(ptr(out), self.H, self.W, ptr(A), ptr(B), ptr(C), ptr(r), ptr(prof), len(table.r),
+                                       table.r0, table.dlnr, table.amp, table.sign, stream_ptr()), "nf_paint_radial")
+        return out
+
+    # ---- real-space tail -----------------------------------------------------------------------------------
+    def scale_mask(self, m32, signalNorm, psMask):
+        t = self.t
+        # numpy >= 2 promotion: float32 array * np.float64 scalar -> float64; * Python float / np.float32 -> float32
+        wide = isinstance(signalNorm, np.float64)
+        vt = NF_F64 if wide else NF_F32
+        out = t.empty((self.H, self.W), dtype=t.float64 if wide else t.float32, device=self.dev)
+        check(self.lib.nf_scale_mask(vt, ptr(m32), ptr(out), float(signalNorm), ptr(psMask), self.npix, stream_ptr()),
+              "nf_scale_mask")
+        return out
+
+    def median_weights(self, weightsList):
+        t = self.t
+        if len(weightsList) == 1:
+            return weightsList[0]
+        stack = t.stack(weightsList).contiguous()
+        out = t.empty_like(weightsList[0])
+        check(self.lib.nf_median_stack(prec_of(stack), ptr(stack), ptr(out), len(weightsList), self.npix, stream_ptr()),
+              "nf_median_stack")
+        return out
+
+    def noise_map(self, filtered, medWeights, noiseParams, pixSizeDeg):
+        """MapFilter.makeNoiseMap, grid mode (nemo/filters.py:407-478)."""
+        t = self.t
+        if noiseParams.get('noiseGridArcmin', None) == "smart":
+            raise NemoFiltError("noiseGridArcmin: 'smart' is not implemented on the GPU path yet")
+        estimator = noiseParams.get('RMSEstimator', None)
+        if estimator is not None:
+            raise NemoFiltError("RMSEstimator '%s' is not implemented on the GPU path yet" % (estimator))
+        if 'noiseGridArcmin' not in noiseParams or noiseParams['noiseGridArcmin'] is None:
+            overlap, nx, ny = 0, 1, 1
+        else:
+            grid = int(round((noiseParams['noiseGridArcmin'] / 60.) / pixSizeDeg))
+            overlap = int(grid / 2)
+            nx = self.W / grid
+            ny = self.H / grid
+        yEdges = np.linspace(0, self.H, int(ny + 1), dtype=int).astype(np.int32)
+        xEdges = np.linspace(0, self.W, int(nx + 1), dtype=int).astype(np.int32)
+        numBins = noiseParams.get('numNoiseBins', 1)
+        percentiles = np.arange(0, 100, 100 / numBins)
+        nb = len(percentiles)
+        quant = (ctypes.c_double * nb)(*[float(np.true_divide(p, 100)) for p in percentiles])
+        ncy, ncx = len(yEdges) - 1, len(xEdges) - 1
+        rms = t.empty((self.H, self.W), dtype=t.float32, device=self.dev)
+        if ncy < 1 or ncx < 1:
+            rms.zero_()
+            return rms
+        wbytes = self.lib.nf_noise_workspace_bytes(ncy, ncx, nb)
+        work = t.empty(wbytes // 8 + 1, dtype=t.float64, device=self.dev)
+        yE, xE = to_dev(yEdges), to_dev(xEdges)
+        check(self.lib.nf_noise_map(prec_of(filtered), ptr(filtered), ptr(medWeights), prec_of(medWeights), ptr(rms),
+                                    self.H, self.W, ncy, ncx, ptr(yE), ptr(xE), overlap, nb, quant, 0, ptr(work),
+                                    work.numel() * 8, stream_ptr()), "nf_noise_map")
+        return rms
+
+    def edge_check(self, filtered, psMask, size):
+        t = self.t
+        tmp = t.empty((self.H, self.W), dtype=t.uint8, device=self.dev)
+        out = t.empty((self.H, self.W), dtype=t.uint8, device=self.dev)
+        check(self.lib.nf_edge_check(prec_of(filtered), ptr(filtered), ptr(psMask), ptr(tmp), ptr(out), self.H, self.W,
+                                     int(size), stream_ptr()), "nf_edge_check")
+        return out
+
+    def finalize(self, filtered, rms, surveyMask, psMask, edgeCheck, mulSurvey):
+        t = self.t
+        sn = t.empty_like(filtered)
+        rmsOut = t.empty_like(rms)
+        maskOut = t.empty((self.H, self.W), dtype=t.uint8, device=self.dev)
+        check(self.lib.nf_finalize(prec_of(filtered), ptr(filtered), ptr(rms), ptr(surveyMask), ptr(psMask), ptr(edgeCheck),
+                                   ptr(sn), ptr(rmsOut), ptr(maskOut), self.H, self.W, self.APOD_PIX, 1 if mulSurvey else 0,
+                                   stream_ptr()), "nf_finalize")
+        return filtered, sn, rmsOut, maskOut
+
+    def undo_pixel_window(self, data):
+        """filterMaps' last step (nemo/filters.py:98-101)."""
+        out = self.apply_window(data, -1.0)
+        check(self.lib.nf_restore_zeros(prec_of(data), ptr(out), ptr(data), self.npix, stream_ptr()), "nf_restore_zeros")
+        return out
+
+    def subtract_background(self, data, sigmaYX):
+        """maps.subtractBackground (nemo/maps.py:1279-1292)."""
+        sm = self.gaussian_filter(data, sigmaYX)
+        out = self.t.empty_like(data)
+        check(self.lib.nf_subtract(prec_of(data), ptr(data), ptr(sm), ptr(out), data.numel(), stream_ptr()), "nf_subtract")
+        return out
+
+    def convolve(self, m32, kern2d):
+        """scipy.ndimage.convolve(float32 map, float64 kernel), reflect (nemo/filters.py:1193)."""
+        t = self.t
+        kf = to_dev(np.ascontiguousarray(np.asarray(kern2d, dtype=np.float64)[::-1, ::-1]))
+        out = t.empty_like(m32)
+        check(self.lib.nf_convolve2d(ptr(m32), ptr(out), self.H, self.W, ptr(kf), kern2d.shape[0], kern2d.shape[1],
+                                     stream_ptr()), "nf_convolve2d")
+        return out
+
+    # ---- detection -----------------------------------------------------------------------------------------
+    def label(self, sn, threshold, negate=False):
+        t = self.t
+        labels = t.empty((self.H, self.W), dtype=t.int32, device=self.dev)
+        work = t.empty(self.npix + self.npix // 1024 + 8, dtype=t.int32, device=self.dev)
+        n = ctypes.c_int(0)
+        check(self.lib.nf_label_components(prec_of(sn), ptr(sn), float(threshold), 1 if negate else 0, ptr(labels), self.H,
+                                           self.W, ptr(work), ctypes.byref(n), stream_ptr()), "nf_label_components")
+        return labels, n.value
+
+    def object_stats(self, sn, labels, numObjects, negate=False):
+        t = self.t
+        stats = t.empty((numObjects + 1) * 8, dtype=t.float64, device=self.dev)
+        check(self.lib.nf_object_stats(prec_of(sn), ptr(sn), 1 if negate else 0, ptr(labels), self.H, self.W, numObjects,
+                                       ptr(stats), stream_ptr()), "nf_object_stats")
+        return stats[:(numObjects + 1) * 6].reshape(numObjects + 1, 6)
+
+    def ring_flags(self, ringLabels, ringStats, numRing, minRingPix=30):
+        t = self.t
+        isRing = t.empty(numRing + 1, dtype=t.uint8, device=self.dev)
+        rs = ringStats.contiguous()
+        check(self.lib.nf_ring_flags(ptr(ringLabels), ptr(rs), numRing, minRingPix, self.H, self.W, ptr(isRing), stream_ptr()),
+              "nf_ring_flags")
+        return isRing
+
+    def map_max(self, m):
+        """(max value, flat index of its first occurrence) of a device map."""
+        t = self.t
+        out = t.empty(4, dtype=t.float64, device=self.dev)
+        check(self.lib.nf_map_max(prec_of(m), ptr(m), m.numel(), ptr(out), stream_ptr()), "nf_map_max")
+        res = out[:2].cpu().numpy()
+        return res[0], int(res[1])
+
+    def spline_eval(self, m, yx, negate=False, halfWin=32):
+        t = self.t
+        yx = np.ascontiguousarray(np.asarray(yx, dtype=np.float64).reshape(-1, 2))
+        if len(yx) == 0:
+            return np.zeros(0)
+        yx_d = to_dev(yx)
+        out = t.empty(len(yx), dtype=t.float64, device=self.dev)
+        check(self.lib.nf_spline_eval(prec_of(m), ptr(m), 1 if negate else 0, self.H, self.W, ptr(yx_d), len(yx), halfWin,
+                                      ptr(out), stream_ptr()), "nf_spline_eval")
+        return out.cpu().numpy()

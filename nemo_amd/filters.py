@@ -1,0 +1,676 @@
+"""MI355X-native filter classes with the reference's names and call protocol (nemo/filters.py).
+
+* :func:`filterMaps`                                  - nemo/filters.py:51-106
+* :class:`MapFilter` (``makeNoiseMap`` etc.)           - nemo/filters.py:109-513
+* :class:`MatchedFilter`                              - nemo/filters.py:516-855
+* :class:`RealSpaceMatchedFilter`                     - nemo/filters.py:858-1210
+* template mixins and the six concrete classes        - nemo/filters.py:1214-1320
+
+All map-sized arithmetic runs in libnemofilt (hand-written gfx950 kernels, see include/nemofilt.h) on
+tensors resident in HBM; this module only sequences the calls in the reference's order, keeps the
+reference's dtype behaviour (numpy >= 2 promotion rules: the 'yc' normalisation is a float64 scalar, so the
+filtered / S/N maps become float64 at nemo/filters.py:853; in 'uK' mode they stay float32), and holds the
+small scalar logic (weights, normalisation, file caching).  There is no CPU fallback.
+
+Returned maps are numpy arrays by default (drop-in); set ``nemo_amd.filters.RETURN_DEVICE_ARRAYS = True`` (the
+pipeline driver and bench do) to keep them as torch tensors on the GPU for ``photometry.findObjects``.
+"""
+import os
+
+import numpy as np
+
+from . import engine, maps, signals, fitsio
+from ._lib import NF_F32, NF_F64, NemoFiltError
+from .wcs import calcAngSepDeg
+
+RETURN_DEVICE_ARRAYS = False
+
+
+def _asnumpy(x, dtype=None):
+    if hasattr(x, 'is_cuda'):
+        x = x.cpu().numpy()
+    if dtype is not None:
+        x = np.asarray(x).astype(dtype, copy=False)
+    return x
+
+
+# ------------------------------------------------------------------------------------------------------------
+def filterMaps(unfilteredMapsDictList, filterParams, tileName, diagnosticsDir='.', selFnDir='.', verbose=True,
+               undoPixelWindow=True, useCachedFilter=False, returnFilter=False):
+    """Builds and applies a filter to the unfiltered map(s) (nemo/filters.py:51-106)."""
+    f = filterParams
+    label = f['label'] + "#" + tileName
+    if verbose:
+        print("... making filtered map %s" % (label))
+    filterClass = _FILTER_CLASSES[f['class']]
+    filterObj = filterClass(f['label'], unfilteredMapsDictList, f['params'], tileName=tileName,
+                            diagnosticsDir=diagnosticsDir, selFnDir=selFnDir)
+    filteredMapDict = filterObj.buildAndApply(useCachedFilter=useCachedFilter)
+
+    filteredMapDict['wcs'].header['BUNIT'] = filteredMapDict['mapUnits']
+    if 'beamSolidAngle_nsr' in filteredMapDict.keys() and filteredMapDict['beamSolidAngle_nsr'] > 0:
+        filteredMapDict['wcs'].header['BEAMNSR'] = filteredMapDict['beamSolidAngle_nsr']
+        filteredMapDict['wcs'].header['FREQGHZ'] = filteredMapDict['obsFreqGHz']
+    filteredMapDict['wcs'].updateFromHeader()
+
+    # Undo the pixel window (FFT . W^-1 . IFFT), restoring exact zeros (nemo/filters.py:98-101)
+    if undoPixelWindow == True:
+        data = filteredMapDict['data']
+        eng = filterObj.engine
+        d = engine.to_dev(data)
+        out = eng.undo_pixel_window(d)
+        filteredMapDict['data'] = out if RETURN_DEVICE_ARRAYS else _asnumpy(out)
+
+    if returnFilter == True:
+        return filteredMapDict, filterObj
+    return filteredMapDict
+
+
+# ------------------------------------------------------------------------------------------------------------
+class MapFilter(object):
+    """Base class defining the common interface (nemo/filters.py:109-513)."""
+
+    templateKind = None
+
+    def __init__(self, label, unfilteredMapsDictList, paramsDict, tileName='PRIMARY', writeFilter=False,
+                 forceRebuild=False, diagnosticsDir=None, selFnDir=None):
+        self.label = label
+        self.params = paramsDict
+        self.diagnosticsDir = diagnosticsDir
+        self.selFnDir = selFnDir
+        self.tileName = tileName
+        if self.diagnosticsDir is not None:
+            self.filterFileName = self.diagnosticsDir + os.path.sep + self.tileName + os.path.sep + \
+                "filter_%s#%s.fits" % (self.label, self.tileName)
+        else:
+            self.filterFileName = None
+
+        # Copies, preprocessed per tile (nemo/filters.py:153-161)
+        self.unfilteredMapsDictList = []
+        for mapDict in unfilteredMapsDictList:
+            if 'mapToUse' in self.params.keys() and mapDict['label'] != self.params['mapToUse']:
+                continue
+            newMapDict = mapDict.copy()
+            newMapDict.preprocess(tileName=tileName, diagnosticsDir=diagnosticsDir)
+            self.unfilteredMapsDictList.append(newMapDict)
+        self.wcs = self.unfilteredMapsDictList[0]['wcs']
+        self.shape = tuple(self.unfilteredMapsDictList[0]['data'].shape)
+
+        # Combined flag mask (nemo/filters.py:165-168)
+        self.flagMask = np.zeros(self.shape, dtype=int)
+        for mapDict, i in zip(self.unfilteredMapsDictList, range(len(self.unfilteredMapsDictList))):
+            self.flagMask = self.flagMask + (_asnumpy(mapDict['flagMask']) * (i + 1))
+
+        # Beam solid angles in nanosteradians (nemo/filters.py:170-189)
+        self.beamSolidAnglesDict = {}
+        for mapDict in self.unfilteredMapsDictList:
+            if 'solidAngle_nsr' in mapDict.keys():
+                solidAngle_nsr = mapDict['solidAngle_nsr']
+            else:
+                solidAngle_nsr = 0.0
+                beamFileName = mapDict.get('beamFileName')
+                if isinstance(beamFileName, str):
+                    with open(beamFileName, "r") as inFile:
+                        for line in inFile.readlines():
+                            if line.find("solid angle") != -1:
+                                bits = line.split("=")
+                                solidAngle_nsr = float(bits[1].split()[0])
+                                break
+            self.beamSolidAnglesDict[mapDict['obsFreqGHz']] = solidAngle_nsr
+
+        self.apodPix = 20
+        for mapDict in self.unfilteredMapsDictList:
+            if tuple(mapDict['data'].shape) != self.shape:
+                raise Exception("Maps at different frequencies have different dimensions!")
+
+        self.makeRadiansMap()
+        self.signalNorm = 1.0
+        self.fRelWeights = {}
+
+        # device residency: one engine per tile shape, maps / weights / masks uploaded once
+        self.engine = engine.TileEngine.get(self.shape)
+        t = engine.torch()
+        self._dData = [engine.to_dev(m['data']) for m in self.unfilteredMapsDictList]
+        for d in self._dData:
+            if d.dtype not in (t.float32, t.float64):
+                raise NemoFiltError("maps must be float32 or float64")
+        self._dWeights = [engine.to_dev(m['weights']) for m in self.unfilteredMapsDictList]
+        self._dWeights = [w if w.dtype in (t.float32, t.float64) else w.to(t.float64) for w in self._dWeights]
+        self._dSurveyMask = engine.to_dev(self.unfilteredMapsDictList[0]['surveyMask'], dtype=t.uint8)
+        self._dPSMask = engine.to_dev(self.unfilteredMapsDictList[0]['pointSourceMask'], dtype=t.uint8)
+        self._geom = None
+        self._dFilt = None
+
+    # -- geometry ---------------------------------------------------------------------------------------------
+    def makeRadiansMap(self):
+        """nemo/filters.py:211-236."""
+        H, W = self.shape
+        x0 = int(W / 2)
+        y0 = int(H / 2)
+        ra0, dec0 = self.wcs.pix2wcs(x0, y0)
+        ra1, dec1 = self.wcs.pix2wcs(x0 + 1, y0 + 1)
+        self.degPerPixX = calcAngSepDeg(ra0, dec0, ra1, dec0)
+        self.degPerPixY = calcAngSepDeg(ra0, dec0, ra0, dec1)
+        xRad = np.arange(int(np.floor(-W / 2)), int(W / 2), dtype=np.float64) * np.radians(self.degPerPixX)
+        yRad = np.arange(int(np.floor(-H / 2)), int(H / 2), dtype=np.float64) * np.radians(self.degPerPixY)
+        self._xRad, self._yRad = xRad, yRad
+        self._radiansMap = None
+
+    @property
+    def radiansMap(self):
+        if self._radiansMap is None:
+            self._radiansMap = np.sqrt(self._xRad[None, :] ** 2 + self._yRad[:, None] ** 2)
+        return self._radiansMap
+
+    @property
+    def filt(self):
+        """Fourier-space filter cube, float32 [N, H, W] (numpy view of the device cube)."""
+        return None if self._dFilt is None else _asnumpy(self._dFilt)
+
+    @filt.setter
+    def filt(self, value):
+        self._dFilt = None if value is None else engine.to_dev(np.asarray(value, dtype=np.float32))
+
+    def buildAndApply(self):
+        raise Exception("Called a base filter class without a buildAndApply() function implemented.")
+
+    # -- templates --------------------------------------------------------------------------------------------
+    def _beamOf(self, beamFileName):
+        return signals._asBeam(beamFileName)
+
+    def _paintTemplate(self, beamFileName, amplitude=None):
+        """Device float32 template centred on the tile centre (template mixins, nemo/filters.py:1214-1266)."""
+        if self.templateKind is None:
+            raise Exception("Called a base filter class without a makeSignalTemplateMap() function implemented.")
+        if self._geom is None:
+            RADeg, decDeg = self.wcs.getCentreWCSCoords()
+            self._geom = signals.paintGeometry(self.shape, self.wcs, RADeg, decDeg)
+        table = signals.templateTables(self.templateKind, self._beamOf(beamFileName), self.params, amplitude=amplitude)
+        return self.engine.paint(self._geom, table)
+
+    def makeSignalTemplateMap(self, beamFileName, amplitude=None):
+        out = self._paintTemplate(beamFileName, amplitude=amplitude)
+        return out if RETURN_DEVICE_ARRAYS else _asnumpy(out)
+
+    # -- noise ------------------------------------------------------------------------------------------------
+    def makeNoiseMap(self, mapData):
+        """Local RMS map of a filtered map (nemo/filters.py:342-480); float32."""
+        d = engine.to_dev(mapData)
+        rms = self._noiseMapDevice(d)
+        return rms if hasattr(mapData, 'is_cuda') else _asnumpy(rms)
+
+    def _noiseMapDevice(self, dMap):
+        medWeights = self.engine.median_weights(self._dWeights)
+        return self.engine.noise_map(dMap, medWeights, self.params['noiseParams'], self.wcs.getPixelSizeDeg())
+
+    def makeRealSpaceFilterProfile(self):
+        """nemo/filters.py:279-301: 1-D real-space profile of the Fourier filter along +x from the centre."""
+        realSpace = self._realSpaceFilter()
+        x0 = int(realSpace.shape[2] / 2)
+        y0 = int(realSpace.shape[1] / 2)
+        normFactor = abs(realSpace[:, y0, x0:]).max()
+        prof = realSpace[:, y0, x0:] / normFactor
+        arcminRange = np.arange(0, prof.shape[1]) * self.degPerPixX * 60.0
+        return prof, arcminRange
+
+    def _realSpaceFilter(self):
+        """fftshift(ifft2(filt).real), float32 [N, H, W] (ifft2 of a real cube = conj(fft2)/n)."""
+        F = self.engine.fft(self._dFilt, prec=NF_F32, unitary=False)
+        n = np.float32(self.shape[0] * self.shape[1])
+        real = _asnumpy(F.real.contiguous()) / n
+        return np.fft.fftshift(real, axes=(-2, -1))
+
+    def loadFRelWeights(self):
+        """nemo/filters.py:483-495."""
+        data, header = fitsio.readFITS(self.filterFileName, headerOnly=True)
+        self.fRelWeights = {}
+        for i in range(1, 10):
+            if 'RW%d_GHZ' % (i) in header.keys():
+                self.fRelWeights[header['RW%d_GHZ' % (i)]] = header['RW%d' % (i)]
+
+    # -- shared tail of buildAndApply ---------------------------------------------------------------------------
+    def _unitsInfo(self, allowMultiFreqUK=True):
+        if self.params['outputUnits'] == 'yc':
+            return 'yc', 'yc', 0.0
+        elif self.params['outputUnits'] == 'uK':
+            if not allowMultiFreqUK and len(self.unfilteredMapsDictList) > 1:
+                raise Exception("multi-frequency filtering not currently supported for outputUnits 'uK' (point source finding)")
+            combinedObsFreqGHz = float(list(self.beamSolidAnglesDict.keys())[0])
+            return 'uK', combinedObsFreqGHz, self.beamSolidAnglesDict[combinedObsFreqGHz]
+        raise Exception('need to specify "outputUnits" ("yc" or "uK") in filter params')
+
+    def _finish(self, dFiltered, trimSizePix, fourierVariant):
+        """Noise map, S/N, edge trim, masks (nemo/filters.py:716-756 / :1111-1157); all on the device."""
+        eng = self.engine
+        rms = self._noiseMapDevice(dFiltered)
+        edge = None
+        if trimSizePix > 0:
+            edge = eng.edge_check(dFiltered, self._dPSMask, trimSizePix)
+        data, sn, rmsOut, mask = eng.finalize(dFiltered, rms, self._dSurveyMask, self._dPSMask, edge, fourierVariant)
+        return data, sn, rmsOut, mask, trimSizePix > 0
+
+    def _packResult(self, data, sn, rms, mask, trimmed, fourierVariant, mapUnits, combinedObsFreqGHz, beamSolidAngle_nsr):
+        if RETURN_DEVICE_ARRAYS:
+            out = {'data': data, 'SNMap': sn, 'RMSMap': rms, 'surveyMask': mask}
+        else:
+            # dtypes as the reference produces them under numpy >= 2: the masks become float through
+            # edgeCheck (float32 if a rank filter ran in the Fourier variant, else float64)
+            mdt = np.float32 if (trimmed and fourierVariant) else np.float64
+            out = {'data': _asnumpy(data).astype(np.result_type(_asnumpy(data).dtype, mdt)),
+                   'SNMap': _asnumpy(sn).astype(np.result_type(_asnumpy(sn).dtype, mdt)),
+                   'RMSMap': _asnumpy(rms).astype(np.result_type(np.float32, mdt)),
+                   'surveyMask': _asnumpy(mask).astype(mdt)}
+        out.update({'wcs': self.wcs, 'obsFreqGHz': combinedObsFreqGHz, 'flagMask': self.flagMask, 'mapUnits': mapUnits,
+                    'beamSolidAngle_nsr': beamSolidAngle_nsr, 'label': self.label, 'tileName': self.tileName})
+        return out
+
+
+# ------------------------------------------------------------------------------------------------------------
+class MatchedFilter(MapFilter):
+    """Multi-frequency matched filter in Fourier space (nemo/filters.py:516-855)."""
+
+    def _dataPrec(self):
+        t = engine.torch()
+        return NF_F64 if self._dData[0].dtype == t.float64 else NF_F32
+
+    def buildAndApply(self, useCachedFilter=False):
+        eng = self.engine
+        t = engine.torch()
+        N = len(self.unfilteredMapsDictList)
+        dCube = t.stack(self._dData).contiguous() if N > 1 else self._dData[0].reshape(1, *self.shape)
+        fMapsToFilter = eng.fft(dCube, apod=True)                                 # :523-526  K1+K2
+
+        haveFile = self.filterFileName is not None and os.path.exists(self.filterFileName)
+        if haveFile == False and useCachedFilter == False:
+            method = self.params['noiseParams']['method']
+            if method not in ['dataMap', 'max(dataMap,CMB)']:
+                if method == 'model':
+                    raise NotImplementedError("noise method 'model' (simulated CMB + white noise) is not part of this build yet")
+                raise Exception("'%s' is not a valid filter noise method name - fix the .yml config file" % (method))
+            if self.params.get('noiseModelCatalog', None) is not None:
+                raise NotImplementedError("noiseModelCatalog needs maps.makeModelImage (scope table row f1)")
+            fMapsForNoise = fMapsToFilter                                         # identical to :548 without a catalog
+            NP = eng.cross_power(fMapsForNoise)                                   # :573  K4
+            if method == 'max(dataMap,CMB)':
+                NPCMB = engine.to_dev(self.makeForegroundsPower().astype(_asnumpy(NP[0, 0, :1, :1]).dtype))
+                NP = t.maximum(NP, NPCMB)
+            noiseCov = eng.gaussian_filter(NP, (3, 3))                            # :580  K5
+            del NP
+
+            w = self._frequencyWeights()                                          # :587-608
+            fSignals = t.stack([eng.fft(self._paintTemplate(m['beamFileName']))   # :611-618  K20+K2
+                                for m in self.unfilteredMapsDictList])
+            self._dFilt = eng.build_filter(noiseCov, fSignals, w)                 # :621-627  K6
+            del fSignals, noiseCov
+
+            if self.params['outputUnits'] == 'yc':                                # :632-668
+                y0 = 2e-4
+                fSignalMaps = []
+                for mapDict in self.unfilteredMapsDictList:
+                    if mapDict['units'] == 'yc':
+                        signalMap = self._paintTemplate(mapDict['beamFileName'], amplitude=y0)
+                    else:
+                        deltaT0 = maps.convertToDeltaT(y0, mapDict['obsFreqGHz'])
+                        signalMap = self._paintTemplate(mapDict['beamFileName'], amplitude=deltaT0)
+                    signalMap = eng.apply_window(signalMap, 1.0)                   # :644  K8
+                    fSignalMaps.append(eng.fft(signalMap))
+                fSignalMaps = t.stack(fSignalMaps)
+                filteredSignal = self._applyFilterDevice(fSignalMaps)
+                cRADeg, cDecDeg = self.wcs.getCentreWCSCoords()
+                cx, cy = self.wcs.wcs2pix(cRADeg, cDecDeg)
+                peakFilteredSignal = eng.spline_eval(filteredSignal, [[cy, cx]])[0]             # :654-657  K9
+                self.signalNorm = np.float64(y0) / np.float64(peakFilteredSignal)
+                maxValue, maxIndex = eng.map_max(filteredSignal)                  # :661
+                totalSignal = np.float32(maxValue)
+                self.fRelWeights = {}
+                for i, mapDict in enumerate(self.unfilteredMapsDictList):         # :662-667
+                    plane = eng.ifft(eng.apply_filter(fSignalMaps[i:i + 1], self._dFilt[i:i + 1]), out='f32')
+                    planeValue = np.float32(plane.reshape(-1)[maxIndex].item())
+                    self.fRelWeights[mapDict['obsFreqGHz']] = planeValue / totalSignal
+                del fSignalMaps
+            elif self.params['outputUnits'] == 'uK':                              # :669-685
+                fSignalMaps = t.stack([eng.fft(self._paintTemplate(m['beamFileName']))
+                                       for m in self.unfilteredMapsDictList])
+                filteredSignal = self._applyFilterDevice(fSignalMaps)
+                maxValue, maxIndex = eng.map_max(filteredSignal)
+                self.signalNorm = np.float32(1.0) / np.float32(maxValue)
+                del fSignalMaps
+            else:
+                raise Exception('need to specify "outputUnits" ("yc" or "uK") in filter params')
+        else:
+            print("... loading cached filter")
+            if self._dFilt is None or haveFile:
+                self.loadFilter()
+            self.params['saveRMSMap'] = False
+            self.params['saveFilter'] = False
+            self.params['savePlots'] = False
+
+        # Apply filter (:696), point-source mask (:714)
+        filtered32 = self._applyFilterDevice(fMapsToFilter, scale=False)
+        del fMapsToFilter
+        mapUnits, combinedObsFreqGHz, beamSolidAngle_nsr = self._unitsInfo()
+        dFiltered = eng.scale_mask(filtered32, self.signalNorm, self._dPSMask)
+
+        if 'edgeTrimArcmin' in self.params.keys() and self.params['edgeTrimArcmin'] > 0:      # :725-733
+            trimSizePix = int(round((self.params['edgeTrimArcmin'] / 60.) / self.wcs.getPixelSizeDeg()))
+        else:
+            trimSizePix = 0
+        data, sn, rms, mask, trimmed = self._finish(dFiltered, trimSizePix, True)
+
+        if 'saveFilter' in self.params and self.params['saveFilter'] == True and self.filterFileName is not None:
+            header = {'SIGNORM': float(self.signalNorm)}                          # :761-772
+            count = 0
+            for key in list(self.fRelWeights.keys()):
+                count = count + 1
+                header['RW%d_GHZ' % (count)] = key
+                header['RW%d' % (count)] = float(self.fRelWeights[key])
+            os.makedirs(os.path.split(self.filterFileName)[0], exist_ok=True)
+            fitsio.writeFITS(self.filterFileName, self.filt, header)
+
+        return self._packResult(data, sn, rms, mask, trimmed, True, mapUnits, combinedObsFreqGHz, beamSolidAngle_nsr)
+
+    def _frequencyWeights(self):
+        """Signal frequency weighting (nemo/filters.py:587-608)."""
+        w = []
+        for mapDict in self.unfilteredMapsDictList:
+            if mapDict['units'] != 'yc':
+                if 'specWeight' in mapDict.keys():
+                    w.append(mapDict['specWeight'])
+                else:
+                    if self.params['outputUnits'] == 'yc':
+                        w.append(signals.fSZ(mapDict['obsFreqGHz']))
+                    elif self.params['outputUnits'] == 'uK':
+                        if 'alpha' in self.params.keys() and self.params['alpha'] is not None:
+                            w.append(np.power(mapDict['obsFreqGHz'] / self.unfilteredMapsDictList[0]['obsFreqGHz'],
+                                              self.params['alpha']))
+                        else:
+                            w.append(1.0)
+                    else:
+                        raise Exception('need to specify "outputUnits" ("yc" or "uK") in filter params')
+            else:
+                w.append(1.0)
+        return np.array(w)
+
+    def makeForegroundsPower(self):
+        """nemo/filters.py:261-276: CMB power on the 2-D Fourier grid (flat-sky |l| of the tile)."""
+        tab = np.loadtxt(os.path.join(os.path.dirname(__file__), "data", "planck_lensedCls.dat"))
+        L, TT = tab[:, 0], tab[:, 1]
+        TT = (TT * 2 * np.pi) / (L * (L + 1))
+        H, W = self.shape
+        ly = np.fft.fftfreq(H, d=np.radians(self.degPerPixY)) * 2 * np.pi
+        lx = np.fft.fftfreq(W, d=np.radians(self.degPerPixX)) * 2 * np.pi
+        lmap = np.sqrt(ly[:, None] ** 2 + lx[None, :] ** 2)
+        fgPower = np.interp(lmap, L, TT, left=0.0, right=0.0) * H * W
+        return fgPower
+
+    def loadFilter(self):
+        """nemo/filters.py:780-790."""
+        data, header = fitsio.readFITS(self.filterFileName)
+        self._dFilt = engine.to_dev(data.astype(np.float32))
+        self.signalNorm = header['SIGNORM']
+        self.loadFRelWeights()
+
+    def reshapeFilter(self, shape):
+        raise NotImplementedError("reshapeFilter (nemo/filters.py:793-817) is only reached when map and filter shapes "
+                                  "differ; not part of this build yet")
+
+    def _applyFilterDevice(self, cube, scale=True):
+        """Device form of applyFilter: complex (Fourier) or real [N,H,W] tensor in, float32 [H,W] map out; with
+        ``scale`` the map is multiplied by signalNorm exactly as nemo/filters.py:853 does (numpy promotion)."""
+        eng = self.engine
+        t = engine.torch()
+        if tuple(cube.shape[-2:]) != self.shape:
+            raise NotImplementedError("map / filter shape mismatch needs reshapeFilter")
+        if cube.is_complex():
+            fMaps = cube
+        else:
+            fMaps = eng.fft(cube, apod=True)                                      # :845
+        G = eng.apply_filter(fMaps.reshape(-1, *self.shape), self._dFilt, sum=True)             # K7
+        out = eng.ifft(G, out='f32', unitary=False, clobber=True)                 # :847  K3
+        if 'bckSub' in self.params.keys() and 'bckSubScaleArcmin' in self.params.keys() and self.params['bckSub'] == True:
+            out = maps.subtractBackground(out, self.wcs, smoothScaleDeg=self.params['bckSubScaleArcmin'] / 60.)   # :850-851
+        if scale:
+            if isinstance(self.signalNorm, np.float64):
+                out = out.to(t.float64) * float(self.signalNorm)
+            else:
+                out = out * float(np.float32(self.signalNorm))
+        return out
+
+    def applyFilter(self, mapDataToFilter):
+        """nemo/filters.py:820-855.  numpy in -> numpy out; device tensor in -> device tensor out."""
+        isDev = hasattr(mapDataToFilter, 'is_cuda')
+        out = self._applyFilterDevice(engine.to_dev(mapDataToFilter))
+        return out if isDev else _asnumpy(out)
+
+
+# ------------------------------------------------------------------------------------------------------------
+class RealSpaceMatchedFilter(MapFilter):
+    """Matched filter truncated to a small real-space kernel applied by direct convolution
+    (nemo/filters.py:858-1210)."""
+
+    def loadFilter(self):
+        """nemo/filters.py:866-885."""
+        kern2d, header = fitsio.readFITS(self.filterFileName)
+        self.kern2d = kern2d
+        self.signalNorm = header['SIGNORM']
+        self.bckSubScaleArcmin = header['BCKSCALE'] if 'BCKSCALE' in header.keys() else 0
+        self.applyRACentre = header['APP_RA']
+        self.applyDecCentre = header['APP_DEC']
+        self.fRelWeights = {}
+        for i in range(1, 10):
+            if 'RW%d_GHZ' % (i) in header.keys():
+                self.fRelWeights[header['RW%d_GHZ' % (i)]] = header['RW%d' % (i)]
+
+    def buildKernel(self, RADecSection, RADeg='centre', decDeg='centre'):
+        """nemo/filters.py:888-1068 (plots omitted)."""
+        if self.filterFileName is not None and os.path.exists(self.filterFileName) == True:
+            return self.loadFilter()
+
+        keysWanted = ['mapFileName', 'weights', 'weightsFileName', 'obsFreqGHz', 'units', 'beamFileName', 'addNoise',
+                      'pointSourceRemoval', 'weightsType', 'tileName', 'reprojectToTan',
+                      'mapData', 'weightsData', 'wcs', 'label']        # last four: in-memory map carriers of this build
+        kernelUnfilteredMapsDictList = []
+        for mapDict in self.unfilteredMapsDictList:
+            for key in list(mapDict.keys()):
+                if key not in keysWanted:
+                    del mapDict[key]
+            kernelUnfilteredMapsDict = maps.MapDict(mapDict, tileCoordsDict=mapDict.tileCoordsDict)
+            kernelUnfilteredMapsDict['RADecSection'] = RADecSection
+            kernelUnfilteredMapsDictList.append(kernelUnfilteredMapsDict)
+        kernelLabel = "realSpaceKernel_%s" % (self.label)
+        matchedFilterDir = None
+        if self.diagnosticsDir is not None:
+            matchedFilterDir = self.diagnosticsDir + os.path.sep + kernelLabel + "#" + self.tileName
+            for d in [matchedFilterDir, matchedFilterDir + os.path.sep + 'diagnostics', matchedFilterDir + os.path.sep + 'selFn']:
+                os.makedirs(d, exist_ok=True)
+        matchedFilterClass = _FILTER_CLASSES[self.params['noiseParams']['matchedFilterClass']]
+        matchedFilter = matchedFilterClass(kernelLabel, kernelUnfilteredMapsDictList, self.params,
+                                           tileName=mapDict['tileName'],
+                                           diagnosticsDir=None if matchedFilterDir is None else matchedFilterDir + os.path.sep + 'diagnostics',
+                                           selFnDir=None if matchedFilterDir is None else matchedFilterDir + os.path.sep + 'selFn')
+        matchedFilter.buildAndApply()
+
+        # Truncate the real-space filter to a small kernel (:943-974)
+        kernelMaxArcmin = self.params['noiseParams']['kernelMaxArcmin']
+        prof, arcminRange = matchedFilter.makeRealSpaceFilterProfile()
+        rIndex = np.where(arcminRange > kernelMaxArcmin)[0][0]
+        mask = np.less(arcminRange, kernelMaxArcmin)
+        if 'symmetrize' in self.params['noiseParams'].keys() and self.params['noiseParams']['symmetrize'] == True:
+            from scipy import interpolate
+            rRadians = np.radians(arcminRange / 60.)
+            profile2d = []
+            for i in range(prof.shape[0]):
+                r2p = interpolate.interp1d(rRadians[mask], prof[i, mask], bounds_error=False, fill_value=0.0)
+                profile2d.append(r2p(matchedFilter.radiansMap))
+            profile2d = np.array(profile2d)
+        else:
+            profile2d = matchedFilter._realSpaceFilter()
+        z, y, x = np.where(abs(profile2d) == abs(profile2d).max())
+        y = y[0]
+        x = x[0]
+        yMin, yMax, xMin, xMax = y - rIndex, y + rIndex, x - rIndex, x + rIndex
+        if (yMax - yMin) % 2 == 0:
+            yMin = yMin + 1
+        if (xMax - xMin) % 2 == 0:
+            xMin = xMin + 1
+        self.kern2d = profile2d[:, yMin:yMax, xMin:xMax]
+
+        if 'bckSubScaleArcmin' in self.params.keys():                             # :977-988
+            self.bckSubScaleArcmin = self.params['bckSubScaleArcmin']
+        else:
+            func = np.min if np.greater(prof[0, 0], 0) == True else np.max
+            self.bckSubScaleArcmin = arcminRange[prof[0] == func(prof[0])][0]
+
+        # Normalisation from an ideal signal map (:994-1021)
+        signalMaps = []
+        for mapDict in self.unfilteredMapsDictList:
+            if self.params['outputUnits'] == 'yc':
+                y0 = 2e-4
+                if mapDict['obsFreqGHz'] is not None:
+                    deltaT0 = maps.convertToDeltaT(y0, mapDict['obsFreqGHz'])
+                    signalMap = self._paintTemplate(mapDict['beamFileName'], amplitude=deltaT0)
+                else:
+                    signalMap = self._paintTemplate(mapDict['beamFileName'], amplitude=y0)
+            elif self.params['outputUnits'] == 'uK':
+                signalMap = self._paintTemplate(mapDict['beamFileName'])
+            else:
+                raise Exception('need to specify "outputUnits" ("yc" or "uK") in filter params')
+            signalMaps.append(signalMap)
+        signalMaps = engine.torch().stack(signalMaps)
+        filteredSignal = self._applyFilterDevice(signalMaps, calcFRelWeights=True)
+        maxValue, maxIndex = self.engine.map_max(filteredSignal)
+        if self.params['outputUnits'] == 'yc':
+            self.signalNorm = y0 / np.float32(maxValue)
+        else:
+            self.signalNorm = 1.0 / np.float32(maxValue)
+
+        if self.filterFileName is not None:                                       # :1023-1037
+            header = dict(self.wcs.header)
+            if self.params['bckSub'] == True:
+                header['BCKSCALE'] = float(self.bckSubScaleArcmin)
+            header['SIGNORM'] = float(self.signalNorm)
+            header['APP_RA'] = float(self.applyRACentre)
+            header['APP_DEC'] = float(self.applyDecCentre)
+            count = 0
+            for key in list(self.fRelWeights.keys()):
+                count = count + 1
+                header['RW%d_GHZ' % (count)] = key
+                header['RW%d' % (count)] = float(self.fRelWeights[key])
+            os.makedirs(os.path.split(self.filterFileName)[0], exist_ok=True)
+            fitsio.writeFITS(self.filterFileName, np.asarray(self.kern2d), header)
+
+    def buildAndApply(self, useCachedFilter=False):
+        """nemo/filters.py:1071-1161."""
+        if self.filterFileName is None or os.path.exists(self.filterFileName) == False:
+            RAMin, RAMax, decMin, decMax = self.wcs.getImageMinMaxWCSCoords()
+            section = self.params['noiseParams']['RADecSection']
+            if section == 'tileNoiseRegions':
+                RADecSection = [self.wcs.header['NRAMIN'], self.wcs.header['NRAMAX'],
+                                self.wcs.header['NDEMIN'], self.wcs.header['NDEMAX']]
+            elif section == 'auto':
+                cRA, cDec = self.wcs.getCentreWCSCoords()
+                halfSizeDeg = 2.0
+                RADecSection = [cRA - halfSizeDeg / np.cos(np.radians(cDec)), cRA + halfSizeDeg / np.cos(np.radians(cDec)),
+                                cDec - halfSizeDeg, cDec + halfSizeDeg]
+            else:
+                RADecSection = section
+            self.applyDecCentre = (decMax + decMin) / 2.
+            self.applyRACentre = (RAMax + RAMin) / 2.
+            self.buildKernel(RADecSection, RADeg=self.applyRACentre, decDeg=self.applyDecCentre)
+        else:
+            self.loadFilter()
+
+        # Apply kernel to the RAW tile (:1102-1106)
+        t = engine.torch()
+        mapDataToFilter = t.stack([engine.to_dev(m.loadTile('mapFileName', tileName=self.tileName))
+                                   for m in self.unfilteredMapsDictList])
+        filtered32 = self._applyFilterDevice(mapDataToFilter, scale=False)
+        dFiltered = self.engine.scale_mask(filtered32, np.float32(self.signalNorm), self._dPSMask)   # :1205-1208, :1109
+
+        mapUnits, combinedObsFreqGHz, beamSolidAngle_nsr = self._unitsInfo(allowMultiFreqUK=False)
+        if 'edgeTrimArcmin' in self.params.keys():                                # :1133-1137
+            trimSizePix = int(round((self.params['edgeTrimArcmin'] / 60.) / self.wcs.getPixelSizeDeg()))
+        else:
+            gridSize = int(round((self.params['noiseParams']['noiseGridArcmin'] / 60.) / self.wcs.getPixelSizeDeg()))
+            trimSizePix = int(round(gridSize * 3.0))
+        data, sn, rms, mask, trimmed = self._finish(dFiltered, trimSizePix, False)
+        return self._packResult(data, sn, rms, mask, trimmed, False, mapUnits, combinedObsFreqGHz, beamSolidAngle_nsr)
+
+    def _applyFilterDevice(self, cube, calcFRelWeights=False, scale=True):
+        """Device form of applyFilter (nemo/filters.py:1164-1210): [N,H,W] real tensor -> float32 [H,W]."""
+        eng = self.engine
+        t = engine.torch()
+        N = cube.shape[0]
+        planes = []
+        for i in range(N):
+            if self.params['bckSub'] == True and self.bckSubScaleArcmin > 0:      # :1182-1187  K14
+                p = maps.subtractBackground(cube[i], self.wcs, RADeg=self.applyRACentre, decDeg=self.applyDecCentre,
+                                            smoothScaleDeg=self.bckSubScaleArcmin / 60.).to(t.float32)
+            else:
+                p = cube[i]
+                if p.dtype != t.float32:
+                    raise NotImplementedError("float64 maps with bckSub: False are convolved in float64 by the reference; "
+                                              "not part of this build yet")
+            planes.append(eng.convolve(p.contiguous(), np.asarray(self.kern2d[i])))         # :1192-1193  K13
+        total = planes[0]
+        for p in planes[1:]:
+            total = total + p
+        if calcFRelWeights == True:                                               # :1196-1203
+            self.fRelWeights = {}
+            maxValue, maxIndex = eng.map_max(total)
+            for plane, mapDict in zip(planes, self.unfilteredMapsDictList):
+                self.fRelWeights[mapDict['obsFreqGHz']] = np.float32(plane.reshape(-1)[maxIndex].item()) / np.float32(maxValue)
+        if scale:
+            total = total * float(np.float32(self.signalNorm))
+        return total
+
+    def applyFilter(self, mapDataToFilter, calcFRelWeights=False):
+        isDev = hasattr(mapDataToFilter, 'is_cuda')
+        out = self._applyFilterDevice(engine.to_dev(mapDataToFilter), calcFRelWeights=calcFRelWeights)
+        return out if isDev else _asnumpy(out)
+
+
+# ------------------------------------------------------------------------------------------------------------
+class BeamFilter(MapFilter):
+    """Point-source (beam) template (nemo/filters.py:1214-1222)."""
+    templateKind = 'beam'
+
+
+class ArnaudModelFilter(MapFilter):
+    """Arnaud et al. (2010) GNFW cluster template (nemo/filters.py:1225-1241)."""
+    templateKind = 'arnaud'
+
+
+class BattagliaModelFilter(MapFilter):
+    """Battaglia et al. (2012) GNFW cluster template (nemo/filters.py:1244-1266)."""
+    templateKind = 'battaglia'
+
+
+class ArnaudModelMatchedFilter(MatchedFilter, ArnaudModelFilter):
+    pass
+
+
+class BattagliaModelMatchedFilter(MatchedFilter, BattagliaModelFilter):
+    pass
+
+
+class BeamMatchedFilter(MatchedFilter, BeamFilter):
+    pass
+
+
+class ArnaudModelRealSpaceMatchedFilter(RealSpaceMatchedFilter, ArnaudModelFilter):
+    pass
+
+
+class BattagliaModelRealSpaceMatchedFilter(RealSpaceMatchedFilter, BattagliaModelFilter):
+    pass
+
+
+class BeamRealSpaceMatchedFilter(RealSpaceMatchedFilter, BeamFilter):
+    pass
+
+
+# class lookup replacing the reference's eval() of the YAML 'class' string (nemo/filters.py:82,933)
+_FILTER_CLASSES = {c.__name__: c for c in [ArnaudModelMatchedFilter, BattagliaModelMatchedFilter, BeamMatchedFilter,
+                                           ArnaudModelRealSpaceMatchedFilter, BattagliaModelRealSpaceMatchedFilter,
+                                           BeamRealSpaceMatchedFilter]}

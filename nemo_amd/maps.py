@@ -1,0 +1,172 @@
+"""Map containers and the two map-level helpers the filters call.
+
+Mirrors, for the hot path only:
+
+* ``MapDict`` (copy / loadTile / preprocess)   - nemo/maps.py:47-480
+* ``subtractBackground`` / ``smoothMap``       - nemo/maps.py:1279-1292,1357-1382
+* ``convertToDeltaT``                          - nemo/maps.py:679-697
+
+Maps are held in memory (numpy arrays, or torch tensors already resident in HBM): a ``MapDict`` takes
+``mapData`` / ``weightsData`` (arrays) or ``mapFileName`` / ``weightsFileName`` (``.npy`` or simple FITS
+files readable by :mod:`nemo_amd.fitsio`).  The catalogue-driven preprocessing steps of the reference
+(hole filling, model subtraction, source injection: nemo/maps.py:294-465) are the "next" row of the scope
+table and raise if requested.
+"""
+import os
+
+import numpy as np
+
+from . import engine
+from .signals import convertToDeltaT  # noqa: F401  (re-exported: reference has it in maps)
+from .wcs import calcAngSepDeg
+
+_UNSUPPORTED_KEYS = ['CMBSimSeed', 'injectSources', 'applyBeamConvolution', 'smoothKernel', 'extendedMask',
+                     'maskPointSourcesFromCatalog', 'subtractModelFromCatalog', 'maskAndFillFromCatalog',
+                     'apodizeUsingSurveyMask']
+
+
+def _is_tensor(x):
+    return hasattr(x, 'is_cuda')
+
+
+class MapDict(dict):
+    """Dictionary describing one frequency map (nemo/maps.py:47-80)."""
+
+    def __init__(self, inputDict, tileCoordsDict=None):
+        super(MapDict, self).__init__(inputDict)
+        self.tileCoordsDict = tileCoordsDict
+        self._maskKeys = ['pointSourceMask', 'surveyMask', 'flagMask', 'extendedMask']
+        self.validMapKeys = ['mapFileName', 'weightsFileName'] + self._maskKeys
+
+    def copy(self):
+        return MapDict(self, tileCoordsDict=self.tileCoordsDict)
+
+    def _load(self, value):
+        if isinstance(value, str):
+            if value.endswith('.npy'):
+                return np.load(value)
+            from . import fitsio
+            return fitsio.readFITS(value)[0]
+        return value
+
+    def loadTile(self, mapKey, tileName, returnWCS=False):
+        """nemo/maps.py:83-175 for in-memory / single-tile inputs (tile clipping via ``tileCoordsDict``)."""
+        if mapKey not in self.validMapKeys:
+            raise Exception("mapKey must be one of %s - given mapKey = '%s'." % (self.validMapKeys, mapKey))
+        alias = {'mapFileName': 'mapData', 'weightsFileName': 'weightsData'}
+        if mapKey in alias and self.get(alias[mapKey]) is not None:
+            data = self[alias[mapKey]]
+        else:
+            data = self._load(self.get(mapKey))
+        if data is None:
+            raise Exception("no map given for '%s'" % (mapKey))
+        if self.tileCoordsDict is not None and tileName in self.tileCoordsDict:
+            minX, maxX, minY, maxY = self.tileCoordsDict[tileName]['clippedSection']
+            data = data[..., minY:maxY, minX:maxX]
+        data = data.clone() if _is_tensor(data) else np.array(data)
+        if data.ndim == 3:
+            data = data[0]
+        if mapKey in self._maskKeys and not _is_tensor(data) and data.dtype != np.uint8:
+            data = np.array(data, dtype=np.uint8)
+        if mapKey == 'surveyMask' and self.tileCoordsDict is not None and tileName in self.tileCoordsDict:
+            minX, maxX, minY, maxY = self.tileCoordsDict[tileName]['areaMaskInClipSection']
+            data[:minY, :] = 0
+            data[maxY:, :] = 0
+            data[:, :minX] = 0
+            data[:, maxX:] = 0
+        if returnWCS:
+            wcs = self['wcs']
+            if self.tileCoordsDict is not None and tileName in self.tileCoordsDict:
+                wcs = self.tileCoordsDict[tileName].get('wcs', wcs)
+            return data, wcs
+        return data
+
+    def preprocess(self, tileName='PRIMARY', diagnosticsDir=None):
+        """nemo/maps.py:178-480, the steps that apply to plain (map, weights, masks) inputs."""
+        for k in _UNSUPPORTED_KEYS:
+            if k in self and self[k] not in (None, False):
+                raise NotImplementedError("MapDict key '%s' (catalogue/simulation preprocessing, nemo/maps.py:294-465) "
+                                          "is not part of this build yet" % (k))
+        data, wcs = self.loadTile('mapFileName', tileName, returnWCS=True)
+        if 'calibFactor' in self.keys():
+            data = data * self['calibFactor']
+        if self.get('weightsFileName') is not None or self.get('weightsData') is not None:
+            weights = self.loadTile('weightsFileName', tileName)
+        else:
+            weights = np.ones(data.shape) if not _is_tensor(data) else engine.torch().ones_like(data)
+        data[weights == 0] = 0                                                    # :243
+        if self.get('surveyMask') is not None:
+            surveyMask = self.loadTile('surveyMask', tileName)
+        else:
+            if _is_tensor(data):
+                surveyMask = (weights != 0).to(engine.torch().uint8)
+            else:
+                surveyMask = np.ones(data.shape, dtype=np.uint8)
+                surveyMask[weights == 0] = 0
+        if self.get('pointSourceMask') is not None:
+            psMask = self.loadTile('pointSourceMask', tileName)
+        else:
+            psMask = np.ones(data.shape, dtype=np.uint8) if not _is_tensor(data) else \
+                engine.torch().ones(data.shape, dtype=engine.torch().uint8, device=data.device)
+        if self.get('flagMask') is not None:
+            flagMask = self.loadTile('flagMask', tileName) * surveyMask
+        else:
+            flagMask = np.zeros(tuple(data.shape), dtype=np.uint8)
+        if self.get('RADecSection') is not None:
+            RAMin, RAMax, decMin, decMax = self['RADecSection']
+            x0, y0 = wcs.wcs2pix(RAMax, decMin)
+            x1, y1 = wcs.wcs2pix(RAMin, decMax)
+            xa, xb = sorted([int(round(x0)), int(round(x1))])
+            ya, yb = sorted([int(round(y0)), int(round(y1))])
+            xa, ya = max(xa, 0), max(ya, 0)
+            xb, yb = min(xb, data.shape[1]), min(yb, data.shape[0])
+            sl = (slice(ya, yb), slice(xa, xb))
+            data, weights, psMask, surveyMask, flagMask = data[sl], weights[sl], psMask[sl], surveyMask[sl], flagMask[sl]
+            hdr = dict(wcs.header)
+            hdr['NAXIS1'], hdr['NAXIS2'] = xb - xa, yb - ya
+            hdr['CRPIX1'] = hdr['CRPIX1'] - xa
+            hdr['CRPIX2'] = hdr['CRPIX2'] - ya
+            wcs = type(wcs)(hdr)
+            if data.shape[0] == 0 or data.shape[1] == 0:
+                raise Exception("Clipping using RADecSection returned empty array - check RADecSection in config .yml file is in map")
+        self['data'] = data
+        self['weights'] = weights
+        self['wcs'] = wcs
+        self['surveyMask'] = surveyMask
+        self['pointSourceMask'] = psMask
+        self['flagMask'] = flagMask
+        self['tileName'] = tileName
+        if tuple(self['data'].shape) != tuple(self['pointSourceMask'].shape):
+            raise Exception("Map and point source mask dimensions are not the same (they should also have same WCS)")
+        if tuple(self['data'].shape) != tuple(self['surveyMask'].shape):
+            raise Exception("Map and survey mask dimensions are not the same (they should also have same WCS)")
+
+
+def pixelScalesDeg(wcs, RADeg='centre', decDeg='centre'):
+    """x / y pixel scales (degrees) at the given coordinates, as nemo/maps.py:1367-1377 derives them."""
+    ra0, dec0 = wcs.getCentreWCSCoords()
+    if RADeg != 'centre':
+        ra0 = float(RADeg)
+    if decDeg != 'centre':
+        dec0 = float(decDeg)
+    x0, y0 = wcs.wcs2pix(ra0, dec0)
+    ra1, dec1 = wcs.pix2wcs(x0 + 1, y0 + 1)
+    xPixScale = calcAngSepDeg(ra0, dec0, ra1, dec0)
+    yPixScale = calcAngSepDeg(ra0, dec0, ra0, dec1)
+    return xPixScale, yPixScale
+
+
+def smoothMap(data, wcs, RADeg='centre', decDeg='centre', smoothScaleDeg=5.0 / 60.0):
+    """nemo/maps.py:1357-1382: Gaussian smoothing at the given scale (device tensor in, device tensor out)."""
+    xPixScale, yPixScale = pixelScalesDeg(wcs, RADeg, decDeg)
+    eng = engine.TileEngine.get(data.shape)
+    d = engine.to_dev(data)
+    return eng.gaussian_filter(d, (smoothScaleDeg / yPixScale, smoothScaleDeg / xPixScale))
+
+
+def subtractBackground(data, wcs, RADeg='centre', decDeg='centre', smoothScaleDeg=30.0 / 60.0):
+    """nemo/maps.py:1279-1292."""
+    xPixScale, yPixScale = pixelScalesDeg(wcs, RADeg, decDeg)
+    eng = engine.TileEngine.get(data.shape)
+    d = engine.to_dev(data)
+    return eng.subtract_background(d, (smoothScaleDeg / yPixScale, smoothScaleDeg / xPixScale))

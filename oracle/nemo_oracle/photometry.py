@@ -1,0 +1,92 @@
+"""Oracle for the detection half of the path (TEST INFRASTRUCTURE - see package docstring).
+
+Restates nemo/photometry.py:25-248 (``findObjects``, ``getObjectPositions``) with scipy.ndimage,
+the same library the reference calls, so label numbering, centre-of-mass arithmetic and the
+whole-map spline are pinned by scipy itself.  WCS work is delegated to a caller-supplied
+``pix2wcs(x, y)``; naming / galactic latitude (astLib, absent offline) are left to the caller.
+"""
+import numpy as np
+from scipy import ndimage, interpolate
+
+
+def get_object_positions(mapData, threshold, findCenterOfMass=True):
+    """photometry.getObjectPositions (nemo/photometry.py:213-248)."""
+    if threshold < 0:
+        raise Exception("Detection threshold (thresholdSigma in the config file) cannot be negative "
+                        "unless in forced photometry mode.")
+    sigPix = np.array(np.greater(mapData, threshold), dtype=int)
+    if (sigPix != 0).sum() == 0:
+        return None
+    sigPixMask = np.equal(sigPix, 1)
+    segMap, numObjects = ndimage.label(sigPix)
+    objIDs = np.unique(segMap)
+    if findCenterOfMass:
+        positions = ndimage.center_of_mass(mapData, labels=segMap, index=objIDs)
+    else:
+        positions = ndimage.maximum_position(mapData, labels=segMap, index=objIDs)
+    numPix = ndimage.sum(sigPixMask, labels=segMap, index=objIDs)
+    return objIDs, positions, numPix, segMap
+
+
+def ring_mask(data, ringThresholdSigma, minRingPix=30):
+    """Ring detection (nemo/photometry.py:65-75): components above ``ringThresholdSigma`` with more than
+    ``minRingPix`` pixels whose centre of mass does not fall on one of their own pixels."""
+    ringIDs, ringPositions, ringNumPix, ringSegMap = get_object_positions(data, ringThresholdSigma,
+                                                                         findCenterOfMass=True)
+    for i in range(len(ringIDs)):
+        if type(ringNumPix) != float and ringNumPix[i] > minRingPix:
+            y, x = ringPositions[i]
+            if ringSegMap[int(y), int(x)] != ringIDs[i]:
+                sel = np.equal(ringSegMap, ringIDs[i])
+                ringSegMap[sel] = -1 * ringSegMap[sel]
+    return np.array(np.less(ringSegMap, 0), dtype=int)
+
+
+def find_objects(SNMap, flagMask, pix2wcs, threshold=3.0, minObjPix=3, findCenterOfMass=True, flagRings=True,
+                 ringThresholdSigma=0, ringFlagDistArcmin=12.0, ringFlagMinRingerSNR=20, invertMap=False,
+                 useInterpolator=True, angSepDeg=None):
+    """photometry.findObjects (nemo/photometry.py:25-210) up to the catalog rows (list of dicts with keys
+    id, x, y, RADeg, decDeg, numSigPix, SNR, flags, ringFlag).  Returns [] when nothing is significant."""
+    data = SNMap
+    if invertMap:
+        data = data * -1
+    stuff = get_object_positions(data, threshold, findCenterOfMass=findCenterOfMass)
+    if stuff is None:
+        return []
+    objIDs, objPositions, objNumPix, segMap = stuff
+    ringMask = ring_mask(data, ringThresholdSigma) if flagRings else None
+    if useInterpolator:
+        spline = interpolate.RectBivariateSpline(np.arange(data.shape[0]), np.arange(data.shape[1]),
+                                                 data, kx=3, ky=3)
+    catalog = []
+    idNumCount = 1
+    for i in range(len(objIDs)):
+        if type(objNumPix) != float and objNumPix[i] >= minObjPix:                # :106 (label 0 included)
+            obj = {'id': idNumCount, 'x': objPositions[i][1], 'y': objPositions[i][0], 'ringFlag': False}
+            if ringMask is not None and ringMask[int(obj['y']), int(obj['x'])] > 0:
+                obj['ringFlag'] = True
+            obj['RADeg'], obj['decDeg'] = pix2wcs(obj['x'], obj['y'])
+            if obj['RADeg'] < 0:
+                obj['RADeg'] = 360.0 + obj['RADeg']
+            obj['numSigPix'] = objNumPix[i]
+            if useInterpolator:
+                obj['SNR'] = spline(obj['y'], obj['x'])[0][0]
+            else:
+                obj['SNR'] = data[int(round(obj['y'])), int(round(obj['x']))]
+            obj['flags'] = flagMask[int(round(obj['y'])), int(round(obj['x']))]
+            if obj['SNR'] > threshold:                                            # :186
+                catalog.append(obj)
+            idNumCount = idNumCount + 1                                           # :188
+    if len(catalog) > 0 and angSepDeg is not None:                                # :196-208
+        ra = np.array([o['RADeg'] for o in catalog])
+        dec = np.array([o['decDeg'] for o in catalog])
+        snr = np.array([o['SNR'] for o in catalog])
+        high = snr > ringFlagMinRingerSNR
+        for o in catalog:
+            if o['ringFlag']:
+                rDeg = angSepDeg(o['RADeg'], o['decDeg'], ra[high], dec[high])
+                if np.logical_and((rDeg * 60) < ringFlagDistArcmin, rDeg > 0).sum() == 0:
+                    o['ringFlag'] = False
+        for o in catalog:
+            o['flags'] = o['flags'] + o['ringFlag']
+    return catalog

@@ -16,6 +16,10 @@
 #include "nf_common.h"
 #include "nf_fft.h"
 
+// The library is built with -ffp-contract=off (the stencil / painter kernels reproduce numpy roundings bit for bit);
+// the butterflies gain accuracy and speed from fused multiply-adds, so contraction is switched back on here.
+#pragma clang fp contract(fast)
+
 #include <cmath>
 #include <cstring>
 #include <vector>

@@ -217,9 +217,10 @@ class TileEngine(object):
     def paint(self, geom, table):
         """float32 template from a signals.RadialTable and the (A, B, C) haversine tables."""
         t = self.t
-        key = id(geom)
+        geom = tuple(np.ascontiguousarray(g, dtype=np.float64) for g in geom)
+        key = hash(b"".join(g.tobytes() for g in geom))
         if key not in self._geom:
-            self._geom = {key: tuple(to_dev(np.asarray(g, dtype=np.float64)) for g in geom)}
+            self._geom = {key: tuple(to_dev(g) for g in geom)}
         A, B, C = self._geom[key]
         if not hasattr(table, '_dev'):
             table._dev = (to_dev(table.r), to_dev(table.prof))
@@ -318,7 +319,7 @@ class TileEngine(object):
     def convolve(self, m32, kern2d):
         """scipy.ndimage.convolve(float32 map, float64 kernel), reflect (nemo/filters.py:1193)."""
         t = self.t
-        kf = to_dev(np.ascontiguousarray(np.asarray(kern2d, dtype=np.float64)[::-1, ::-1]))
+        kf = to_dev(np.array(np.asarray(kern2d, dtype=np.float64)[::-1, ::-1], order='C', copy=True))
         out = t.empty_like(m32)
         check(self.lib.nf_convolve2d(ptr(m32), ptr(out), self.H, self.W, ptr(kf), kern2d.shape[0], kern2d.shape[1],
                                      stream_ptr()), "nf_convolve2d")

@@ -69,3 +69,72 @@ def product_maps(mapsL):
 
 def oracle_find(SNMap, flagMask, wcs, **kw):
     return ophot.find_objects(SNMap, flagMask, wcs.pix2wcs, angSepDeg=calcAngSepDeg, **kw)
+
+
+def _section_slice(wcs, shape, RADecSection):
+    """Pixel window of an RADecSection (what MapDict.preprocess clips for the kernel build, nemo/maps.py:300-312)."""
+    RAMin, RAMax, decMin, decMax = RADecSection
+    x0, y0 = wcs.wcs2pix(RAMax, decMin)
+    x1, y1 = wcs.wcs2pix(RAMin, decMax)
+    xa, xb = sorted([int(round(x0)), int(round(x1))])
+    ya, yb = sorted([int(round(y0)), int(round(y1))])
+    xa, ya = max(xa, 0), max(ya, 0)
+    xb, yb = min(xb, shape[1]), min(yb, shape[0])
+    hdr = dict(wcs.header)
+    hdr['NAXIS1'], hdr['NAXIS2'] = xb - xa, yb - ya
+    hdr['CRPIX1'] = hdr['CRPIX1'] - xa
+    hdr['CRPIX2'] = hdr['CRPIX2'] - ya
+    return (slice(ya, yb), slice(xa, xb)), type(wcs)(hdr)
+
+
+def oracle_realspace(mapsL, wcs, params, kind):
+    """Oracle statement of RealSpaceMatchedFilter.buildAndApply (nemo/filters.py:888-1161) on one tile.
+    Returns (result dict, dict with kern2d, signalNorm, bckSubScaleArcmin)."""
+    shape = mapsL[0]['mapData'].shape
+    sl, subWCS = _section_slice(wcs, shape, params['noiseParams']['RADecSection'])
+    subMaps = []
+    for m in mapsL:
+        d = dict(m)
+        for k in ('mapData', 'weightsData', 'surveyMask', 'pointSourceMask'):
+            d[k] = np.ascontiguousarray(m[k][sl])
+        subMaps.append(d)
+    _, inner = oracle_matched(subMaps, subWCS, params, kind)
+    subShape = subMaps[0]['mapData'].shape
+    x0, y0 = int(subShape[1] / 2), int(subShape[0] / 2)
+    ra0, dec0 = subWCS.pix2wcs(x0, y0)
+    ra1, dec1 = subWCS.pix2wcs(x0 + 1, y0 + 1)
+    degPerPixX = calcAngSepDeg(ra0, dec0, ra1, dec0)
+    degPerPixY = calcAngSepDeg(ra0, dec0, ra0, dec1)
+    xRad = np.arange(int(np.floor(-subShape[1] / 2)), int(subShape[1] / 2), dtype=np.float64) * np.radians(degPerPixX)
+    yRad = np.arange(int(np.floor(-subShape[0] / 2)), int(subShape[0] / 2), dtype=np.float64) * np.radians(degPerPixY)
+    radiansMap = np.sqrt(xRad[None, :] ** 2 + yRad[:, None] ** 2)
+    kern2d, prof, arcminRange = ofilt.crop_kernel(inner.filt, radiansMap, degPerPixX, params['noiseParams']['kernelMaxArcmin'],
+                                                  symmetrize=params['noiseParams'].get('symmetrize', False))
+    if 'bckSubScaleArcmin' in params:
+        bckScale = params['bckSubScaleArcmin']
+    else:
+        func = np.min if np.greater(prof[0, 0], 0) == True else np.max
+        bckScale = arcminRange[prof[0] == func(prof[0])][0]
+    RAMin, RAMax, decMin, decMax = wcs.getImageMinMaxWCSCoords()
+    appRA, appDec = (RAMax + RAMin) / 2., (decMax + decMin) / 2.
+    sig = None
+    if params['bckSub'] == True and bckScale > 0:
+        xps, yps = pmaps.pixelScalesDeg(wcs, RADeg=appRA, decDeg=appDec)
+        sig = ofilt.smooth_sigma_pix(bckScale / 60., xps, yps)
+    RADeg, decDeg = wcs.getCentreWCSCoords()
+    geom = signals.paintGeometry(shape, wcs, RADeg, decDeg)
+    y0v = 2e-4
+    sigMaps = []
+    for m in mapsL:
+        amp = signals.convertToDeltaT(y0v, m['obsFreqGHz']) if params['outputUnits'] == 'yc' else None
+        sigMaps.append(cpu_paint(geom, signals.templateTables(kind, m['beamFileName'], params, amplitude=amp)))
+    filteredSignal, fRel = ofilt.real_space_apply(np.array(sigMaps), kern2d, 1.0, bckSubSigmaYX=sig, calcFRelWeights=True,
+                                                  obsFreqs=[m['obsFreqGHz'] for m in mapsL])
+    signalNorm = (y0v if params['outputUnits'] == 'yc' else 1.0) / filteredSignal.max()
+    raw = np.array([m['mapData'] for m in mapsL])
+    filtered = ofilt.real_space_apply(raw, kern2d, signalNorm, bckSubSigmaYX=sig)
+    weights = [m['weightsData'] for m in mapsL]
+    res = ofilt.real_space_finish(filtered, weights, mapsL[0]['surveyMask'], mapsL[0]['pointSourceMask'], params,
+                                  wcs.getPixelSizeDeg())
+    return res, {'kern2d': kern2d, 'signalNorm': signalNorm, 'bckSubScaleArcmin': bckScale, 'fRelWeights': fRel,
+                 'bckSigma': sig}

@@ -1,0 +1,360 @@
+"""GPU parity tests, one per C-ABI entry point (include/nemofilt.h), against numpy / scipy - the libraries the
+reference itself calls for these primitives.  Tolerances: bit-exact for integer / index
+work and for the kernels that reproduce scipy's accumulation order; 1e-12 relative for fp64 FFTs, 2e-5 for fp32."""
+import numpy as np
+import pytest
+from scipy import ndimage, interpolate
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from nemo_amd import engine  # noqa: E402
+from nemo_oracle import pixell_restated as enmap, filters as ofilt, photometry as ophot  # noqa: E402
+
+SHAPES = [(96, 120), (211, 256), (64, 1031), (1031, 48), (129, 86), (840, 1440)]
+
+
+def _eng(shape):
+    return engine.TileEngine.get(shape)
+
+
+def _np(t):
+    return t.cpu().numpy()
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_fft_forward_inverse(shape, dtype):
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((2,) + shape).astype(dtype)
+    eng = _eng(shape)
+    tol = 1e-12 if dtype == np.float64 else 3e-5
+    F = _np(eng.fft(engine.to_dev(x)))
+    ref = enmap.fft(x.astype(np.float64))
+    assert F.dtype == (np.complex128 if dtype == np.float64 else np.complex64)
+    assert np.abs(F - ref).max() / np.abs(ref).max() < tol
+    # apodised forward
+    Fa = _np(eng.fft(engine.to_dev(x), apod=True))
+    refa = enmap.fft(enmap.apod(x, 20).astype(np.float64))
+    assert np.abs(Fa - refa).max() / np.abs(refa).max() < tol
+    # inverse (normalize=False), real part as float32 and complex
+    G = (rng.standard_normal((2,) + shape) + 1j * rng.standard_normal((2,) + shape)).astype(F.dtype)
+    back = _np(eng.ifft(engine.to_dev(G), out='complex'))
+    refb = enmap.ifft(G.astype(np.complex128), normalize=False)
+    assert np.abs(back - refb).max() / np.abs(refb).max() < tol
+    r32 = _np(eng.ifft(engine.to_dev(G), out='f32'))
+    assert r32.dtype == np.float32
+    assert np.abs(r32 - refb.real).max() / np.abs(refb).max() < max(tol, 2e-7)
+    # round trip
+    rt = _np(eng.ifft(eng.fft(engine.to_dev(x)), out='complex', unitary=True))
+    assert np.abs(rt.real - x).max() < (1e-12 if dtype == np.float64 else 2e-5)
+
+
+def test_fft_4096_f64():
+    shape = (4096, 4096)
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal(shape)
+    F = _np(_eng(shape).fft(engine.to_dev(x)))
+    ref = enmap.fft(x)
+    assert np.abs(F - ref).max() / np.abs(ref).max() < 1e-12
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("N", [1, 2, 3])
+def test_cross_power_gauss_build_apply(dtype, N):
+    shape = (129, 86)
+    rng = np.random.default_rng(11)
+    eng = _eng(shape)
+    ctype = np.complex128 if dtype == np.float64 else np.complex64
+    F = (rng.standard_normal((N,) + shape) + 1j * rng.standard_normal((N,) + shape)).astype(ctype)
+    dF = engine.to_dev(F)
+    NP = _np(eng.cross_power(dF))
+    ref = np.array([[np.real(F[i] * F[j].conj()) for j in range(N)] for i in range(N)])
+    assert NP.dtype == dtype
+    # numpy evaluates re*re + im*im without fusing; the kernel may contract one product into an fma
+    assert np.abs(NP - ref).max() <= (1e-15 if dtype == np.float64 else 1e-6) * np.abs(ref).max()
+    # Gaussian smoothing of exactly the same input: bit-exact against scipy
+    sm = _np(eng.gaussian_filter(engine.to_dev(NP), (3, 3)))
+    refsm = np.array([[ndimage.gaussian_filter(NP[i, j], (3, 3)) for j in range(N)] for i in range(N)])
+    assert np.array_equal(sm, refsm)
+    # filter build from a well-conditioned covariance
+    cov = refsm.copy()
+    for i in range(N):
+        cov[i, i] += np.abs(cov).max()
+    S = (rng.standard_normal((N,) + shape) + 1j * rng.standard_normal((N,) + shape)).astype(ctype)
+    w = rng.uniform(-2, 2, N)
+    cov[:, :, 5, 7] = 0       # singular mode stays zero
+    filt = _np(eng.build_filter(engine.to_dev(cov), engine.to_dev(S), w))
+    rf = np.zeros((N,) + shape, dtype=np.float32)
+    for y in range(shape[0]):
+        for x in range(shape[1]):
+            try:
+                rf[:, y, x] = np.dot(np.linalg.inv(cov[:, :, y, x]), w * abs(S[:, y, x]))
+            except Exception:
+                continue
+    assert filt.dtype == np.float32
+    assert np.all(filt[:, 5, 7] == 0)
+    assert np.abs(filt - rf).max() <= (3e-7 if dtype == np.float64 else 2e-5) * np.abs(rf).max()
+    # application: sum_i F_i filt_i and per-frequency products
+    G = _np(eng.apply_filter(dF, engine.to_dev(rf), sum=True))
+    refG = (F * rf).sum(axis=0)
+    assert np.abs(G - refG).max() <= (1e-15 if dtype == np.float64 else 1e-6) * np.abs(refG).max()
+    Gp = _np(eng.apply_filter(dF, engine.to_dev(rf), sum=False))
+    assert np.abs(Gp - F * rf).max() <= (1e-15 if dtype == np.float64 else 1e-6) * np.abs(refG).max()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_gaussian_filter_and_background(dtype):
+    shape = (211, 256)
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal(shape).astype(dtype)
+    eng = _eng(shape)
+    for sig in [(3, 3), (7.3, 6.9), (0.8, 14.0)]:
+        got = _np(eng.gaussian_filter(engine.to_dev(x), sig))
+        assert np.array_equal(got, ndimage.gaussian_filter(x, sig))
+    got = _np(eng.subtract_background(engine.to_dev(x), (7.3, 6.9)))
+    assert np.array_equal(got, ofilt.subtract_background(x, (7.3, 6.9)))
+    # radius larger than the map (reflection wraps more than once)
+    small = (24, 40)
+    xs = rng.standard_normal(small).astype(dtype)
+    got = _np(_eng(small).gaussian_filter(engine.to_dev(xs), (9.0, 2.0)))
+    assert np.array_equal(got, ndimage.gaussian_filter(xs, (9.0, 2.0)))
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_apply_window(dtype):
+    shape = (129, 86)
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal(shape).astype(dtype)
+    eng = _eng(shape)
+    for p in (1.0, -1.0):
+        got = _np(eng.apply_window(engine.to_dev(x), p))
+        ref = enmap.apply_window(x.astype(np.float64), p)
+        assert got.dtype == dtype
+        assert np.abs(got - ref).max() < (1e-12 if dtype == np.float64 else 2e-5)
+    x[10:20, 10:20] = 0
+    got = _np(eng.undo_pixel_window(engine.to_dev(x)))
+    assert np.all(got[10:20, 10:20] == 0)
+    ref = ofilt.undo_pixel_window(x.astype(np.float64))
+    assert np.abs(got - ref).max() < (1e-12 if dtype == np.float64 else 2e-5)
+
+
+def test_convolve2d():
+    shape = (211, 256)
+    rng = np.random.default_rng(8)
+    x = rng.standard_normal(shape).astype(np.float32)
+    eng = _eng(shape)
+    for k in (29, 5, 1):
+        kern = rng.standard_normal((k, k))
+        kern[0, 0] = 0.0
+        got = _np(eng.convolve(engine.to_dev(x), kern))
+        assert np.array_equal(got, ndimage.convolve(x, kern))
+    kern = rng.standard_normal((9, 13))
+    got = _np(eng.convolve(engine.to_dev(x), kern))
+    assert np.array_equal(got, ndimage.convolve(x, kern))
+
+
+@pytest.mark.parametrize("vdtype", [np.float64, np.float32])
+@pytest.mark.parametrize("numBins", [1, 2, 8])
+def test_noise_map(vdtype, numBins):
+    shape = (211, 256)
+    rng = np.random.default_rng(21)
+    m = rng.standard_normal(shape).astype(vdtype)
+    m[rng.uniform(size=shape) > 0.999] += 40        # outliers the clipping must reject
+    m[:, :9] = 0
+    m[100:140, 60:130] = 0                           # a hole bigger than one cell's core
+    yy, xx = np.mgrid[0:shape[0], 0:shape[1]]
+    w1 = (1.0 + 3.0 * xx / shape[1] * yy / shape[0]).astype(vdtype)
+    w2 = (2.0 + np.sin(xx / 17.0)).astype(vdtype)
+    eng = _eng(shape)
+    pix = 0.5 / 60.0
+    for grid, wl in [(20.0, [w1]), (40.0, [w1, w2]), (None, [w1, w2, w2 * 0.5])]:
+        params = {'noiseGridArcmin': grid, 'numNoiseBins': numBins}
+        if grid is None:
+            del params['noiseGridArcmin']
+        ref = ofilt.make_noise_map(m, wl, params, pix)
+        med = eng.median_weights([engine.to_dev(w) for w in wl])
+        assert np.array_equal(_np(med), np.median(np.array(wl), axis=0))
+        got = _np(eng.noise_map(engine.to_dev(m), med, params, pix))
+        assert got.dtype == np.float32
+        nz = ref > 0
+        assert np.array_equal(got > 0, nz)
+        # float64 sums are accumulated in a different order than numpy's pairwise sum: agree to ~1e-13, i.e. exact
+        # after the float32 store except for rare 1-ulp flips
+        assert np.abs(got - ref).max() <= 1.2e-7 * ref.max()
+        # (float32 maps: numpy's mean / std accumulate in float32 pairwise order, the kernel in float64, so 1-ulp
+        # differences of the float32 result are common there)
+        assert (got != ref).mean() < (0.02 if vdtype == np.float64 else 0.6)
+    # constant weights: every percentile edge coincides (only the last bin is populated)
+    params = {'noiseGridArcmin': 20.0, 'numNoiseBins': numBins}
+    wc = np.ones(shape, dtype=vdtype)
+    ref = ofilt.make_noise_map(m, [wc], params, pix)
+    got = _np(eng.noise_map(engine.to_dev(m), engine.to_dev(wc), params, pix))
+    assert np.array_equal(got > 0, ref > 0)
+    assert np.abs(got - ref).max() <= 1.2e-7 * max(ref.max(), 1e-30)
+    # all-zero map
+    got = _np(eng.noise_map(engine.to_dev(np.zeros(shape, dtype=vdtype)), engine.to_dev(wc), params, pix))
+    assert np.all(got == 0)
+
+
+@pytest.mark.parametrize("vdtype", [np.float64, np.float32])
+def test_edge_check_and_finalize(vdtype):
+    shape = (129, 86)
+    rng = np.random.default_rng(31)
+    f = rng.standard_normal(shape).astype(vdtype)
+    f[:, :7] = 0
+    f[50:60, 30:45] = 0
+    ps = np.ones(shape, dtype=np.uint8)
+    ps[50:60, 30:45] = 0
+    ps[80:84, 10:14] = 0
+    f = f * ps
+    sm = np.ones(shape, dtype=np.uint8)
+    sm[:, -9:] = 0
+    rms = np.abs(rng.standard_normal(shape)).astype(np.float32)
+    rms[20:30, 20:30] = 0
+    eng = _eng(shape)
+    for size in (6, 7):
+        ref = ndimage.rank_filter(abs(f + (1 - ps)), 0, size=(size, size)) > 0
+        got = _np(eng.edge_check(engine.to_dev(f), engine.to_dev(ps), size))
+        assert np.array_equal(got > 0, ref)
+    for trim, fourier in [(6, True), (0, True), (6, False)]:
+        fm, sn, smask = ofilt._snr_and_masks(f.copy(), rms, sm, ps, trim, fourier)
+        if fourier:
+            fm = fm * smask
+        apod = np.equal(enmap.apod(np.ones(shape), 20), 1)
+        smask = smask * apod
+        sn = sn * smask
+        sn[np.isnan(sn)] = 0
+        rr = rms * smask
+        edge = eng.edge_check(engine.to_dev(f), engine.to_dev(ps), trim) if trim > 0 else None
+        d, s, r, mk = eng.finalize(engine.to_dev(f.copy()), engine.to_dev(rms), engine.to_dev(sm), engine.to_dev(ps), edge,
+                                   fourier)
+        assert np.array_equal(_np(mk) > 0, smask > 0)
+        assert np.array_equal(_np(d), fm.astype(vdtype))
+        assert np.array_equal(_np(s), sn.astype(vdtype))
+        assert np.array_equal(_np(r), rr.astype(np.float32))
+
+
+def _blob_map(shape, seed, dtype):
+    rng = np.random.default_rng(seed)
+    m = ndimage.gaussian_filter(rng.standard_normal(shape), 1.5)
+    m = m / m.std()
+    yy, xx = np.mgrid[0:shape[0], 0:shape[1]]
+    # a ring (centre of mass outside itself), a U shape (labels that merge late), a long snake
+    r = np.hypot(yy - 60, xx - 70)
+    m[(r > 8) & (r < 11)] = 8.0
+    m[100:130, 20] = 7.0
+    m[100:130, 40] = 7.0
+    m[130, 20:41] = 7.0
+    for k in range(0, 60, 4):
+        m[150 + (k // 4) % 2 * 3:154 + (k // 4) % 2 * 3, 100 + k:104 + k] = 6.0
+    # no exact ties: ndimage.maximum_position's choice among equal maxima depends on an unstable sort
+    m = m + 1e-3 * rng.standard_normal(shape)
+    return m.astype(dtype)
+
+
+@pytest.mark.parametrize("vdtype", [np.float64, np.float32])
+@pytest.mark.parametrize("thr", [4.0, 0.5, 0.0])
+def test_label_and_object_stats(vdtype, thr):
+    shape = (211, 256)
+    m = _blob_map(shape, 5, vdtype)
+    eng = _eng(shape)
+    d = engine.to_dev(m)
+    labels, n = eng.label(d, thr)
+    refLab, refN = ndimage.label(m > thr)
+    assert n == refN
+    assert np.array_equal(_np(labels), refLab)
+    st = _np(eng.object_stats(d, labels, n))
+    ids = np.arange(1, n + 1)
+    cnt = ndimage.sum(m > thr, labels=refLab, index=ids)
+    assert np.array_equal(st[1:, 0], cnt)
+    com = np.array(ndimage.center_of_mass(m, labels=refLab, index=ids))
+    got = np.stack([st[1:, 2] / st[1:, 1], st[1:, 3] / st[1:, 1]], axis=1)
+    big = np.abs(st[1:, 1]) > 1e-3         # centre of mass is ill-conditioned when sum v ~ 0 (threshold 0)
+    assert np.abs(got - com)[big].max() < 1e-9
+    mp = np.array(ndimage.maximum_position(m, labels=refLab, index=ids))
+    assert np.array_equal(st[1:, 5].astype(int), mp[:, 0] * shape[1] + mp[:, 1])
+    assert np.array_equal(st[1:, 4], ndimage.maximum(m, labels=refLab, index=ids).astype(np.float64))
+    # negated map
+    labels2, n2 = eng.label(d, 2.0, negate=True)
+    refLab2, refN2 = ndimage.label((m * -1) > 2.0)
+    assert n2 == refN2 and np.array_equal(_np(labels2), refLab2)
+
+
+def test_label_edge_cases():
+    shape = (64, 1031)
+    eng = _eng(shape)
+    z = np.zeros(shape)
+    labels, n = eng.label(engine.to_dev(z), 1.0)
+    assert n == 0 and not _np(labels).any()
+    labels, n = eng.label(engine.to_dev(z + 2), 1.0)
+    assert n == 1 and np.all(_np(labels) == 1)
+    # checkerboard: every foreground pixel is its own 4-connected component
+    cb = (np.indices(shape).sum(axis=0) % 2).astype(np.float64) * 3
+    labels, n = eng.label(engine.to_dev(cb), 1.0)
+    refLab, refN = ndimage.label(cb > 1.0)
+    assert n == refN and np.array_equal(_np(labels), refLab)
+    # comb: one component whose teeth meet only in the last row
+    comb = np.zeros(shape)
+    comb[:, ::2] = 3
+    comb[-1, :] = 3
+    labels, n = eng.label(engine.to_dev(comb), 1.0)
+    assert n == 1 and np.array_equal(_np(labels) > 0, comb > 1)
+
+
+def test_map_max():
+    shape = (129, 86)
+    rng = np.random.default_rng(9)
+    m = rng.standard_normal(shape).astype(np.float32)
+    m[40, 40] = m[90, 3] = 11.0
+    v, i = _eng(shape).map_max(engine.to_dev(m))
+    assert v == 11.0 and i == np.argmax(m)
+    v, i = _eng(shape).map_max(engine.to_dev(-np.abs(m).astype(np.float64) - 1))
+    assert v == (-np.abs(m).astype(np.float64) - 1).max() and i == np.argmax(-np.abs(m).astype(np.float64) - 1)
+
+
+@pytest.mark.parametrize("vdtype", [np.float64, np.float32])
+def test_spline_eval(vdtype):
+    shape = (211, 256)
+    rng = np.random.default_rng(13)
+    m = ndimage.gaussian_filter(rng.standard_normal(shape), 1.2).astype(vdtype)
+    spl = interpolate.RectBivariateSpline(np.arange(shape[0]), np.arange(shape[1]), m, kx=3, ky=3)
+    pts = np.stack([rng.uniform(0, shape[0] - 1, 200), rng.uniform(0, shape[1] - 1, 200)], axis=1)
+    pts[:6] = [[0, 0], [shape[0] - 1, shape[1] - 1], [0.3, 100.2], [105.5, 0.7], [105.0, 128.0], [209.9, 254.9]]
+    got = _eng(shape).spline_eval(engine.to_dev(m), pts)
+    ref = np.array([spl(y, x)[0][0] for y, x in pts])
+    assert np.abs(got - ref).max() < 1e-12 * max(1.0, np.abs(ref).max()) * (1 if vdtype == np.float64 else 10)
+
+
+def test_ring_flags_match_oracle():
+    shape = (211, 256)
+    m = _blob_map(shape, 6, np.float64)
+    eng = _eng(shape)
+    d = engine.to_dev(m)
+    labels, n = eng.label(d, 0.5)
+    st = eng.object_stats(d, labels, n)
+    isRing = _np(eng.ring_flags(labels, st, n, minRingPix=30))
+    ringMask = ophot.ring_mask(m, 0.5)
+    lab = _np(labels)
+    assert np.array_equal(isRing[lab] > 0, ringMask > 0)
+    assert ringMask.sum() > 0
+
+
+def test_paint_radial_matches_numpy_painter():
+    import helpers
+    from nemo_amd import signals
+    from nemo_amd.wcs import CARWCS
+    shape = (129, 86)
+    wcs = CARWCS.make(shape, RADeg=10.0, decDeg=-12.0)
+    beam = signals.BeamProfile(FWHMArcmin=1.4)
+    eng = _eng(shape)
+    for kind, params, amp in [('beam', {}, None), ('arnaud', {'z': 0.4, 'M500MSun': 2e14}, None),
+                              ('arnaud', {'z': 0.2, 'M500MSun': 8e14}, -3.7e2), ('beam', {}, 612.0)]:
+        for (ra, dec) in [wcs.getCentreWCSCoords(), wcs.pix2wcs(3.3, 100.9)]:
+            geom = signals.paintGeometry(shape, wcs, ra, dec)
+            table = signals.templateTables(kind, beam, params, amplitude=amp)
+            got = _np(eng.paint(geom, table))
+            ref = helpers.cpu_paint(geom, table)
+            assert got.dtype == np.float32
+            assert np.array_equal(got, ref)

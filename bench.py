@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""Headline benchmark: filtered Mpix/s of the map-filtering + detection hot path (BASELINE.json `metric`).
+
+Workload (BASELINE.json configs[1], SURVEY.md 8d "C2"): one 4096 x 4096 f090 tile per GPU, float64 maps,
+ArnaudModelMatchedFilter at 15 theta500 scales (examples/ACT-DR5-clusters/DR5ClusterSearch.yml:95-127, photFilter first),
+noise method dataMap, 40' noise grid, outputUnits yc, pixel-window undo, then photometry.findObjects at 4 sigma on every
+scale.  A "step" is one pass of that whole path over the tile (data FFT and noise covariance once, then the 15 scales);
+Mpix counts H*W*N*S per step.  Inputs are synthetic (seeded CMB + white noise + 50 painted GNFW clusters) and resident in
+HBM before the timed region starts.  N GPUs = N tiles (weak scaling; tiles are independent, no data-path collective).
+
+  python bench.py --gpus 1 --steps 3 --warmup 1
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.  `roofline` is for the kernel with the largest share of device time, timed with HIP
+events inside the library on the stream it runs on (nf_profile_*); `cpu_baseline` is the oracle (numpy/scipy restatement
+of the reference algorithm) timed on the host cores, on a bounded sample, before the GPU is touched.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E peak (MI355X_MICROARCH.md)
+
+SCALES = [(m, z) for z in (0.2, 0.4, 0.8, 1.2) for m in (1.0e14, 2.0e14, 4.0e14, 8.0e14)][:15]
+PHOT_FILTER = "Arnaud_M2e14_z0p4"
+
+
+def filter_list(numScales):
+    out = []
+    for m, z in SCALES[:numScales]:
+        label = "Arnaud_M%de14_z%s" % (int(round(m / 1e14)), ("%.1f" % z).replace(".", "p"))
+        out.append({'label': label, 'class': 'ArnaudModelMatchedFilter',
+                    'params': {'noiseParams': {'method': 'dataMap', 'noiseGridArcmin': 40.0}, 'outputUnits': 'yc',
+                               'edgeTrimArcmin': 0.0, 'M500MSun': m, 'z': z, 'saveFilteredMaps': False,
+                               'saveRMSMap': False, 'savePlots': False, 'saveDS9Regions': False}})
+    # photFilter first (nemo/pipelines.py:161-173)
+    out.sort(key=lambda f: 0 if f['label'] == PHOT_FILTER else 1)
+    return out
+
+
+def make_workload(shape, seed, dtype):
+    """Synthetic tile resident in HBM: numpy CMB + noise realisation, clusters painted on the GPU."""
+    import numpy as np
+    from nemo_amd import signals, simgen, engine, maps as pmaps
+    beam = signals.BeamProfile(FWHMArcmin=2.1)
+    mapsL, wcs, truth = simgen.makeSimTile(shape, [97.8], [beam], [30.0], seed=seed, numSources=0, painter=None,
+                                           dtype=np.float64)
+    t = engine.torch()
+    eng = engine.TileEngine.get(shape)
+    m = mapsL[0]
+    data = engine.to_dev(m['mapData'])
+    rng = np.random.default_rng(seed + 7)
+    bank = [(mm, zz) for mm, zz in SCALES]
+    for k in range(50):
+        y = rng.uniform(60, shape[0] - 60)
+        x = rng.uniform(60, shape[1] - 60)
+        ra, dec = wcs.pix2wcs(x, y)
+        y0 = rng.uniform(0.5e-4, 5e-4)
+        mm, zz = bank[k % len(bank)]
+        geom = signals.paintGeometry(shape, wcs, ra, dec)
+        table = signals.templateTables('arnaud', beam, {'z': zz, 'M500MSun': mm},
+                                       amplitude=signals.convertToDeltaT(y0, 97.8))
+        data += eng.paint(geom, table).to(t.float64)
+        truth.append({'RADeg': ra, 'decDeg': dec, 'y0': y0})
+    tdt = t.float64 if dtype == 'f64' else t.float32
+    md = pmaps.MapDict({'mapData': data.to(tdt), 'weightsData': engine.to_dev(m['weightsData']).to(tdt),
+                        'obsFreqGHz': 97.8, 'units': 'uK', 'beamFileName': beam, 'label': 'f090', 'wcs': wcs,
+                        'surveyMask': t.ones(shape, dtype=t.uint8, device=data.device),
+                        'pointSourceMask': t.ones(shape, dtype=t.uint8, device=data.device)})
+    return [md], wcs, truth
+
+
+def run_step(mapsList, filtersList, verbose=False):
+    from nemo_amd import filters, photometry, catalogs
+    tileCache = {}
+    catalogDict = {}
+    for f in filtersList:
+        fmd = filters.filterMaps(mapsList, f, 'PRIMARY', diagnosticsDir=None, selFnDir=None, verbose=False,
+                                 undoPixelWindow=True, tileCache=tileCache)
+        cat = photometry.findObjects(fmd, threshold=4.0, minObjPix=1, rejectBorder=0, findCenterOfMass=True,
+                                     useInterpolator=True, objIdent='ACT-CL', longNames=False, verbose=False)
+        catalogDict[f['label'] + "#PRIMARY"] = {'catalog': cat}
+        del fmd
+    optimal = catalogs.makeOptimalCatalog(catalogDict, constraintsList=[], photFilter=None, method='ref-first')
+    return optimal
+
+
+def cpu_baseline(procs, size):
+    """Oracle timed on the host: `procs` processes, each one scale of a size x size crop of the same workload."""
+    cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "--size", str(size)]
+    t0 = time.time()
+    ps = [subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                           env=dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1"))
+          for _ in range(procs)]
+    secs = []
+    for p in ps:
+        out, err = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError("cpu baseline failed: %s" % err[-2000:])
+        secs.append(json.loads(out.strip().splitlines()[-1])['seconds'])
+    wall = max(secs)
+    return {'value': round(procs * size * size / 1e6 / wall, 4), 'unit': 'Mpix/s', 'cores': procs, 'kind': 'port',
+            'sample': "%d process(es), each 1 scale (Arnaud M2e14 z0.4) of a %dx%d f64 crop of the same workload: "
+                      "oracle MatchedFilter.buildAndApply + pixel-window undo + find_objects (vectorised inverse); "
+                      "%.1f s per process" % (procs, size, size, wall),
+            'launch_wall_s': round(time.time() - t0, 2)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--size", type=int, default=4096, help="tile side in pixels (headline: 4096)")
+    ap.add_argument("--scales", type=int, default=15)
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--cpu-procs", type=int, default=-1, help="processes for the CPU baseline (0 = skip; -1 = auto)")
+    ap.add_argument("--cpu-size", type=int, default=2048)
+    ap.add_argument("--no-profile", action="store_true", help="do not record per-entry-point HIP events")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+
+    # ---- CPU baseline first: nothing has touched the GPU yet, so child processes are plain fork/exec -------------
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_procs != 0:
+        procs = args.cpu_procs if args.cpu_procs > 0 else max(1, min(16, int(os.environ.get("OMP_NUM_THREADS", "8"))))
+        cpu = cpu_baseline(procs, args.cpu_size)
+
+    import torch
+    from nemo_amd import _lib, engine, pipelines
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    pipelines.initDistributed()
+    import torch.distributed as dist
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local % torch.cuda.device_count())
+    lib = _lib.load()
+    shape = (args.size, args.size)
+    mapsList, wcs, truth = make_workload(shape, 1234 + rank, args.dtype)
+    filtersList = filter_list(args.scales)
+    N, S = 1, len(filtersList)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        cat = run_step(mapsList, filtersList)
+    barrier()
+    if not args.no_profile:
+        lib.nf_profile_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        cat = run_step(mapsList, filtersList)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+
+    # ---- per-entry-point device time from the library's HIP events ------------------------------------------
+    import ctypes
+    kernels = {}
+    if not args.no_profile:
+        for tag in range(lib.nf_profile_num_tags()):
+            n, ms, by = ctypes.c_longlong(0), ctypes.c_double(0), ctypes.c_double(0)
+            _lib.check(lib.nf_profile_read(tag, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(by)), "nf_profile_read")
+            if n.value > 0:
+                kernels[lib.nf_profile_tag_name(tag).decode()] = {
+                    'calls': n.value, 'ms_total': round(ms.value, 3), 'avg_us': round(1e3 * ms.value / n.value, 2),
+                    'alg_GB_per_call': round(by.value / n.value / 1e9, 6),
+                    'GBps': round(by.value / 1e9 / (ms.value / 1e3), 1) if ms.value > 0 else None}
+        lib.nf_profile_enable(0)
+
+    if rank == 0:
+        mpix = shape[0] * shape[1] * N * S * args.steps * world / 1e6
+        out = {"metric": "filtered Mpix/sec (all scales, all freqs)", "value": round(mpix / elapsed, 2), "unit": "Mpix/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(1e3 * elapsed / args.steps, 2), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+               "config": {"workload": "C2: one %dx%d f090 tile per GPU, ArnaudModelMatchedFilter x %d theta500 scales "
+                                      "(DR5 bank), dataMap noise, 40' grid, yc, pixel-window undo, findObjects 4 sigma"
+                                      % (shape[0], shape[1], S),
+                          "tile": list(shape), "frequencies": N, "scales": S, "tiles_per_gpu": 1,
+                          "objects_in_optimal_catalog": int(len(cat))}}
+        if kernels:
+            dom = max(kernels, key=lambda k: kernels[k]['ms_total'])
+            devMs = sum(k['ms_total'] for k in kernels.values())
+            algGB = sum(k['alg_GB_per_call'] * k['calls'] for k in kernels.values())
+            out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]['GBps'], "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": round(kernels[dom]['GBps'] / HBM_PEAK_GBS, 4), "traffic": None,
+                               "avg_us": kernels[dom]['avg_us'], "alg_GB_per_launch": kernels[dom]['alg_GB_per_call'],
+                               "share_of_device_time": round(kernels[dom]['ms_total'] / devMs, 3)}
+            out["pipeline"] = {"device_ms_per_step": round(devMs / args.steps, 2),
+                               "alg_GB_per_step": round(algGB / args.steps, 3),
+                               "hbm_frac_device_time": round(algGB / (devMs / 1e3) / HBM_PEAK_GBS, 4),
+                               "hbm_frac_wall": round(algGB / elapsed / HBM_PEAK_GBS, 4)}
+            out["kernels"] = kernels
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -153,6 +153,16 @@ int nf_ring_flags(const int* ringLabels_d, const double* ringStats_d, int numRin
 int nf_spline_eval(int vtype, const void* map_d, int negate, int H, int W, const double* yx_d, int nPts, int halfWin,
                    double* out_d, void* stream);
 
+/* Instrumentation (no counterpart in the reference; used by bench.py): when enabled, every entry point above brackets
+ * the work it enqueues with a HIP event pair on the caller's stream.  nf_profile_enable(on) switches recording and
+ * clears earlier records; nf_profile_read synchronises the recorded events of one tag and returns the number of calls,
+ * their summed device time (ms) and their summed algorithmic HBM bytes (inputs read once + outputs written once).
+ * Tags 0..nf_profile_num_tags()-1 are named by nf_profile_tag_name (fft_rows_f64, fft_cols_f64, ..., spline_eval). */
+int nf_profile_enable(int on);
+int nf_profile_num_tags(void);
+const char* nf_profile_tag_name(int tag);
+int nf_profile_read(int tag, long long* count, double* totalMs, double* totalBytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -9,6 +9,7 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <vector>
 
 static thread_local std::string g_lastError;
 
@@ -17,6 +18,51 @@ void nf_set_error(const std::string& msg) { g_lastError = msg; }
 int nf_hip_fail(hipError_t e, const char* what) {
     g_lastError = std::string(what) + ": " + hipGetErrorString(e);
     return NF_ERR_HIP;
+}
+
+// ---- profiler: event pairs around entry points, resolved when read --------------------------------------------
+namespace {
+struct ProfRec {
+    int tag;
+    double bytes;
+    hipEvent_t a, b;
+};
+const int kProfMax = 1 << 16;
+bool g_profOn = false;
+std::mutex g_profMu;
+std::vector<ProfRec> g_profRecs;       // used records [0, g_profUsed)
+int g_profUsed = 0;
+const char* kProfNames[nf::PT_COUNT] = {
+    "fft_rows_f64", "fft_cols_f64", "fft_rows_f32", "fft_cols_f32", "cross_power", "gaussian_filter", "build_filter",
+    "apply_filter", "window_mul", "paint_radial", "scale_mask", "noise_map", "median_stack", "edge_check", "finalize",
+    "restore_zeros", "subtract", "convolve2d", "label_components", "object_stats", "map_max", "ring_flags", "spline_eval"};
+}  // namespace
+
+nf::ProfScope::ProfScope(int tag, hipStream_t s, double bytes) : slot(-1), stream(s) {
+    if (!g_profOn) return;
+    std::lock_guard<std::mutex> lock(g_profMu);
+    if (g_profUsed >= kProfMax) return;
+    if (g_profUsed >= (int)g_profRecs.size()) {
+        ProfRec r;
+        r.tag = 0;
+        r.bytes = 0;
+        if (hipEventCreate(&r.a) != hipSuccess) return;
+        if (hipEventCreate(&r.b) != hipSuccess) {
+            (void)hipEventDestroy(r.a);
+            return;
+        }
+        g_profRecs.push_back(r);
+    }
+    slot = g_profUsed++;
+    g_profRecs[slot].tag = tag;
+    g_profRecs[slot].bytes = bytes;
+    (void)hipEventRecord(g_profRecs[slot].a, s);
+}
+
+nf::ProfScope::~ProfScope() {
+    if (slot < 0) return;
+    std::lock_guard<std::mutex> lock(g_profMu);
+    (void)hipEventRecord(g_profRecs[slot].b, stream);
 }
 
 struct nf_plan {
@@ -65,6 +111,40 @@ int nf_device_count(void) {
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess) return nf_hip_fail(e, "hipGetDeviceCount");
     return n;
+}
+
+int nf_profile_enable(int on) {
+    std::lock_guard<std::mutex> lock(g_profMu);
+    g_profOn = on != 0;
+    g_profUsed = 0;
+    return NF_OK;
+}
+
+int nf_profile_num_tags(void) { return nf::PT_COUNT; }
+
+const char* nf_profile_tag_name(int tag) { return (tag >= 0 && tag < nf::PT_COUNT) ? kProfNames[tag] : ""; }
+
+int nf_profile_read(int tag, long long* count, double* totalMs, double* totalBytes) {
+    if (tag < 0 || tag >= nf::PT_COUNT || !count || !totalMs || !totalBytes) {
+        nf_set_error("nf_profile_read: bad arguments");
+        return NF_ERR_ARG;
+    }
+    std::lock_guard<std::mutex> lock(g_profMu);
+    long long n = 0;
+    double ms = 0, by = 0;
+    for (int i = 0; i < g_profUsed; ++i) {
+        if (g_profRecs[i].tag != tag) continue;
+        NF_HIP(hipEventSynchronize(g_profRecs[i].b));
+        float t = 0;
+        NF_HIP(hipEventElapsedTime(&t, g_profRecs[i].a, g_profRecs[i].b));
+        ms += t;
+        by += g_profRecs[i].bytes;
+        ++n;
+    }
+    *count = n;
+    *totalMs = ms;
+    *totalBytes = by;
+    return NF_OK;
 }
 
 int nf_plan_create(int H, int W, nf_plan** plan) {
@@ -126,6 +206,8 @@ int nf_cross_power(int prec, const void* F, void* NP, int N, long long npix, voi
         nf_set_error("nf_cross_power: bad arguments");
         return NF_ERR_ARG;
     }
+    const double es = prec == NF_F32 ? 4.0 : 8.0;
+    nf::ProfScope ps(nf::PT_CROSS_POWER, S(stream), (double)npix * (N * 2 * es + (double)N * N * es));
     if (prec == NF_F32) return nf::cross_power<float>(F, NP, N, npix, S(stream));
     return nf::cross_power<double>(F, NP, N, npix, S(stream));
 }
@@ -136,6 +218,7 @@ int nf_gaussian_filter(int rtype, const void* in, void* tmp, void* out, int H, i
         nf_set_error("nf_gaussian_filter: bad arguments");
         return NF_ERR_ARG;
     }
+    nf::ProfScope ps(nf::PT_GAUSSIAN, S(stream), (double)H * W * batch * 2 * (rtype == NF_F32 ? 4.0 : 8.0));
     return nf::gaussian_filter(rtype, in, tmp, out, H, W, batch, wY, radY, wX, radX, S(stream));
 }
 
@@ -148,6 +231,8 @@ int nf_build_filter(int covType, int sigType, const void* cov, const void* Sg, c
     nf::WeightVec wv;
     memset(&wv, 0, sizeof(wv));
     for (int i = 0; i < N; ++i) wv.v[i] = w[i];
+    nf::ProfScope ps(nf::PT_BUILD_FILTER, S(stream),
+                     (double)npix * ((double)N * N * (covType == NF_F32 ? 4.0 : 8.0) + N * (sigType == NF_F32 ? 8.0 : 16.0) + N * 4.0));
     return nf::build_filter(covType, sigType, cov, Sg, wv, filt, N, npix, S(stream));
 }
 
@@ -156,6 +241,8 @@ int nf_apply_filter(int prec, const void* F, const float* filt, void* G, int N, 
         nf_set_error("nf_apply_filter: bad arguments");
         return NF_ERR_ARG;
     }
+    const double cs = prec == NF_F32 ? 8.0 : 16.0;
+    nf::ProfScope ps(nf::PT_APPLY_FILTER, S(stream), (double)npix * (N * cs + N * 4.0 + (sum ? 1 : N) * cs));
     if (prec == NF_F32) return nf::apply_filter<float>(F, filt, G, N, sum, npix, S(stream));
     return nf::apply_filter<double>(F, filt, G, N, sum, npix, S(stream));
 }
@@ -165,6 +252,7 @@ int nf_window_mul(int prec, void* F, const double* wy, const double* wx, int H, 
         nf_set_error("nf_window_mul: bad arguments");
         return NF_ERR_ARG;
     }
+    nf::ProfScope ps(nf::PT_WINDOW_MUL, S(stream), (double)H * W * batch * 2 * (prec == NF_F32 ? 8.0 : 16.0));
     if (prec == NF_F32) return nf::window_mul<float>(F, wy, wx, H, W, batch, S(stream));
     return nf::window_mul<double>(F, wy, wx, H, W, batch, S(stream));
 }
@@ -175,6 +263,7 @@ int nf_paint_radial(float* out, int H, int W, const double* A, const double* B, 
         nf_set_error("nf_paint_radial: bad arguments");
         return NF_ERR_ARG;
     }
+    nf::ProfScope ps(nf::PT_PAINT, S(stream), (double)H * W * 4.0);
     return nf::paint_radial(out, H, W, A, B, C, r, prof, ntab, r0, dlnr, amp, sign, S(stream));
 }
 
@@ -183,6 +272,7 @@ int nf_scale_mask(int vtype, const float* in, void* out, double norm, const unsi
         nf_set_error("nf_scale_mask: bad arguments");
         return NF_ERR_ARG;
     }
+    nf::ProfScope ps(nf::PT_SCALE_MASK, S(stream), (double)n * (4.0 + (vtype == NF_F32 ? 4.0 : 8.0) + (psMask ? 1.0 : 0.0)));
     return nf::scale_mask(vtype, in, out, norm, psMask, n, S(stream));
 }
 
@@ -213,6 +303,8 @@ int nf_noise_map(int vtype, const void* filtered, const void* weights, int wtype
     g.yEdges = yEdges;
     g.xEdges = xEdges;
     for (int i = 0; i < numBins && quantiles; ++i) g.quantiles[i] = quantiles[i];
+    nf::ProfScope ps(nf::PT_NOISE_MAP, S(stream),
+                     (double)H * W * ((vtype == NF_F32 ? 4.0 : 8.0) + (wtype == NF_F32 ? 4.0 : 8.0) + 4.0));
     return nf::noise_map(vtype, filtered, weights, wtype, rms, H, W, g, work, workBytes, S(stream));
 }
 
@@ -221,6 +313,7 @@ int nf_median_stack(int rtype, const void* in, void* out, int N, long long n, vo
         nf_set_error("nf_median_stack: bad arguments (1 <= N <= 8)");
         return NF_ERR_ARG;
     }
+    nf::ProfScope ps(nf::PT_MEDIAN_STACK, S(stream), (double)n * (N + 1) * (rtype == NF_F32 ? 4.0 : 8.0));
     return nf::median_stack(rtype, in, out, N, n, S(stream));
 }
 
@@ -230,6 +323,7 @@ int nf_edge_check(int vtype, const void* filtered, const unsigned char* psMask, 
         nf_set_error("nf_edge_check: bad arguments");
         return NF_ERR_ARG;
     }
+    nf::ProfScope ps(nf::PT_EDGE_CHECK, S(stream), (double)H * W * ((vtype == NF_F32 ? 4.0 : 8.0) + 2.0));
     return nf::edge_check(vtype, filtered, psMask, tmp, out, H, W, size, S(stream));
 }
 
@@ -240,6 +334,7 @@ int nf_finalize(int vtype, void* filtered, const float* rms, const unsigned char
         nf_set_error("nf_finalize: bad arguments");
         return NF_ERR_ARG;
     }
+    nf::ProfScope ps(nf::PT_FINALIZE, S(stream), (double)H * W * (3 * (vtype == NF_F32 ? 4.0 : 8.0) + 8.0 + 4.0));
     return nf::finalize(vtype, filtered, rms, surveyMask, psMask, edgeCheck, sn, rmsOut, maskOut, H, W, apodPix, mulSurvey,
                         S(stream));
 }
@@ -249,6 +344,7 @@ int nf_restore_zeros(int vtype, void* data, const void* ref, long long n, void* 
         nf_set_error("nf_restore_zeros: bad arguments");
         return NF_ERR_ARG;
     }
+    nf::ProfScope ps(nf::PT_RESTORE_ZEROS, S(stream), (double)n * 3 * (vtype == NF_F32 ? 4.0 : 8.0));
     return nf::restore_zeros(vtype, data, ref, n, S(stream));
 }
 
@@ -257,6 +353,7 @@ int nf_subtract(int rtype, const void* a, const void* b, void* out, long long n,
         nf_set_error("nf_subtract: bad arguments");
         return NF_ERR_ARG;
     }
+    nf::ProfScope ps(nf::PT_SUBTRACT, S(stream), (double)n * 3 * (rtype == NF_F32 ? 4.0 : 8.0));
     return nf::subtract(rtype, a, b, out, n, S(stream));
 }
 
@@ -265,6 +362,7 @@ int nf_convolve2d(const float* in, float* out, int H, int W, const double* kernF
         nf_set_error("nf_convolve2d: bad arguments");
         return NF_ERR_ARG;
     }
+    nf::ProfScope ps(nf::PT_CONVOLVE2D, S(stream), (double)H * W * 8.0);
     return nf::convolve2d(in, out, H, W, kernFlipped, kh, kw, S(stream));
 }
 
@@ -274,6 +372,7 @@ int nf_label_components(int vtype, const void* sn, double threshold, int negate,
         nf_set_error("nf_label_components: bad arguments");
         return NF_ERR_ARG;
     }
+    nf::ProfScope ps(nf::PT_LABEL, S(stream), (double)H * W * ((vtype == NF_F32 ? 4.0 : 8.0) + 4.0));
     return nf::label_components(vtype, sn, threshold, negate, labels, H, W, work, numObjects, S(stream));
 }
 
@@ -283,6 +382,7 @@ int nf_object_stats(int vtype, const void* sn, int negate, const int* labels, in
         nf_set_error("nf_object_stats: bad arguments");
         return NF_ERR_ARG;
     }
+    nf::ProfScope ps(nf::PT_OBJECT_STATS, S(stream), (double)H * W * ((vtype == NF_F32 ? 4.0 : 8.0) + 4.0));
     return nf::object_stats(vtype, sn, negate, labels, H, W, numObjects, stats, S(stream));
 }
 
@@ -291,6 +391,7 @@ int nf_map_max(int vtype, const void* map, long long n, double* out, void* strea
         nf_set_error("nf_map_max: bad arguments");
         return NF_ERR_ARG;
     }
+    nf::ProfScope ps(nf::PT_MAP_MAX, S(stream), (double)n * (vtype == NF_F32 ? 4.0 : 8.0));
     return nf::map_max(vtype, map, n, out, S(stream));
 }
 
@@ -300,6 +401,7 @@ int nf_ring_flags(const int* ringLabels, const double* ringStats, int numRing, i
         nf_set_error("nf_ring_flags: bad arguments");
         return NF_ERR_ARG;
     }
+    nf::ProfScope ps(nf::PT_RING_FLAGS, S(stream), (double)numRing * 49.0);
     return nf::ring_flags(ringLabels, ringStats, numRing, minRingPix, H, W, isRing, S(stream));
 }
 
@@ -309,6 +411,7 @@ int nf_spline_eval(int vtype, const void* map, int negate, int H, int W, const d
         nf_set_error("nf_spline_eval: bad arguments");
         return NF_ERR_ARG;
     }
+    nf::ProfScope ps(nf::PT_SPLINE, S(stream), (double)nPts * (2.0 * halfWin + 1) * (2.0 * halfWin + 1) * (vtype == NF_F32 ? 4.0 : 8.0));
     return nf::spline_eval(vtype, map, negate, H, W, yx, nPts, halfWin, out, S(stream));
 }
 

@@ -79,3 +79,41 @@ __device__ __forceinline__ cpx<T> cmulnegi(cpx<T> a) {
 }
 
 static inline int nf_div_up(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// ---- optional per-entry-point timing with HIP events (nf_profile_* in include/nemofilt.h) ----
+namespace nf {
+enum ProfTag {
+    PT_FFT_ROWS_F64 = 0,
+    PT_FFT_COLS_F64,
+    PT_FFT_ROWS_F32,
+    PT_FFT_COLS_F32,
+    PT_CROSS_POWER,
+    PT_GAUSSIAN,
+    PT_BUILD_FILTER,
+    PT_APPLY_FILTER,
+    PT_WINDOW_MUL,
+    PT_PAINT,
+    PT_SCALE_MASK,
+    PT_NOISE_MAP,
+    PT_MEDIAN_STACK,
+    PT_EDGE_CHECK,
+    PT_FINALIZE,
+    PT_RESTORE_ZEROS,
+    PT_SUBTRACT,
+    PT_CONVOLVE2D,
+    PT_LABEL,
+    PT_OBJECT_STATS,
+    PT_MAP_MAX,
+    PT_RING_FLAGS,
+    PT_SPLINE,
+    PT_COUNT
+};
+// Records an event pair around the work enqueued on `s` during its lifetime when profiling is on (no-op otherwise).
+// `bytes` = algorithmic HBM bytes of that work (inputs read once + outputs written once).
+struct ProfScope {
+    ProfScope(int tag, hipStream_t s, double bytes);
+    ~ProfScope();
+    int slot;
+    hipStream_t stream;
+};
+}  // namespace nf

@@ -251,13 +251,13 @@ __device__ __forceinline__ cpx<T> load_elem(const nf::LineArgs<T>& a, long long 
     return v;
 }
 
-template <typename T>
+template <typename T, bool LINEFAST>
 __global__ void k_fft_lines(nf::LineArgs<T> a) {
     extern __shared__ __align__(16) unsigned char nf_smem[];
     cpx<T>* buf = (cpx<T>*)nf_smem;
     const nf::LinePlan<T>& p = a.plan;
     const int n = p.n, m = p.m, lpw = a.linesPerWG;
-    const bool lineFast = a.lineFast != 0;
+    constexpr bool lineFast = LINEFAST;
     const int line0 = blockIdx.x * lpw;
     const int nl = min(lpw, a.nLines - line0);
     const long long inBase = (long long)blockIdx.y * a.inBatchStride;
@@ -492,11 +492,20 @@ int launch_lines(const LineArgs<T>& a, int batch, int threads, hipStream_t strea
     static bool attrSet[2] = {false, false};
     int which = sizeof(T) == 8 ? 1 : 0;
     if (!attrSet[which]) {
-        NF_HIP(hipFuncSetAttribute((const void*)k_fft_lines<T>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
+        NF_HIP(hipFuncSetAttribute((const void*)k_fft_lines<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
+        NF_HIP(hipFuncSetAttribute((const void*)k_fft_lines<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
         attrSet[which] = true;
     }
+    const double npixTotal = (double)a.nLines * a.plan.n * batch;
+    const double inB = a.inType == 0 ? sizeof(cpx<T>) : (a.inType == 1 ? 8.0 : 4.0);
+    const double outB = a.outType == 0 ? sizeof(cpx<T>) : (a.outType == 1 ? 8.0 : 4.0);
+    const int tag = sizeof(T) == 8 ? (a.lineFast ? PT_FFT_COLS_F64 : PT_FFT_ROWS_F64) : (a.lineFast ? PT_FFT_COLS_F32 : PT_FFT_ROWS_F32);
+    ProfScope ps(tag, stream, npixTotal * (inB + outB));
     dim3 grid(nf_div_up(a.nLines, a.linesPerWG), batch);
-    hipLaunchKernelGGL(k_fft_lines<T>, grid, dim3(threads), lds, stream, a);
+    if (a.lineFast)
+        hipLaunchKernelGGL((k_fft_lines<T, true>), grid, dim3(threads), lds, stream, a);
+    else
+        hipLaunchKernelGGL((k_fft_lines<T, false>), grid, dim3(threads), lds, stream, a);
     NF_CHECK_LAUNCH("k_fft_lines");
     return NF_OK;
 }

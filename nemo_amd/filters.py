@@ -36,15 +36,19 @@ def _asnumpy(x, dtype=None):
 
 # ------------------------------------------------------------------------------------------------------------
 def filterMaps(unfilteredMapsDictList, filterParams, tileName, diagnosticsDir='.', selFnDir='.', verbose=True,
-               undoPixelWindow=True, useCachedFilter=False, returnFilter=False):
-    """Builds and applies a filter to the unfiltered map(s) (nemo/filters.py:51-106)."""
+               undoPixelWindow=True, useCachedFilter=False, returnFilter=False, tileCache=None):
+    """Builds and applies a filter to the unfiltered map(s) (nemo/filters.py:51-106).
+
+    ``tileCache`` (extension; a dict owned by the caller, one per tile) lets the filter scales of one tile share what does
+    not depend on the template: the preprocessed maps / weights / masks in HBM, the apodised data FFTs and the smoothed noise
+    covariance.  The reference recomputes those identically for every scale (SURVEY.md headline facts)."""
     f = filterParams
     label = f['label'] + "#" + tileName
     if verbose:
         print("... making filtered map %s" % (label))
     filterClass = _FILTER_CLASSES[f['class']]
     filterObj = filterClass(f['label'], unfilteredMapsDictList, f['params'], tileName=tileName,
-                            diagnosticsDir=diagnosticsDir, selFnDir=selFnDir)
+                            diagnosticsDir=diagnosticsDir, selFnDir=selFnDir, tileCache=tileCache)
     filteredMapDict = filterObj.buildAndApply(useCachedFilter=useCachedFilter)
 
     filteredMapDict['wcs'].header['BUNIT'] = filteredMapDict['mapUnits']
@@ -73,8 +77,9 @@ class MapFilter(object):
     templateKind = None
 
     def __init__(self, label, unfilteredMapsDictList, paramsDict, tileName='PRIMARY', writeFilter=False,
-                 forceRebuild=False, diagnosticsDir=None, selFnDir=None):
+                 forceRebuild=False, diagnosticsDir=None, selFnDir=None, tileCache=None):
         self.label = label
+        self._tileCache = tileCache
         self.params = paramsDict
         self.diagnosticsDir = diagnosticsDir
         self.selFnDir = selFnDir
@@ -85,21 +90,35 @@ class MapFilter(object):
         else:
             self.filterFileName = None
 
-        # Copies, preprocessed per tile (nemo/filters.py:153-161)
-        self.unfilteredMapsDictList = []
-        for mapDict in unfilteredMapsDictList:
-            if 'mapToUse' in self.params.keys() and mapDict['label'] != self.params['mapToUse']:
-                continue
-            newMapDict = mapDict.copy()
-            newMapDict.preprocess(tileName=tileName, diagnosticsDir=diagnosticsDir)
-            self.unfilteredMapsDictList.append(newMapDict)
+        # Copies, preprocessed per tile (nemo/filters.py:153-161); shared between the scales of a tile via tileCache
+        shared = None
+        if tileCache is not None and not isinstance(self, RealSpaceMatchedFilter):
+            shared = tileCache.setdefault(('tile', tileName, self.params.get('mapToUse', None)), {})
+        self._shared = shared
+        if shared is not None and 'maps' in shared:
+            self.unfilteredMapsDictList = shared['maps']
+        else:
+            self.unfilteredMapsDictList = []
+            for mapDict in unfilteredMapsDictList:
+                if 'mapToUse' in self.params.keys() and mapDict['label'] != self.params['mapToUse']:
+                    continue
+                newMapDict = mapDict.copy()
+                newMapDict.preprocess(tileName=tileName, diagnosticsDir=diagnosticsDir)
+                self.unfilteredMapsDictList.append(newMapDict)
+            if shared is not None:
+                shared['maps'] = self.unfilteredMapsDictList
         self.wcs = self.unfilteredMapsDictList[0]['wcs']
         self.shape = tuple(self.unfilteredMapsDictList[0]['data'].shape)
 
         # Combined flag mask (nemo/filters.py:165-168)
-        self.flagMask = np.zeros(self.shape, dtype=int)
-        for mapDict, i in zip(self.unfilteredMapsDictList, range(len(self.unfilteredMapsDictList))):
-            self.flagMask = self.flagMask + (_asnumpy(mapDict['flagMask']) * (i + 1))
+        if shared is not None and 'flagMask' in shared:
+            self.flagMask = shared['flagMask']
+        else:
+            self.flagMask = np.zeros(self.shape, dtype=int)
+            for mapDict, i in zip(self.unfilteredMapsDictList, range(len(self.unfilteredMapsDictList))):
+                self.flagMask = self.flagMask + (_asnumpy(mapDict['flagMask']) * (i + 1))
+            if shared is not None:
+                shared['flagMask'] = self.flagMask
 
         # Beam solid angles in nanosteradians (nemo/filters.py:170-189)
         self.beamSolidAnglesDict = {}
@@ -130,14 +149,19 @@ class MapFilter(object):
         # device residency: one engine per tile shape, maps / weights / masks uploaded once
         self.engine = engine.TileEngine.get(self.shape)
         t = engine.torch()
-        self._dData = [engine.to_dev(m['data']) for m in self.unfilteredMapsDictList]
-        for d in self._dData:
-            if d.dtype not in (t.float32, t.float64):
-                raise NemoFiltError("maps must be float32 or float64")
-        self._dWeights = [engine.to_dev(m['weights']) for m in self.unfilteredMapsDictList]
-        self._dWeights = [w if w.dtype in (t.float32, t.float64) else w.to(t.float64) for w in self._dWeights]
-        self._dSurveyMask = engine.to_dev(self.unfilteredMapsDictList[0]['surveyMask'], dtype=t.uint8)
-        self._dPSMask = engine.to_dev(self.unfilteredMapsDictList[0]['pointSourceMask'], dtype=t.uint8)
+        if shared is not None and 'dev' in shared:
+            self._dData, self._dWeights, self._dSurveyMask, self._dPSMask = shared['dev']
+        else:
+            self._dData = [engine.to_dev(m['data']) for m in self.unfilteredMapsDictList]
+            for d in self._dData:
+                if d.dtype not in (t.float32, t.float64):
+                    raise NemoFiltError("maps must be float32 or float64")
+            self._dWeights = [engine.to_dev(m['weights']) for m in self.unfilteredMapsDictList]
+            self._dWeights = [w if w.dtype in (t.float32, t.float64) else w.to(t.float64) for w in self._dWeights]
+            self._dSurveyMask = engine.to_dev(self.unfilteredMapsDictList[0]['surveyMask'], dtype=t.uint8)
+            self._dPSMask = engine.to_dev(self.unfilteredMapsDictList[0]['pointSourceMask'], dtype=t.uint8)
+            if shared is not None:
+                shared['dev'] = (self._dData, self._dWeights, self._dSurveyMask, self._dPSMask)
         self._geom = None
         self._dFilt = None
 
@@ -200,7 +224,12 @@ class MapFilter(object):
         return rms if hasattr(mapData, 'is_cuda') else _asnumpy(rms)
 
     def _noiseMapDevice(self, dMap):
-        medWeights = self.engine.median_weights(self._dWeights)
+        if self._shared is not None and 'medWeights' in self._shared:
+            medWeights = self._shared['medWeights']
+        else:
+            medWeights = self.engine.median_weights(self._dWeights)
+            if self._shared is not None:
+                self._shared['medWeights'] = medWeights
         return self.engine.noise_map(dMap, medWeights, self.params['noiseParams'], self.wcs.getPixelSizeDeg())
 
     def makeRealSpaceFilterProfile(self):
@@ -277,8 +306,15 @@ class MatchedFilter(MapFilter):
         eng = self.engine
         t = engine.torch()
         N = len(self.unfilteredMapsDictList)
-        dCube = t.stack(self._dData).contiguous() if N > 1 else self._dData[0].reshape(1, *self.shape)
-        fMapsToFilter = eng.fft(dCube, apod=True)                                 # :523-526  K1+K2
+        shared = self._shared
+        if shared is not None and 'fMapsToFilter' in shared:
+            fMapsToFilter = shared['fMapsToFilter']
+        else:
+            dCube = t.stack(self._dData).contiguous() if N > 1 else self._dData[0].reshape(1, *self.shape)
+            fMapsToFilter = eng.fft(dCube, apod=True)                             # :523-526  K1+K2
+            del dCube
+            if shared is not None:
+                shared['fMapsToFilter'] = fMapsToFilter
 
         haveFile = self.filterFileName is not None and os.path.exists(self.filterFileName)
         if haveFile == False and useCachedFilter == False:
@@ -289,13 +325,18 @@ class MatchedFilter(MapFilter):
                 raise Exception("'%s' is not a valid filter noise method name - fix the .yml config file" % (method))
             if self.params.get('noiseModelCatalog', None) is not None:
                 raise NotImplementedError("noiseModelCatalog needs maps.makeModelImage (scope table row f1)")
-            fMapsForNoise = fMapsToFilter                                         # identical to :548 without a catalog
-            NP = eng.cross_power(fMapsForNoise)                                   # :573  K4
-            if method == 'max(dataMap,CMB)':
-                NPCMB = engine.to_dev(self.makeForegroundsPower().astype(_asnumpy(NP[0, 0, :1, :1]).dtype))
-                NP = t.maximum(NP, NPCMB)
-            noiseCov = eng.gaussian_filter(NP, (3, 3))                            # :580  K5
-            del NP
+            if shared is not None and ('noiseCov', method) in shared:
+                noiseCov = shared[('noiseCov', method)]
+            else:
+                fMapsForNoise = fMapsToFilter                                     # identical to :548 without a catalog
+                NP = eng.cross_power(fMapsForNoise)                               # :573  K4
+                if method == 'max(dataMap,CMB)':
+                    NPCMB = engine.to_dev(self.makeForegroundsPower().astype(_asnumpy(NP[0, 0, :1, :1]).dtype))
+                    NP = t.maximum(NP, NPCMB)
+                noiseCov = eng.gaussian_filter(NP, (3, 3))                        # :580  K5
+                del NP
+                if shared is not None:
+                    shared[('noiseCov', method)] = noiseCov
 
             w = self._frequencyWeights()                                          # :587-608
             fSignals = t.stack([eng.fft(self._paintTemplate(m['beamFileName']))   # :611-618  K20+K2

@@ -1,0 +1,229 @@
+"""Tile x filter driver with the reference's call surface (nemo/pipelines.py:35-398).
+
+``filterMapsAndMakeCatalogs(config, ...)`` loops over this rank's tiles and over the filters (photFilter first,
+nemo/pipelines.py:161-173), calls :func:`nemo_amd.filters.filterMaps` and :func:`nemo_amd.photometry.findObjects`
+exactly as the reference does, merges the per-(filter, tile) catalogues with ``catalogs.makeOptimalCatalog`` and - when
+several GPUs share the tiles - all-gathers the merged catalogue so that every rank holds all of it (the reference's
+``comm.allgather`` at nemo/pipelines.py:322), then removes the duplicates found in tile overlaps (:335).
+
+What differs from the reference is where things live: per tile, the maps, weights, masks, the apodised data FFTs and
+the smoothed noise covariance are kept in HBM and shared by all filter scales of that tile (the reference recomputes
+them for each scale - they do not depend on the template), and the filtered / S/N maps stay on the device for source
+finding.  Only catalogue rows reach the host.
+"""
+import os
+import time
+
+import numpy as np
+
+from . import catalogs, filters, photometry, engine
+
+# columns exchanged between ranks (fixed-width float64 rows; strings are rebuilt from indices / coordinates)
+_GATHER_COLS = ['RADeg', 'decDeg', 'SNR', 'numSigPix', 'flags', 'ringFlag', 'galacticLatDeg', 'x', 'y']
+
+
+def initDistributed():
+    """One process per GPU: bind this process to its GPU and join the job (RCCL via backend 'nccl' when GPUs are present,
+    gloo otherwise).  Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as set by ``torch.distributed.run``."""
+    import torch
+    import torch.distributed as dist
+    if dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world == 1:
+        return 0, 1
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local % torch.cuda.device_count())
+        dist.init_process_group('nccl', device_id=torch.device('cuda', torch.cuda.current_device()))
+    else:
+        dist.init_process_group('gloo')
+    return dist.get_rank(), dist.get_world_size()
+
+
+def _gatherCatalogs(optimalCatalog, config):
+    """All ranks end up with the rows of all ranks: all-gather of the row counts, then of the rows padded to the largest
+    count.  Rows are [len(_GATHER_COLS) + 2] float64: the listed columns, the index of the template in the filter list and
+    the index of the tile in ``config.allTileNames``.  Extra (photometry) columns travel too when present on every rank."""
+    import torch
+    import torch.distributed as dist
+    dev = torch.device('cuda', torch.cuda.current_device()) if dist.get_backend() == 'nccl' else torch.device('cpu')
+    labels = [f['label'] for f in config.parDict['mapFilters']]
+    extra = []
+    if len(optimalCatalog) > 0:
+        extra = [k for k in optimalCatalog.keys() if k not in _GATHER_COLS + ['name', 'template', 'tileName']
+                 and np.asarray(optimalCatalog[k]).dtype.kind in 'fiub']
+    # agree on the extra columns (a rank with no detections has none to offer): keep those every non-empty rank has
+    names = [None] * config.size
+    dist.all_gather_object(names, extra if len(optimalCatalog) > 0 else None)
+    common = None
+    for n in names:
+        if n is not None:
+            common = list(n) if common is None else [k for k in common if k in n]
+    extra = common or []
+    cols = _GATHER_COLS + extra
+    n = len(optimalCatalog)
+    rows = np.zeros((n, len(cols) + 2), dtype=np.float64)
+    if n > 0:
+        for j, k in enumerate(cols):
+            rows[:, j] = np.asarray(optimalCatalog[k], dtype=np.float64) if k in optimalCatalog.keys() else -99
+        rows[:, len(cols)] = [labels.index(str(t)) if str(t) in labels else -1 for t in optimalCatalog['template']]
+        rows[:, len(cols) + 1] = [config.allTileNames.index(str(t)) for t in optimalCatalog['tileName']]
+    counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(config.size)]
+    dist.all_gather(counts, torch.tensor([n], dtype=torch.int64, device=dev))
+    counts = [int(c.item()) for c in counts]
+    nmax = max(counts)
+    if nmax == 0:
+        return catalogs.Table(names=('SNR', 'RADeg', 'decDeg'))
+    padded = torch.zeros((nmax, rows.shape[1]), dtype=torch.float64, device=dev)
+    if n > 0:
+        padded[:n] = torch.from_numpy(rows).to(dev)
+    gathered = [torch.empty_like(padded) for _ in range(config.size)]
+    dist.all_gather(gathered, padded)
+    allRows = np.concatenate([g[:c].cpu().numpy() for g, c in zip(gathered, counts)], axis=0)
+    tab = catalogs.Table()
+    for j, k in enumerate(cols):
+        col = allRows[:, j]
+        if k == 'ringFlag':
+            col = col > 0
+        tab[k] = col
+    tab['template'] = np.array([labels[int(i)] if i >= 0 else '' for i in allRows[:, len(cols)]], dtype='U30')
+    tab['tileName'] = np.array([config.allTileNames[int(i)] for i in allRows[:, len(cols) + 1]], dtype='U30')
+    ident = config.parDict['objIdent']
+    namer = catalogs.makeLongName if config.parDict['longNames'] else catalogs.makeName
+    tab['name'] = np.array([namer(r, d, prefix=ident) for r, d in zip(tab['RADeg'], tab['decDeg'])], dtype='U30')
+    return tab
+
+
+def filterMapsAndMakeCatalogs(config, rootOutDir=None, useCachedFilters=False, useCachedRMSMap=False,
+                              useCachedFilteredMaps=False, measureFluxes=True, invertMap=False, verbose=True,
+                              writeAreaMask=False, writeFlagMask=False):
+    """Runs the map filtering and catalogue construction steps (nemo/pipelines.py:35-115).  Returns the optimal
+    catalogue (highest S/N detection across filter scales), the same on every rank."""
+    if config.filterSets != [] and useCachedFilters == False and useCachedFilteredMaps == False:
+        for setNum in config.filterSets:
+            if verbose and config.rank == 0:
+                print(">>> Filter set: %d" % (setNum))
+            config.setFilterSet(setNum)
+            if setNum == config.filterSets[-1]:
+                writeAreaMask = True
+                writeFlagMask = True
+            config.filterSetOptions[setNum]['catalog'] = _filterMapsAndMakeCatalogs(config, verbose=verbose,
+                                                                                    useCachedFilters=False,
+                                                                                    useCachedFilteredMaps=False,
+                                                                                    writeAreaMask=writeAreaMask,
+                                                                                    writeFlagMask=writeFlagMask)
+            if config.filterSetOptions[setNum]['addSiphonedFromSets'] is not None:
+                toStack = [config.filterSetOptions[setNum]['catalog']]
+                for siphonSetNum in config.filterSetOptions[setNum]['addSiphonedFromSets']:
+                    toStack.append(config.filterSetOptions[siphonSetNum]['catalog'])
+                config.filterSetOptions[setNum]['catalog'] = catalogs.vstack(toStack)
+        catalog = config.filterSetOptions[config.filterSets[-1]]['catalog']
+    else:
+        catalog = _filterMapsAndMakeCatalogs(config, rootOutDir=rootOutDir, useCachedFilters=useCachedFilters,
+                                             useCachedFilteredMaps=useCachedFilteredMaps, useCachedRMSMap=useCachedRMSMap,
+                                             measureFluxes=measureFluxes, invertMap=invertMap, verbose=verbose,
+                                             writeAreaMask=writeAreaMask, writeFlagMask=writeFlagMask)
+    if verbose == True and config.rank == 0:
+        print("... after map filtering and making catalogs: time since start = %.3f sec" % (time.time() - config._timeStarted))
+    if isinstance(catalog, list) and catalog == []:
+        catalog = catalogs.Table(names=('SNR', 'RADeg', 'decDeg'))
+    return catalog
+
+
+def _filterMapsAndMakeCatalogs(config, rootOutDir=None, useCachedFilters=False, useCachedRMSMap=False,
+                               useCachedFilteredMaps=False, measureFluxes=True, invertMap=False, verbose=True,
+                               writeAreaMask=False, writeFlagMask=False):
+    """nemo/pipelines.py:118-398."""
+    if useCachedFilteredMaps or useCachedRMSMap:
+        raise NotImplementedError("useCachedFilteredMaps / useCachedRMSMap read products written by completeness / selFn code "
+                                  "(nemo/pipelines.py:204-218,234-250): 'next' row of the scope table")
+    if config.parDict['forcedPhotometryCatalog'] is not None:
+        raise NotImplementedError("forced photometry (nemo/photometry.py:380-444) is a 'next' row of the scope table")
+    if rootOutDir is not None:
+        diagnosticsDir = rootOutDir + os.path.sep + "diagnostics"
+        for d in [rootOutDir, rootOutDir + os.path.sep + "filteredMaps", diagnosticsDir]:
+            os.makedirs(d, exist_ok=True)
+    diagnosticsDir = config.diagnosticsDir
+
+    photFilter = config.parDict['photFilter']
+    filtersList = []
+    if photFilter is not None:
+        for f in config.parDict['mapFilters']:
+            if f['label'] == photFilter:
+                filtersList.append(f)
+    for f in config.parDict['mapFilters']:
+        if photFilter is not None and f['label'] == photFilter:
+            continue
+        filtersList.append(f)
+    if photFilter is not None and len(config.parDict['mapFilters']) > 1:
+        assert (filtersList[0]['label'] == photFilter)
+    photFilteredMapDict = None
+
+    catalogDict = {}
+    config.areaMaskDict, config.flagMaskDict = {}, {}
+    config.stitchedFilteredMapDict, config.stitchedSNMapDict, config.stitchedRMSMapDict = {}, {}, {}
+    keepDevice = filters.RETURN_DEVICE_ARRAYS
+    filters.RETURN_DEVICE_ARRAYS = True
+    try:
+        for tileName in config.tileNames:
+            if verbose == True:
+                print(">>> [rank = %d] Making filtered maps - tileName = %s " % (config.rank, tileName))
+            tileCache = {}      # what all filter scales of this tile share (data FFTs, noise covariance, masks): HBM-resident
+            for f in filtersList:
+                label = f['label'] + "#" + tileName
+                catalogDict[label] = {}
+                returnFilter = f['label'] == photFilter
+                filterResults = filters.filterMaps(config.unfilteredMapsDictList, f, tileName, diagnosticsDir=diagnosticsDir,
+                                                   selFnDir=config.selFnDir, verbose=verbose,
+                                                   undoPixelWindow=config.parDict['undoPixelWindow'],
+                                                   useCachedFilter=useCachedFilters, returnFilter=returnFilter,
+                                                   tileCache=tileCache)
+                if returnFilter == False:
+                    filteredMapDict = filterResults
+                else:
+                    filteredMapDict, config.cachedFilters[tileName] = filterResults[0], filterResults[1]
+                if 'saveFilteredMaps' in f['params'] and f['params']['saveFilteredMaps'] == True:
+                    t = engine.torch()
+                    config.stitchedFilteredMapDict[tileName] = filteredMapDict['data'].to(t.float32)
+                    config.stitchedSNMapDict[tileName] = filteredMapDict['SNMap'].to(t.float32)
+                    config.stitchedRMSMapDict[tileName] = filteredMapDict['RMSMap'].to(t.float32)
+                if f['label'] == photFilter:
+                    photFilteredMapDict = {'SNMap': filteredMapDict['SNMap'], 'data': filteredMapDict['data']}
+                catalog = photometry.findObjects(filteredMapDict, threshold=config.parDict['thresholdSigma'],
+                                                 minObjPix=config.parDict['minObjPix'],
+                                                 findCenterOfMass=config.parDict['findCenterOfMass'],
+                                                 flagRings=config.parDict['flagRings'],
+                                                 ringFlagDistArcmin=config.parDict['ringFlagDistArcmin'],
+                                                 ringFlagMinRingerSNR=config.parDict['ringFlagMinRingerSNR'],
+                                                 ringThresholdSigma=config.parDict['ringThresholdSigma'],
+                                                 rejectBorder=config.parDict['rejectBorder'],
+                                                 objIdent=config.parDict['objIdent'], longNames=config.parDict['longNames'],
+                                                 useInterpolator=config.parDict['useInterpolator'],
+                                                 measureShapes=config.parDict['measureShapes'], invertMap=invertMap,
+                                                 verbose=verbose)
+                if writeAreaMask == True and tileName not in config.areaMaskDict.keys():
+                    config.areaMaskDict[tileName] = filteredMapDict['surveyMask']
+                if writeFlagMask == True and tileName not in config.flagMaskDict.keys():
+                    config.flagMaskDict[tileName] = filteredMapDict['flagMask']
+                if measureFluxes == True:
+                    photometry.measureFluxes(catalog, filteredMapDict, diagnosticsDir, photFilteredMapDict=photFilteredMapDict,
+                                             useInterpolator=config.parDict['useInterpolator'])
+                elif photFilter is not None:
+                    photometry.getSNRValues(catalog, photFilteredMapDict['SNMap'], filteredMapDict['wcs'], prefix='fixed_',
+                                            useInterpolator=config.parDict['useInterpolator'], invertMap=invertMap)
+                del filteredMapDict
+                catalogDict[label]['catalog'] = catalog
+            del tileCache
+    finally:
+        filters.RETURN_DEVICE_ARRAYS = keepDevice
+
+    optimalCatalog = catalogs.makeOptimalCatalog(catalogDict, constraintsList=config.parDict['catalogCuts'],
+                                                 photFilter=photFilter, method=config.parDict['optimalCatalogMethod'])
+    if config.MPIEnabled == True and config.size > 1:
+        optimalCatalog = _gatherCatalogs(optimalCatalog, config)
+        if len(optimalCatalog) > 0:
+            optimalCatalog, numDuplicatesFound, names = catalogs.removeDuplicates(optimalCatalog)
+    return optimalCatalog

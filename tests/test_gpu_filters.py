@@ -47,7 +47,9 @@ def _check_catalogs(cat, refCat, threshold, posTol=1e-6, snrTol=1e-8):
         assert g['numSigPix'] == r['numSigPix']
         assert abs(g['SNR'] - r['SNR']) < snrTol * max(1.0, abs(r['SNR']))
         assert int(g['flags']) == int(r['flags'])
-        assert abs(g['RADeg'] - r['RADeg']) < 1e-9 and abs(g['decDeg'] - r['decDeg']) < 1e-9
+        # sky coordinates follow the pixel positions: 0.5' pixels -> posTol px = posTol / 120 deg (x2 margin)
+        cTol = max(1e-9, 2 * posTol / 120.0)
+        assert abs(g['RADeg'] - r['RADeg']) < cTol and abs(g['decDeg'] - r['decDeg']) < cTol
     return len(ref)
 
 

@@ -77,19 +77,24 @@ def make_workload(shape, seed, dtype):
     return [md], wcs, truth
 
 
-def run_step(mapsList, filtersList, verbose=False):
-    from nemo_amd import filters, photometry, catalogs
-    tileCache = {}
-    catalogDict = {}
-    for f in filtersList:
-        fmd = filters.filterMaps(mapsList, f, 'PRIMARY', diagnosticsDir=None, selFnDir=None, verbose=False,
-                                 undoPixelWindow=True, tileCache=tileCache)
-        cat = photometry.findObjects(fmd, threshold=4.0, minObjPix=1, rejectBorder=0, findCenterOfMass=True,
-                                     useInterpolator=True, objIdent='ACT-CL', longNames=False, verbose=False)
-        catalogDict[f['label'] + "#PRIMARY"] = {'catalog': cat}
-        del fmd
-    optimal = catalogs.makeOptimalCatalog(catalogDict, constraintsList=[], photFilter=None, method='ref-first')
-    return optimal
+def make_config(mapsList, numScales):
+    """The DR5 cluster-search configuration (examples/ACT-DR5-clusters/DR5ClusterSearch.yml:26-38,82-129) over in-memory maps."""
+    from nemo_amd import startUp
+    parDict = {'unfilteredMaps': [dict(m) for m in mapsList], 'thresholdSigma': 4.0, 'minObjPix': 1, 'findCenterOfMass': True,
+               'useInterpolator': True, 'optimalCatalogMethod': 'ref-forced', 'rejectBorder': 0, 'objIdent': 'ACT-CL',
+               'longNames': False, 'photFilter': PHOT_FILTER, 'mapFilters': filter_list(numScales), 'useTiling': False,
+               'outputDir': None}
+    return startUp.NemoConfig(parDict, makeOutputDirs=False, verbose=False)
+
+
+def run_step(config):
+    """One pass of the hot path over this rank's tile(s): pipelines.filterMapsAndMakeCatalogs = for every filter scale
+    filters.filterMaps (+ pixel-window undo), photometry.findObjects, photometry.measureFluxes, then the optimal catalogue."""
+    from nemo_amd import pipelines
+    cat = pipelines.filterMapsAndMakeCatalogs(config, verbose=False)
+    if len(cat) > 0:
+        cat['name']          # names are formatted lazily: make them part of the timed work
+    return cat
 
 
 def cpu_baseline(procs, size):
@@ -146,8 +151,8 @@ def main():
     lib = _lib.load()
     shape = (args.size, args.size)
     mapsList, wcs, truth = make_workload(shape, 1234 + rank, args.dtype)
-    filtersList = filter_list(args.scales)
-    N, S = 1, len(filtersList)
+    config = make_config(mapsList, args.scales)
+    N, S = 1, len(config.parDict['mapFilters'])
 
     def barrier():
         torch.cuda.synchronize()
@@ -156,13 +161,13 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        cat = run_step(mapsList, filtersList)
+        cat = run_step(config)
     barrier()
     if not args.no_profile:
         lib.nf_profile_enable(1)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        cat = run_step(mapsList, filtersList)
+        cat = run_step(config)
     barrier()
     elapsed = time.perf_counter() - t0
     tmax = torch.tensor([elapsed], dtype=torch.float64, device='cuda')

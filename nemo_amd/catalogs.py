@@ -4,11 +4,16 @@ astropy.table is not available offline, so catalogues are held in :class:`Table`
 handful of operations the path uses (column access, row iteration with in-place updates, boolean selection,
 vstack, sort).  Semantics follow:
 
-* ``makeName`` / ``makeLongName``      - nemo/catalogs.py:436-595 (IAU-style, truncated not rounded)
+* ``makeName`` / ``makeLongName``      - nemo/catalogs.py:436-595 (IAU-style; digits are cut from decimal strings)
 * ``catalogListToTab``                 - nemo/catalogs.py:620-651
 * ``selectFromCatalog``                - nemo/catalogs.py:598-617
 * ``makeOptimalCatalog``               - nemo/catalogs.py:218-362 ('ref-first' and 'ref-forced')
 * ``removeDuplicates``                 - nemo/catalogs.py:704-749
+* ``getTableRADecKeys``                - nemo/catalogs.py:1089-1120
+
+The cross-matching loops of the reference are O(rows x rows) Python; here neighbour candidates come from a k-d tree
+on unit vectors and the reference's own test (``calcAngSepDeg(...) < XMATCH_RADIUS_DEG``) is then applied to the
+candidate pairs, so the outcome is the same and the cost is O(rows log rows).
 """
 import operator
 
@@ -30,20 +35,25 @@ class _Row(object):
         self._i = i
 
     def __getitem__(self, key):
-        return self._tab._cols[key][self._i]
+        return self._tab[key][self._i]
 
     def __setitem__(self, key, value):
-        self._tab._cols[key][self._i] = value
+        self._tab[key][self._i] = value
 
     def keys(self):
         return self._tab.keys()
 
 
 class Table(object):
-    """Minimal stand-in for astropy.table.Table (columns = numpy arrays of equal length)."""
+    """Minimal stand-in for astropy.table.Table (columns = numpy arrays of equal length).
+
+    The ``name`` column may be *lazy* (:meth:`setLazyNames`): names are a pure function of (RADeg, decDeg), so they are
+    only formatted when the column is first read - normally once, on the final merged catalogue - instead of for every
+    candidate at every filter scale."""
 
     def __init__(self, cols=None, names=None):
         self._cols = {}
+        self._nameSpec = None      # (prefix, longNames) while the name column is not materialised
         self.meta = {}
         if cols is not None:
             for k, v in cols.items():
@@ -52,8 +62,25 @@ class Table(object):
             for k in names:
                 self._cols[k] = np.zeros(0)
 
+    def setLazyNames(self, prefix, longNames=False):
+        self._nameSpec = (prefix, bool(longNames))
+        self._cols.pop('name', None)
+
+    def _materialiseNames(self):
+        if self._nameSpec is not None and 'RADeg' in self._cols:
+            prefix, longNames = self._nameSpec
+            fn = makeLongName if longNames else makeName
+            names = [fn(r, d, prefix=prefix) for r, d in zip(self._cols['RADeg'].tolist(), self._cols['decDeg'].tolist())]
+            col = np.array(names, dtype='U30') if len(names) > 0 else np.zeros(0, dtype='U30')
+            # keep 'name' as the first column, where catalogListToTab puts it
+            self._cols = dict([('name', col)] + [(k, v) for k, v in self._cols.items() if k != 'name'])
+        self._nameSpec = None
+
     def keys(self):
-        return list(self._cols.keys())
+        ks = list(self._cols.keys())
+        if self._nameSpec is not None and 'name' not in ks:
+            ks = ['name'] + ks
+        return ks
 
     @property
     def colnames(self):
@@ -70,12 +97,15 @@ class Table(object):
 
     def __getitem__(self, key):
         if isinstance(key, str):
+            if key == 'name' and self._nameSpec is not None:
+                self._materialiseNames()
             return self._cols[key]
         if isinstance(key, (int, np.integer)):
             return _Row(self, int(key))
         out = Table()
         for k, v in self._cols.items():
             out._cols[k] = v[key]
+        out._nameSpec = self._nameSpec
         out.meta = dict(self.meta)
         return out
 
@@ -84,6 +114,8 @@ class Table(object):
         arr = np.array(value)
         if arr.ndim == 0 and len(self._cols) > 0:
             arr = np.full(n, value)
+        if key == 'name':
+            self._nameSpec = None
         self._cols[key] = arr
 
     def add_column(self, data, name):
@@ -96,6 +128,7 @@ class Table(object):
         out = Table()
         for k, v in self._cols.items():
             out._cols[k] = v.copy()
+        out._nameSpec = self._nameSpec
         out.meta = dict(self.meta)
         return out
 
@@ -107,57 +140,88 @@ class Table(object):
             self._cols[k] = self._cols[k][order]
 
     def to_records(self):
-        return [{k: self._cols[k][i] for k in self._cols} for i in range(len(self))]
+        keys = self.keys()
+        cols = {k: self[k] for k in keys}
+        return [{k: cols[k][i] for k in keys} for i in range(len(self))]
 
 
 def vstack(tables):
     tables = [t for t in tables if len(t) > 0 or len(t.keys()) > 0]
     if len(tables) == 0:
         return Table()
-    keys = tables[0].keys()
+    specs = set(t._nameSpec for t in tables)
     out = Table()
-    for k in keys:
+    if len(specs) == 1 and None not in specs:
+        out._nameSpec = tables[0]._nameSpec          # every part still lazy, same naming rule: stay lazy
+    else:
+        for t in tables:
+            t._materialiseNames()
+    for k in tables[0].keys():
+        if k == 'name' and out._nameSpec is not None:
+            continue
         out._cols[k] = np.concatenate([t[k] if k in t.keys() else np.full(len(t), -99) for t in tables])
     return out
 
 
 # ------------------------------------------------------------------------------------------------------------
-def _truncStr(value, digitsBefore, digitsAfter):
-    """Zero-padded, TRUNCATED decimal string (the reference slices '%.10f' strings; no rounding up)."""
-    scaled = int(np.floor(value * 10 ** digitsAfter + 1e-9))
-    whole, frac = divmod(scaled, 10 ** digitsAfter)
-    s = ("%0" + str(digitsBefore) + "d") % (whole)
-    if digitsAfter > 0:
-        s = s + "." + ("%0" + str(digitsAfter) + "d") % (frac)
-    return s
+# Names.  The reference cuts the digits out of decimal strings ("%.10f" for the RA hours / minutes, str() for the
+# declination), so values are truncated, never rounded up, and inherit the quirks of those strings; the same string
+# route is followed here so that names agree character for character (golden vectors: tests/golden/names.json).
+def _afterPoint(text):
+    return float(text[text.index("."):])
+
+
+def _twoDigits(value, text, nKeep):
+    """Leading field of a non-negative decimal string: zero-padded when the value is below ten."""
+    return "0" + text[:nKeep - 1] if value < 10 else text[:nKeep]
+
+
+def _raField(RADeg):
+    hours = (RADeg / 360) * 24
+    sh = "%.10f" % (hours)
+    mins = _afterPoint(sh) * 60
+    return _twoDigits(hours, sh, 2) + _twoDigits(mins, "%.10f" % (mins), 4)
+
+
+def _decField(decDeg):
+    s = str(decDeg)
+    if decDeg > 0:
+        sDeg = "+" + _twoDigits(decDeg, s, 2)
+    else:
+        sDeg = "-0" + s[1] if decDeg > -10 else s[:3]
+    mins = _afterPoint(s) * 60
+    return sDeg + _twoDigits(mins, str(mins), 2)
+
+
+def _longRAField(RADeg):
+    hours = (RADeg / 360) * 24
+    sh = str(hours)
+    mins = _afterPoint(sh) * 60
+    sm = str(mins)
+    secs = _afterPoint(sm) * 60
+    return _twoDigits(hours, sh, 2) + _twoDigits(mins, sm, 2) + _twoDigits(secs, str(secs), 4)
+
+
+def _longDecField(decDeg):
+    s = str(decDeg)
+    if decDeg > 0:
+        sDeg = "+" + _twoDigits(decDeg, s, 2)
+    else:
+        sDeg = "-0" + s[1] if decDeg > -10 else s[:3]
+    mins = _afterPoint(s) * 60
+    sm = str(mins)
+    secs = _afterPoint(sm) * 60
+    return sDeg + _twoDigits(mins, sm, 2) + _twoDigits(secs, str(secs), 4)
 
 
 def makeName(RADeg, decDeg, prefix='ACT-CL'):
-    """``prefix JHHMM.m+DDMM`` (nemo/catalogs.py:436-524)."""
-    hours = (RADeg / 360.0) * 24
-    h = int(hours)
-    mins = (float("%.10f" % (hours)) - h) * 60
-    sRA = "%02d%s" % (h, _truncStr(mins, 2, 1))
-    a = abs(decDeg)
-    d = int(a)
-    dmins = (a - d) * 60
-    sDec = ("+" if decDeg > 0 else "-") + "%02d%02d" % (d, int(dmins))
-    return prefix + " J" + sRA + sDec
+    """``prefix JHHMM.m+DDMM`` (nemo/catalogs.py:436-451,472-524)."""
+    return prefix + " J" + _raField(float(RADeg)) + _decField(float(decDeg))
 
 
 def makeLongName(RADeg, decDeg, prefix="ACT-CL"):
-    """``prefix JHHMMSS.s+DDMMSS`` (nemo/catalogs.py:454-595)."""
-    hours = (RADeg / 360.0) * 24
-    h = int(hours)
-    mins = (hours - h) * 60
-    m = int(mins)
-    secs = (mins - m) * 60
-    a = abs(decDeg)
-    d = int(a)
-    dm = (a - d) * 60
-    dmi = int(dm)
-    ds = (dm - dmi) * 60
-    return prefix + " J%02d%02d%s%s%02d%02d%02d" % (h, m, _truncStr(secs, 2, 1), "+" if decDeg > 0 else "-", d, dmi, int(ds))
+    """``prefix JHHMMSS.s+DDMMSS`` (nemo/catalogs.py:454-469,527-595)."""
+    return prefix + " J" + _longRAField(float(RADeg)) + _longDecField(float(decDeg))
 
 
 def catalogListToTab(catalogList, keysToWrite=COLUMN_NAMES, minStrLength=30):
@@ -172,6 +236,24 @@ def catalogListToTab(catalogList, keysToWrite=COLUMN_NAMES, minStrLength=30):
                 col = col.astype('U%d' % (max(minStrLength, col.dtype.itemsize // 4)))
             tab._cols[key] = col
     return tab
+
+
+def getTableRADecKeys(tab):
+    """nemo/catalogs.py:1089-1120: names of the RA / dec columns of a table."""
+    RAKeysToTry = ['ra', 'RA', 'RADeg']
+    decKeysToTry = ['dec', 'DEC', 'decDeg', 'Dec']
+    RAKey, decKey = None, None
+    for key in RAKeysToTry:
+        if key in tab.keys():
+            RAKey = key
+            break
+    for key in decKeysToTry:
+        if key in tab.keys():
+            decKey = key
+            break
+    if RAKey is None or decKey is None:
+        raise Exception("Couldn't identify RA, dec columns in the supplied table.")
+    return RAKey, decKey
 
 
 _OPS = {'<': operator.lt, '>': operator.gt, '<=': operator.le, '>=': operator.ge, '==': operator.eq, '!=': operator.ne}
@@ -190,8 +272,61 @@ def selectFromCatalog(catalog, constraintsList):
     return passed
 
 
+# ------------------------------------------------------------------------------------------------------------
+def _unitVectors(RADeg, decDeg):
+    ra, dec = np.radians(np.asarray(RADeg, dtype=np.float64)), np.radians(np.asarray(decDeg, dtype=np.float64))
+    return np.stack([np.cos(dec) * np.cos(ra), np.cos(dec) * np.sin(ra), np.sin(dec)], axis=1)
+
+
+def _pairsWithin(RA1, dec1, RA2, dec2, radiusDeg, inclusive=False):
+    """All (i, j) with calcAngSepDeg(row i of set 1, row j of set 2) < radiusDeg (<= if inclusive), sorted by (i, j).
+    Candidates from a k-d tree (chord length, 0.1 % margin), decided by the exact great-circle formula."""
+    from scipy.spatial import cKDTree
+    if len(RA1) == 0 or len(RA2) == 0:
+        return np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64)
+    chord = 2.0 * np.sin(np.radians(radiusDeg) / 2.0) * 1.001 + 1e-12
+    t1 = cKDTree(_unitVectors(RA1, dec1))
+    t2 = cKDTree(_unitVectors(RA2, dec2))
+    sp = t1.sparse_distance_matrix(t2, chord, output_type='coo_matrix')
+    i, j = sp.row.astype(np.int64), sp.col.astype(np.int64)
+    # zero-distance pairs are dropped by the sparse format: identical positions (incl. a row with itself) are added back
+    if len(RA1) == len(RA2) and np.array_equal(np.asarray(RA1), np.asarray(RA2)) and np.array_equal(np.asarray(dec1), np.asarray(dec2)):
+        pairs = t1.query_pairs(1e-15, output_type='ndarray')
+        selfIdx = np.arange(len(RA1), dtype=np.int64)
+        i = np.concatenate([i, selfIdx, pairs[:, 0], pairs[:, 1]])
+        j = np.concatenate([j, selfIdx, pairs[:, 1], pairs[:, 0]])
+    else:
+        zi = t1.query_ball_tree(t2, 1e-15)
+        zp = [(a, b) for a, lst in enumerate(zi) for b in lst]
+        if len(zp) > 0:
+            zp = np.array(zp, dtype=np.int64)
+            i = np.concatenate([i, zp[:, 0]])
+            j = np.concatenate([j, zp[:, 1]])
+    if len(i) > 0:
+        key = np.unique(i * np.int64(len(RA2)) + j)
+        i, j = key // np.int64(len(RA2)), key % np.int64(len(RA2))
+    r = calcAngSepDeg(np.asarray(RA1, dtype=np.float64)[i], np.asarray(dec1, dtype=np.float64)[i],
+                      np.asarray(RA2, dtype=np.float64)[j], np.asarray(dec2, dtype=np.float64)[j])
+    ok = (r <= radiusDeg) if inclusive else (r < radiusDeg)
+    return i[ok], j[ok]
+
+
+def _bestPerGroup(i, j, SNR, n):
+    """For pairs (i, j) sorted by (i, j): per i, the count of partners and the FIRST partner (lowest j) with the highest
+    SNR - what ``xIndices[np.argmax(SNR[xIndices])]`` returns.  best = -1 where i has no partner."""
+    count = np.bincount(i, minlength=n)
+    best = np.full(n, -1, dtype=np.int64)
+    if len(i) > 0:
+        order = np.lexsort((j, -np.asarray(SNR, dtype=np.float64)[j], i))
+        io, jo = i[order], j[order]
+        first = np.ones(len(io), dtype=bool)
+        first[1:] = io[1:] != io[:-1]
+        best[io[first]] = jo[first]
+    return count, best
+
+
 def makeOptimalCatalog(catalogDict, constraintsList=[], photFilter=None, method='ref-first'):
-    """nemo/catalogs.py:218-362."""
+    """nemo/catalogs.py:218-255."""
     if method == 'ref-first':
         cat = _makeOptimalCatalogRefFirst(catalogDict, constraintsList=constraintsList, photFilter=photFilter)
     elif method == 'ref-forced':
@@ -204,6 +339,7 @@ def makeOptimalCatalog(catalogDict, constraintsList=[], photFilter=None, method=
 
 
 def _makeOptimalCatalogRefFirst(catalogDict, constraintsList=[], photFilter=None):
+    """nemo/catalogs.py:258-316."""
     refScale, merged = [], []
     for key in catalogDict.keys():
         if len(catalogDict[key]['catalog']) > 0:
@@ -213,39 +349,50 @@ def _makeOptimalCatalogRefFirst(catalogDict, constraintsList=[], photFilter=None
                 merged.append(catalogDict[key]['catalog'])
     refScale = vstack(refScale) if len(refScale) > 0 else None
     merged = vstack(merged) if len(merged) > 0 else []
-    if refScale is None:
+    sameTable = refScale is None
+    if sameTable:
         refScale = merged
     colsToRewrite = ['SNR', 'template', 'y_c', 'err_y_c', 'deltaT_c', 'err_deltaT_c']
     if len(refScale) > 0 and len(merged) > 0:
-        for row in refScale:
-            rDeg = calcAngSepDeg(row['RADeg'], row['decDeg'], merged['RADeg'], merged['decDeg'])
-            xIndices = np.where(rDeg < XMATCH_RADIUS_DEG)[0]
-            if len(xIndices) > 1:
-                best = xIndices[np.argmax(merged['SNR'][xIndices])]
-                if merged['SNR'][best] > row['SNR']:
-                    for c in colsToRewrite:
-                        if c in refScale.keys():
-                            row[c] = merged[c][best]
+        i, j = _pairsWithin(refScale['RADeg'], refScale['decDeg'], merged['RADeg'], merged['decDeg'], XMATCH_RADIUS_DEG)
+        cols = [c for c in colsToRewrite if c in refScale.keys()]
+        if not sameTable:
+            count, best = _bestPerGroup(i, j, merged['SNR'], len(refScale))
+            rows = np.where(count > 1)[0]
+            rows = rows[merged['SNR'][best[rows]] > refScale['SNR'][rows]]
+            for c in cols:
+                refScale[c][rows] = merged[c][best[rows]]
+        else:
+            # the reference updates the table it is searching (refScaleCatalog is mergedCatalog, :297-298): later rows see
+            # earlier rewrites, so rows with more than one partner are visited in order
+            count = np.bincount(i, minlength=len(refScale))
+            start = np.concatenate([[0], np.cumsum(count)])
+            SNR = refScale['SNR']
+            for row in np.where(count > 1)[0]:
+                xIndices = j[start[row]:start[row + 1]]
+                b = xIndices[np.argmax(SNR[xIndices])]
+                if SNR[b] > SNR[row]:
+                    for c in cols:
+                        refScale[c][row] = refScale[c][b]
         refScale.sort(['RADeg', 'decDeg'])
         refScale = selectFromCatalog(refScale, constraintsList)
     return refScale
 
 
 def _makeOptimalCatalogForcedRef(catalogDict, constraintsList=[]):
+    """nemo/catalogs.py:319-362."""
     allCatalogs = [catalogDict[k]['catalog'] for k in catalogDict.keys() if len(catalogDict[k]['catalog']) > 0]
     if len(allCatalogs) == 0:
         return Table(names=('SNR', 'RADeg', 'decDeg', 'name'))
     allCatalogs = vstack(allCatalogs)
-    toRemove = np.zeros(len(allCatalogs))
-    for row in allCatalogs:
-        rDeg = calcAngSepDeg(row['RADeg'], row['decDeg'], allCatalogs['RADeg'], allCatalogs['decDeg'])
-        xIndices = np.where(rDeg < XMATCH_RADIUS_DEG)[0]
-        if len(xIndices) > 1:
-            keep = xIndices[np.argmax(allCatalogs['SNR'][xIndices])]
-            for index in xIndices:
-                if index != keep:
-                    toRemove[index] = 1
-    merged = allCatalogs[toRemove == 0]
+    n = len(allCatalogs)
+    i, j = _pairsWithin(allCatalogs['RADeg'], allCatalogs['decDeg'], allCatalogs['RADeg'], allCatalogs['decDeg'],
+                        XMATCH_RADIUS_DEG)
+    count, best = _bestPerGroup(i, j, allCatalogs['SNR'], n)
+    toRemove = np.zeros(n, dtype=bool)
+    drop = (count[i] > 1) & (j != best[i])
+    toRemove[j[drop]] = True
+    merged = allCatalogs[~toRemove]
     merged.sort(['RADeg', 'decDeg'])
     return selectFromCatalog(merged, constraintsList)
 
@@ -255,22 +402,19 @@ def removeDuplicates(tab):
     if len(tab) == 1:
         return tab, 1, []
     ra, dec = np.asarray(tab['RADeg'], dtype=float), np.asarray(tab['decDeg'], dtype=float)
-    nearest = np.zeros(len(tab))
-    for i in range(len(tab)):
-        r = calcAngSepDeg(ra[i], dec[i], ra, dec)
-        r[i] = np.inf
-        nearest[i] = r.min()
-    mask = nearest < XMATCH_RADIUS_DEG
+    i, j = _pairsWithin(ra, dec, ra, dec, XMATCH_RADIUS_DEG)
+    other = i != j
+    mask = np.zeros(len(tab), dtype=bool)          # nearest OTHER row closer than the radius (match_coordinates_sky, :722-723)
+    mask[i[other]] = True
     if mask.sum() == 0:
         return tab, 0, []
     dupTab, noDupTab = tab[mask], tab[~mask]
+    di, dj = _pairsWithin(dupTab['RADeg'], dupTab['decDeg'], dupTab['RADeg'], dupTab['decDeg'], XMATCH_RADIUS_DEG,
+                          inclusive=True)
+    count, best = _bestPerGroup(di, dj, dupTab['SNR'], len(dupTab))
+    best = np.where(best < 0, np.arange(len(dupTab)), best)
     keepMask = np.zeros(len(dupTab), dtype=bool)
-    for i in range(len(dupTab)):
-        r = calcAngSepDeg(dupTab['RADeg'][i], dupTab['decDeg'][i], dupTab['RADeg'], dupTab['decDeg'])
-        m = np.less_equal(r, XMATCH_RADIUS_DEG)
-        indices = np.where(m)[0]
-        best = indices[np.equal(dupTab['SNR'][m], dupTab['SNR'][m].max())][0] if m.sum() > 0 else i
-        keepMask[best] = True
+    keepMask[best] = True
     keepTab = vstack([dupTab[keepMask], noDupTab])
     keepTab.sort('RADeg')
     return keepTab, len(dupTab), list(dupTab['name']) if 'name' in dupTab.keys() else []

@@ -111,14 +111,18 @@ class MapFilter(object):
         self.shape = tuple(self.unfilteredMapsDictList[0]['data'].shape)
 
         # Combined flag mask (nemo/filters.py:165-168)
-        if shared is not None and 'flagMask' in shared:
-            self.flagMask = shared['flagMask']
+        # (held on the device as int32; the numpy form of the reference is made on demand by the flagMask property)
+        t = engine.torch()
+        if shared is not None and 'dFlagMask' in shared:
+            self._dFlagMask = shared['dFlagMask']
         else:
-            self.flagMask = np.zeros(self.shape, dtype=int)
+            self._dFlagMask = None
             for mapDict, i in zip(self.unfilteredMapsDictList, range(len(self.unfilteredMapsDictList))):
-                self.flagMask = self.flagMask + (_asnumpy(mapDict['flagMask']) * (i + 1))
+                term = engine.to_dev(mapDict['flagMask']).to(t.int32) * (i + 1)
+                self._dFlagMask = term if self._dFlagMask is None else self._dFlagMask + term
             if shared is not None:
-                shared['flagMask'] = self.flagMask
+                shared['dFlagMask'] = self._dFlagMask
+        self._flagMaskHost = None
 
         # Beam solid angles in nanosteradians (nemo/filters.py:170-189)
         self.beamSolidAnglesDict = {}
@@ -148,7 +152,6 @@ class MapFilter(object):
 
         # device residency: one engine per tile shape, maps / weights / masks uploaded once
         self.engine = engine.TileEngine.get(self.shape)
-        t = engine.torch()
         if shared is not None and 'dev' in shared:
             self._dData, self._dWeights, self._dSurveyMask, self._dPSMask = shared['dev']
         else:
@@ -185,6 +188,18 @@ class MapFilter(object):
         if self._radiansMap is None:
             self._radiansMap = np.sqrt(self._xRad[None, :] ** 2 + self._yRad[:, None] ** 2)
         return self._radiansMap
+
+    @property
+    def flagMask(self):
+        """Combined flag mask as the reference holds it: numpy int array [H, W] (nemo/filters.py:165-168)."""
+        if self._flagMaskHost is None:
+            self._flagMaskHost = _asnumpy(self._dFlagMask).astype(int)
+        return self._flagMaskHost
+
+    @flagMask.setter
+    def flagMask(self, value):
+        self._flagMaskHost = np.asarray(value)
+        self._dFlagMask = engine.to_dev(self._flagMaskHost).to(engine.torch().int32)
 
     @property
     def filt(self):
@@ -289,7 +304,8 @@ class MapFilter(object):
                    'SNMap': _asnumpy(sn).astype(np.result_type(_asnumpy(sn).dtype, mdt)),
                    'RMSMap': _asnumpy(rms).astype(np.result_type(np.float32, mdt)),
                    'surveyMask': _asnumpy(mask).astype(mdt)}
-        out.update({'wcs': self.wcs, 'obsFreqGHz': combinedObsFreqGHz, 'flagMask': self.flagMask, 'mapUnits': mapUnits,
+        out.update({'wcs': self.wcs, 'obsFreqGHz': combinedObsFreqGHz,
+                    'flagMask': self._dFlagMask if RETURN_DEVICE_ARRAYS else self.flagMask, 'mapUnits': mapUnits,
                     'beamSolidAngle_nsr': beamSolidAngle_nsr, 'label': self.label, 'tileName': self.tileName})
         return out
 

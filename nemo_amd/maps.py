@@ -111,7 +111,8 @@ class MapDict(dict):
         if self.get('flagMask') is not None:
             flagMask = self.loadTile('flagMask', tileName) * surveyMask
         else:
-            flagMask = np.zeros(tuple(data.shape), dtype=np.uint8)
+            flagMask = np.zeros(tuple(data.shape), dtype=np.uint8) if not _is_tensor(data) else \
+                engine.torch().zeros(tuple(data.shape), dtype=engine.torch().uint8, device=data.device)
         if self.get('RADecSection') is not None:
             RAMin, RAMax, decMin, decMax = self['RADecSection']
             x0, y0 = wcs.wcs2pix(RAMax, decMin)

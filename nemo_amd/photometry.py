@@ -1,26 +1,32 @@
-"""Source finding on the GPU with the reference's call surface (nemo/photometry.py:25-248).
+"""Source finding and photometry on the GPU with the reference's call surface (nemo/photometry.py:25-444).
 
 ``getObjectPositions``: threshold + 4-connected labelling (scipy.ndimage.label numbering) + per-object
 centre of mass / peak position / pixel count, all in libnemofilt kernels.
 ``findObjects``: ring flagging (second labelling pass at ``ringThresholdSigma``), bicubic-spline S/N at the
 sub-pixel positions (windowed not-a-knot spline = RectBivariateSpline(kx=ky=3)), flag lookup, catalogue rows.
-Only per-object scalars (a few hundred rows) cross to the host.
+``getSNRValues`` / ``measureFluxes`` / ``makeForcedPhotometryCatalog``: spline sampling of the S/N and filtered
+maps at catalogue positions.
+Only per-object scalars cross to the host, as whole columns (no per-object Python loop).
 """
 import numpy as np
 
 from . import engine, catalogs
+from .signals import convertToDeltaT
 from .wcs import calcAngSepDeg
 
 
-def _galacticLatDeg(RADeg, decDeg):
+def galacticLatDeg(RADeg, decDeg):
     """J2000 -> galactic latitude (stands in for astCoords.convertCoords at nemo/photometry.py:118)."""
     ra, dec = np.radians(RADeg), np.radians(decDeg)
     raNGP, decNGP = np.radians(192.85948), np.radians(27.12825)
-    return float(np.degrees(np.arcsin(np.sin(dec) * np.sin(decNGP) + np.cos(dec) * np.cos(decNGP) * np.cos(ra - raNGP))))
+    return np.degrees(np.arcsin(np.sin(dec) * np.sin(decNGP) + np.cos(dec) * np.cos(decNGP) * np.cos(ra - raNGP)))
+
+
+_galacticLatDeg = galacticLatDeg
 
 
 def _segment(eng, dMap, threshold, findCenterOfMass=True, negate=False):
-    """Device part of getObjectPositions; returns (numObjects, labels tensor, stats ndarray [n+1, 6])."""
+    """Device part of getObjectPositions; returns (numObjects, labels tensor, stats tensor [n+1, 6])."""
     labels, numObjects = eng.label(dMap, threshold, negate=negate)
     stats = eng.object_stats(dMap, labels, numObjects, negate=negate)
     return numObjects, labels, stats
@@ -64,6 +70,14 @@ def getObjectPositions(mapData, threshold, findCenterOfMass=True):
     return objIDs, positions, numPix, seg
 
 
+def _lookup(mapLike, iy, ix):
+    """mapLike[iy, ix] for a numpy array or a device tensor; returns numpy."""
+    if hasattr(mapLike, 'is_cuda'):
+        t = engine.torch()
+        return mapLike[t.as_tensor(iy, device=mapLike.device), t.as_tensor(ix, device=mapLike.device)].cpu().numpy()
+    return np.asarray(mapLike)[iy, ix]
+
+
 def findObjects(filteredMapDict, threshold=3.0, minObjPix=3, rejectBorder=10, findCenterOfMass=True, flagRings=True,
                 ringThresholdSigma=0, ringFlagDistArcmin=12.0, ringFlagMinRingerSNR=20, invertMap=False,
                 objIdent='ACT-CL', longNames=False, verbose=True, useInterpolator=True, measureShapes=False,
@@ -103,13 +117,11 @@ def findObjects(filteredMapDict, threshold=3.0, minObjPix=3, rejectBorder=10, fi
         ys = (idx // W).astype(np.float64)
         xs = (idx % W).astype(np.float64)
 
+    iyr, ixr = np.round(ys).astype(np.int64), np.round(xs).astype(np.int64)      # int(round()): half to even, as np.round
     if useInterpolator == True:                                                   # :81-84,128
         SNRs = eng.spline_eval(dSN, np.stack([ys, xs], axis=1), negate=invertMap)
     else:
-        t = engine.torch()
-        iy = t.as_tensor(np.round(ys).astype(np.int64), device=dSN.device)
-        ix = t.as_tensor(np.round(xs).astype(np.int64), device=dSN.device)
-        SNRs = dSN[iy, ix].cpu().numpy().astype(np.float64) * (-1.0 if invertMap else 1.0)
+        SNRs = _lookup(dSN, iyr, ixr).astype(np.float64) * (-1.0 if invertMap else 1.0)
 
     ringFlags = np.zeros(len(sel), dtype=bool)
     if ringLabels is not None:                                                    # :112-114
@@ -119,37 +131,169 @@ def findObjects(filteredMapDict, threshold=3.0, minObjPix=3, rejectBorder=10, fi
         lab = ringLabels[iy, ix].to(t.int64)
         ringFlags = isRing[lab].cpu().numpy() > 0
 
-    fm = flagMask.cpu().numpy() if hasattr(flagMask, 'is_cuda') else np.asarray(flagMask)
-    catalog = []
-    for k in range(len(sel)):
-        objDict = {}
-        objDict['id'] = k + 1                                                     # :108,188
-        objDict['x'] = xs[k]
-        objDict['y'] = ys[k]
-        objDict['ringFlag'] = bool(ringFlags[k])
-        objDict['RADeg'], objDict['decDeg'] = wcs.pix2wcs(objDict['x'], objDict['y'])
-        if objDict['RADeg'] < 0:
-            objDict['RADeg'] = 360.0 + objDict['RADeg']
-        objDict['galacticLatDeg'] = _galacticLatDeg(objDict['RADeg'], objDict['decDeg'])
-        if longNames == False:
-            objDict['name'] = catalogs.makeName(objDict['RADeg'], objDict['decDeg'], prefix=objIdent)
-        else:
-            objDict['name'] = catalogs.makeLongName(objDict['RADeg'], objDict['decDeg'], prefix=objIdent)
-        objDict['numSigPix'] = st[sel[k], 0]
-        objDict['template'] = filteredMapDict['label']
-        objDict['tileName'] = filteredMapDict['tileName']
-        objDict['SNR'] = SNRs[k]
-        objDict['flags'] = fm[int(round(objDict['y'])), int(round(objDict['x']))]
-        if objDict['SNR'] > threshold:                                            # :186
-            catalog.append(objDict)
+    RADeg, decDeg = wcs.pix2wcs(xs, ys)                                           # :115-117
+    RADeg = np.where(RADeg < 0, 360.0 + RADeg, RADeg)
+    keep = SNRs > threshold                                                       # :186
+    if keep.sum() == 0:
+        return []
+    flags = _lookup(flagMask, iyr, ixr)
+    tab = catalogs.Table()
+    tab.setLazyNames(objIdent, longNames)                                          # :120-123 (built on first access)
+    tab['RADeg'] = RADeg[keep]
+    tab['decDeg'] = decDeg[keep]
+    tab['SNR'] = SNRs[keep]
+    tab['numSigPix'] = st[sel, 0][keep]
+    tab['template'] = np.full(int(keep.sum()), filteredMapDict['label'], dtype='U%d' % max(30, len(filteredMapDict['label'])))
+    tab['tileName'] = np.full(int(keep.sum()), filteredMapDict['tileName'], dtype='U%d' % max(30, len(filteredMapDict['tileName'])))
+    tab['flags'] = np.asarray(flags)[keep]
+    tab['ringFlag'] = ringFlags[keep]
+    tab['galacticLatDeg'] = galacticLatDeg(tab['RADeg'], tab['decDeg'])
+    tab['x'] = xs[keep]
+    tab['y'] = ys[keep]
 
-    if len(catalog) > 0:                                                          # :191-208
-        catalog = catalogs.catalogListToTab(catalog)
-        highSNR = catalog[catalog['SNR'] > ringFlagMinRingerSNR]
-        for row in catalog:
-            if row['ringFlag'] == True:
-                rDeg = calcAngSepDeg(row['RADeg'], row['decDeg'], highSNR['RADeg'], highSNR['decDeg'])
-                if np.logical_and((rDeg * 60) < ringFlagDistArcmin, rDeg > 0).sum() == 0:
-                    row['ringFlag'] = False
-        catalog['flags'] = catalog['flags'] + catalog['ringFlag']
-    return catalog
+    # Ring flags only stand near a high S/N object (:196-204); then flags += ringFlag (:208)
+    if tab['ringFlag'].any():
+        high = tab['SNR'] > ringFlagMinRingerSNR
+        hRA, hDec = tab['RADeg'][high], tab['decDeg'][high]
+        rf = tab['ringFlag']
+        for i in np.where(rf)[0]:
+            rDeg = calcAngSepDeg(tab['RADeg'][i], tab['decDeg'][i], hRA, hDec)
+            if np.logical_and((rDeg * 60) < ringFlagDistArcmin, rDeg > 0).sum() == 0:
+                rf[i] = False
+    tab['flags'] = tab['flags'] + tab['ringFlag']
+    return tab
+
+
+def _splineAt(mapData, wcs, RADeg, decDeg, useInterpolator, negate=False):
+    """Map values at sky positions: RectBivariateSpline(y, x) or nearest pixel (nemo/photometry.py:276-281,354-361).
+    Returns (values, inside) where ``inside`` follows the reference's int(x) > 0 ... bounds test."""
+    d = engine.to_dev(mapData)
+    eng = engine.TileEngine.get(d.shape)
+    H, W = d.shape
+    x, y = wcs.wcs2pix(np.asarray(RADeg, dtype=np.float64), np.asarray(decDeg, dtype=np.float64))
+    x, y = np.atleast_1d(x), np.atleast_1d(y)
+    inside = (x.astype(np.int64) > 0) & (x.astype(np.int64) < W) & (y.astype(np.int64) > 0) & (y.astype(np.int64) < H)
+    vals = np.zeros(len(x), dtype=np.float64)
+    if inside.sum() == 0:
+        return vals, inside
+    if useInterpolator:
+        # the spline is only defined on [0, H-1] x [0, W-1]; FITPACK clamps outside (positions there are masked anyway)
+        yy = np.clip(y[inside], 0.0, H - 1.0)
+        xx = np.clip(x[inside], 0.0, W - 1.0)
+        vals[inside] = eng.spline_eval(d, np.stack([yy, xx], axis=1), negate=negate)
+    else:
+        iy = np.clip(np.round(y[inside]).astype(np.int64), 0, H - 1)
+        ix = np.clip(np.round(x[inside]).astype(np.int64), 0, W - 1)
+        vals[inside] = _lookup(d, iy, ix).astype(np.float64) * (-1.0 if negate else 1.0)
+    return vals, inside
+
+
+def getSNRValues(catalog, SNMap, wcs, useInterpolator=True, invertMap=False, prefix=''):
+    """S/N at catalogue positions, added in place as ``prefix+'SNR'`` (nemo/photometry.py:251-281)."""
+    if len(catalog) == 0:
+        return
+    vals, inside = _splineAt(SNMap, wcs, catalog['RADeg'], catalog['decDeg'], useInterpolator, negate=invertMap)
+    col = np.zeros(len(catalog))
+    col[inside] = vals[inside]
+    catalog[prefix + 'SNR'] = col
+
+
+def deltaTToJyPerSr(temp, obsFreqGHz):
+    """nemo/photometry.py:488-502 (Planck function derivative at T_CMB; CGS constants)."""
+    from .signals import TCMB, _h_planck, _k_B, CLight
+    kB = _k_B * 1e7          # erg / K
+    h = _h_planck * 1e7      # erg s
+    c = CLight * 100.0       # cm / s
+    nu = obsFreqGHz * 1.e9
+    T0 = TCMB
+    x = h * nu / (kB * T0)
+    cNu = 2 * (kB * T0) ** 3 / (h ** 2 * c ** 2) * x ** 4 / (4 * (np.sinh(x / 2.)) ** 2)
+    cNu *= 1e23
+    return temp * cNu * 1e-6 / T0
+
+
+def measureFluxes(catalog, filteredMapDict, diagnosticsDir, photFilteredMapDict=None, useInterpolator=True,
+                  ycObsFreqGHz=148.0):
+    """Adds flux columns to ``catalog`` in place (nemo/photometry.py:284-377): y_c / deltaT_c (yc maps) or
+    deltaT_c / fluxJy (uK maps), plus ``fixed_`` versions from the reference-scale maps."""
+    if not hasattr(catalog, 'keys') or len(catalog) == 0:
+        return
+    mapData = filteredMapDict['data']
+    wcs = filteredMapDict['wcs']
+    mapUnits = wcs.header['BUNIT']
+    if photFilteredMapDict is not None:
+        getSNRValues(catalog, photFilteredMapDict['SNMap'], wcs, prefix='fixed_', useInterpolator=useInterpolator)
+    reportJyFluxes = 'BEAMNSR' in wcs.header.keys()
+    if reportJyFluxes:
+        beamSolidAngle_nsr = wcs.header['BEAMNSR']
+        obsFreqGHz = wcs.header['FREQGHZ']
+    mapDataList, prefixList = [mapData], ['']
+    if photFilteredMapDict is not None:
+        mapDataList.append(photFilteredMapDict['data'])
+        prefixList.append('fixed_')
+    keysToAdd = ['deltaT_c', 'err_deltaT_c']
+    if mapUnits == 'yc':
+        keysToAdd = keysToAdd + ['y_c', 'err_y_c']
+    elif mapUnits == 'uK':
+        keysToAdd = keysToAdd + ['fluxJy', 'err_fluxJy']
+    n = len(catalog)
+    for prefix in prefixList:
+        for k in keysToAdd:
+            catalog[prefix + k] = np.zeros(n)
+    for data, prefix in zip(mapDataList, prefixList):
+        mapValue, inside = _splineAt(data, wcs, catalog['RADeg'], catalog['decDeg'], useInterpolator)
+        with np.errstate(divide='ignore', invalid='ignore'):
+            if mapUnits == 'yc':
+                catalog[prefix + 'y_c'] = mapValue / 1e-4
+                catalog[prefix + 'err_y_c'] = catalog[prefix + 'y_c'] / catalog[prefix + 'SNR']
+                deltaTc = convertToDeltaT(mapValue, obsFrequencyGHz=ycObsFreqGHz)
+                catalog[prefix + 'deltaT_c'] = deltaTc
+                catalog[prefix + 'err_deltaT_c'] = np.abs(deltaTc / catalog[prefix + 'SNR'])
+            elif mapUnits == 'uK':
+                catalog[prefix + 'deltaT_c'] = mapValue
+                catalog[prefix + 'err_deltaT_c'] = mapValue / catalog[prefix + 'SNR']
+                if reportJyFluxes:
+                    catalog[prefix + 'fluxJy'] = deltaTToJyPerSr(catalog[prefix + 'deltaT_c'], obsFreqGHz) * beamSolidAngle_nsr * 1.e-9
+                    catalog[prefix + 'err_fluxJy'] = deltaTToJyPerSr(catalog[prefix + 'err_deltaT_c'], obsFreqGHz) * beamSolidAngle_nsr * 1.e-9
+
+
+def makeForcedPhotometryCatalog(filteredMapDict, inputCatalog, useInterpolator=True, DS9RegionsPath=None):
+    """Catalogue of S/N values at given positions (nemo/photometry.py:380-444).  ``inputCatalog``: a
+    :class:`nemo_amd.catalogs.Table` (or dict of columns) with RADeg/decDeg (or ra/dec, RA/DEC) columns."""
+    if isinstance(inputCatalog, str):
+        raise NotImplementedError("reading catalogue files needs astropy.table; pass a Table")
+    tab = inputCatalog if isinstance(inputCatalog, catalogs.Table) else catalogs.Table(cols=dict(inputCatalog))
+    RAKey, decKey = catalogs.getTableRADecKeys(tab)
+    RA = np.array(tab[RAKey], dtype=np.float64)
+    RA = np.where(RA < 0, 360 - np.abs(RA), RA)
+    dec = np.array(tab[decKey], dtype=np.float64)
+    names = np.array(tab['name']) if 'name' in tab.keys() else np.arange(len(tab)) + 1
+    wcs = filteredMapDict['wcs']
+    dSN = engine.to_dev(filteredMapDict['SNMap'])
+    H, W = dSN.shape
+    x, y = wcs.wcs2pix(RA, dec)
+    x, y = np.atleast_1d(x), np.atleast_1d(y)
+    inImage = (x >= 0) & (x < W - 1) & (y >= 0) & (y < H - 1)                     # catalogs.getCatalogWithinImage
+    xi, yi = np.round(x[inImage]).astype(np.int64), np.round(y[inImage]).astype(np.int64)
+    area = _lookup(filteredMapDict['surveyMask'], yi, xi) != 0
+    xi, yi = xi[area], yi[area]
+    if len(xi) == 0:
+        return []
+    eng = engine.TileEngine.get(dSN.shape)
+    if useInterpolator:
+        SNR = eng.spline_eval(dSN, np.stack([yi.astype(np.float64), xi.astype(np.float64)], axis=1))
+    else:
+        SNR = _lookup(dSN, yi, xi).astype(np.float64)
+    out = catalogs.Table()
+    out['name'] = names[inImage][area]
+    out['RADeg'] = RA[inImage][area]
+    out['decDeg'] = dec[inImage][area]
+    out['SNR'] = SNR
+    out['numSigPix'] = np.ones(len(xi))
+    out['template'] = np.full(len(xi), filteredMapDict['label'], dtype='U30')
+    out['tileName'] = np.full(len(xi), filteredMapDict['tileName'], dtype='U30')
+    out['flags'] = _lookup(filteredMapDict['flagMask'], yi, xi)
+    out['galacticLatDeg'] = galacticLatDeg(out['RADeg'], out['decDeg'])
+    out['x'] = xi
+    out['y'] = yi
+    return out

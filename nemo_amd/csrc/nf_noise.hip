@@ -27,7 +27,7 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
     if (lane == 0) red[wave] = v;
     __syncthreads();
     double t = 0.0;
-    for (int i = 0; i < NF_NOISE_THREADS / 64; ++i) t += red[i];
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += red[i];
     return t;
 }
 __device__ __forceinline__ double block_min(double v, double* red) {
@@ -37,7 +37,7 @@ __device__ __forceinline__ double block_min(double v, double* red) {
     if (lane == 0) red[wave] = v;
     __syncthreads();
     double t = red[0];
-    for (int i = 1; i < NF_NOISE_THREADS / 64; ++i) t = fmin(t, red[i]);
+    for (int i = 1; i < (int)(blockDim.x >> 6); ++i) t = fmin(t, red[i]);
     return t;
 }
 __device__ __forceinline__ double block_max(double v, double* red) {
@@ -47,7 +47,7 @@ __device__ __forceinline__ double block_max(double v, double* red) {
     if (lane == 0) red[wave] = v;
     __syncthreads();
     double t = red[0];
-    for (int i = 1; i < NF_NOISE_THREADS / 64; ++i) t = fmax(t, red[i]);
+    for (int i = 1; i < (int)(blockDim.x >> 6); ++i) t = fmax(t, red[i]);
     return t;
 }
 
@@ -77,32 +77,43 @@ __device__ __forceinline__ CellWin cell_window(const NoiseGrid& g, int cell, int
 // per-cell record: [0] active, [1 .. nb+1] bin edges, [nb+2 .. 2nb+1] rms per bin
 __host__ __device__ inline int cell_stride(int nb) { return 2 * nb + 2; }
 
-template <typename VT, typename WT>
+// Iterates over the pixels of a cell window with the lanes of a wavefront along x (coalesced) and the wavefronts
+// of the workgroup striding over rows: no per-pixel division.
+#define NF_CELL_LOOP(c, ww, wh, BODY)                                            \
+    for (int _r = (threadIdx.x >> 6); _r < (wh); _r += NF_NOISE_THREADS / 64) {  \
+        const long long _row = (long long)((c).y0 + _r) * W + (c).x0;            \
+        for (int _x = (threadIdx.x & 63); _x < (ww); _x += 64) {                 \
+            const long long q = _row + _x;                                       \
+            BODY                                                                 \
+        }                                                                        \
+    }
+
+template <typename VT, typename WT, bool ONEBIN>
 __global__ void k_noise_cells(const VT* __restrict__ v, const WT* __restrict__ wts, int H, int W, NoiseGrid g,
                               double* __restrict__ stats) {
     const double* quantiles = g.quantiles;
-    __shared__ double red[NF_NOISE_THREADS / 64];
-    __shared__ unsigned int hist[2 * NF_MAXBINS][256];
+    __shared__ double red[16];
+    __shared__ unsigned int hist[ONEBIN ? 1 : 2 * NF_MAXBINS][256];
     __shared__ unsigned long long prefix[2 * NF_MAXBINS];
     __shared__ unsigned int rankLeft[2 * NF_MAXBINS];
+    __shared__ double edges[NF_MAXBINS + 1];
     const int cell = blockIdx.x;
-    const int nb = g.numBins;
+    const int nb = ONEBIN ? 1 : g.numBins;
     double* rec = stats + (long long)cell * cell_stride(nb);
     const CellWin c = cell_window(g, cell, H, W);
-    const int ww = c.x1 - c.x0, wh = c.y1 - c.y0, npx = ww * wh;
+    const int ww = c.x1 - c.x0, wh = c.y1 - c.y0;
     const int tid = threadIdx.x;
 
     // ---- valid pixels, weight range ----
     double cnt = 0.0, wmin = INFINITY, wmax = -INFINITY;
-    for (int i = tid; i < npx; i += NF_NOISE_THREADS) {
-        long long q = (long long)(c.y0 + i / ww) * W + c.x0 + i % ww;
+    NF_CELL_LOOP(c, ww, wh, {
         if (v[q] != (VT)0) {
             cnt += 1.0;
             double wv = (double)wts[q];
             wmin = fmin(wmin, wv);
             wmax = fmax(wmax, wv);
         }
-    }
+    })
     const double ngood = block_sum(cnt, red);
     if (ngood == 0.0) {
         if (tid == 0) rec[0] = 0.0;
@@ -114,10 +125,10 @@ __global__ void k_noise_cells(const VT* __restrict__ v, const WT* __restrict__ w
     // ---- bin edges: np.percentile(weights[good], p) (linear method), last edge = max + 1e-6 ----
     if (nb == 1) {
         if (tid == 0) {
-            rec[1] = wmin;  // percentile 0 = minimum
-            rec[2] = wmax + 1e-6;
+            edges[0] = wmin;  // percentile 0 = minimum
+            edges[1] = wmax + 1e-6;
         }
-    } else {
+    } else if (!ONEBIN) {
         // ranks needed: floor(vi) and floor(vi)+1 for each quantile, vi = n*q + (1 - q) - 1 (numpy's expression)
         const int nr = 2 * nb;
         if (tid < nr) {
@@ -134,14 +145,213 @@ __global__ void k_noise_cells(const VT* __restrict__ v, const WT* __restrict__ w
         for (int shift = 56; shift >= 0; shift -= 8) {
             for (int i = tid; i < nr * 256; i += NF_NOISE_THREADS) (&hist[0][0])[i] = 0u;
             __syncthreads();
-            for (int i = tid; i < npx; i += NF_NOISE_THREADS) {
-                long long q = (long long)(c.y0 + i / ww) * W + c.x0 + i % ww;
+            NF_CELL_LOOP(c, ww, wh, {
                 if (v[q] != (VT)0) {
                     unsigned long long key = key_of((double)wts[q]);
                     unsigned long long hiBits = (shift == 56) ? 0ULL : (key >> (shift + 8));
                     unsigned int digit = (unsigned int)((key >> shift) & 0xFFULL);
                     for (int rk = 0; rk < nr; ++rk)
                         if (hiBits == prefix[rk]) atomicAdd(&hist[rk][digit], 1u);
+                }
+            })
+            __syncthreads();
+            if (tid < nr) {
+                unsigned int left = rankLeft[tid], acc = 0;
+                int d = 0;
+                for (; d < 256; ++d) {
+                    unsigned int h = hist[tid][d];
+                    if (left < acc + h) break;
+                    acc += h;
+                }
+                rankLeft[tid] = left - acc;
+                prefix[tid] = (prefix[tid] << 8) | (unsigned long long)d;
+            }
+            __syncthreads();
+        }
+        if (tid < nb) {
+            double q = quantiles[tid];
+            double vi = __dsub_rn(__dadd_rn(__dmul_rn(ngood, q), __dsub_rn(1.0, q)), 1.0);
+            double t = __dsub_rn(vi, floor(vi));
+            double a = unkey(prefix[2 * tid]), b = unkey(prefix[2 * tid + 1]);
+            double diff = __dsub_rn(b, a);
+            double lerp = __dadd_rn(a, __dmul_rn(diff, t));
+            if (t >= 0.5) lerp = __dsub_rn(b, __dmul_rn(diff, __dsub_rn(1.0, t)));
+            edges[tid] = lerp;
+        }
+        if (tid == 0) edges[nb] = wmax + 1e-6;
+    }
+    __syncthreads();
+    if (tid <= nb) rec[1 + tid] = edges[tid];
+
+    // ---- per-bin clipped standard deviation ----
+    // With one bin every valid pixel belongs to it ([min, max + 1e-6) covers all valid weights): weights are not re-read.
+#define NF_IN_BIN(val, q) ((val) != 0.0 && (ONEBIN || ((double)wts[q] >= lo && (double)wts[q] < hi)))
+    for (int b = 0; b < nb; ++b) {
+        const double lo = edges[b], hi = edges[b + 1];
+        double thr = INFINITY;
+        double mean = 0.0, rms = 0.0;
+        bool have = false;
+        for (int it = 0; it <= 10; ++it) {
+            double m, r, n;
+            if (it == 0) {
+                // all valid pixels of the bin: two passes (mean, then squared deviations), as np.mean / np.std do
+                double s = 0.0, nn = 0.0;
+                NF_CELL_LOOP(c, ww, wh, {
+                    double val = (double)v[q];
+                    if (NF_IN_BIN(val, q)) {
+                        s += val;
+                        nn += 1.0;
+                    }
+                })
+                s = block_sum(s, red);
+                n = block_sum(nn, red);
+                if (n == 0.0) break;      // empty bin -> rms 0
+                m = s / n;
+                double ss = 0.0;
+                NF_CELL_LOOP(c, ww, wh, {
+                    double val = (double)v[q];
+                    if (NF_IN_BIN(val, q)) {
+                        double d = val - m;
+                        ss += d * d;
+                    }
+                })
+                ss = block_sum(ss, red);
+                r = sqrt(ss / n);
+            } else {
+                // clipped set |v| < |mean + 3 rms|: one pass of moments about the previous mean (which the new mean
+                // differs from only by the clipped tail), so the variance suffers no cancellation
+                const double c0 = mean;
+                double s = 0.0, ss = 0.0, nn = 0.0;
+                NF_CELL_LOOP(c, ww, wh, {
+                    double val = (double)v[q];
+                    if (fabs(val) < thr && NF_IN_BIN(val, q)) {
+                        double d = val - c0;
+                        s += d;
+                        ss += d * d;
+                        nn += 1.0;
+                    }
+                })
+                s = block_sum(s, red);
+                ss = block_sum(ss, red);
+                n = block_sum(nn, red);
+                if (n == 0.0) continue;   // "if mask.sum() > 0" fails: keep previous mean / rms, same threshold next time
+                const double dm = s / n;
+                m = c0 + dm;
+                double var = ss / n - dm * dm;
+                r = sqrt(var > 0.0 ? var : 0.0);
+            }
+            const bool same = have && (m == mean) && (r == rms);
+            mean = m;
+            rms = r;
+            have = true;
+            thr = fabs(mean + 3.0 * rms);
+            if (same) break;          // fixed point: all remaining iterations reproduce these values
+        }
+        if (tid == 0) rec[2 + nb + b] = have ? rms : 0.0;
+    }
+#undef NF_IN_BIN
+    if (tid == 0) rec[0] = 1.0;
+}
+
+// Register-resident variant: a 1024-thread workgroup holds the whole cell window (up to 1024 * NF_VPT pixels, e.g. the
+// 160 x 160 window of a 40' grid at 0.5' pixels) in registers, so the map is read ONCE per cell (plus once per radix
+// digit for the weights when there are several bins) and the <= 11 clipping iterations run out of registers.
+#define NF_VPT 32
+#define NF_REG_THREADS 1024
+
+template <typename VT, typename WT, bool ONEBIN>
+__global__ void __launch_bounds__(NF_REG_THREADS)
+k_noise_cells_reg(const VT* __restrict__ v, const WT* __restrict__ wts, int H, int W, NoiseGrid g, double* __restrict__ stats) {
+    const double* quantiles = g.quantiles;
+    __shared__ double red[16];
+    __shared__ unsigned int hist[ONEBIN ? 1 : 2 * NF_MAXBINS][256];
+    __shared__ unsigned long long prefix[2 * NF_MAXBINS];
+    __shared__ unsigned int rankLeft[2 * NF_MAXBINS];
+    __shared__ double edges[NF_MAXBINS + 1];
+    const int cell = blockIdx.x;
+    const int nb = ONEBIN ? 1 : g.numBins;
+    double* rec = stats + (long long)cell * cell_stride(nb);
+    const CellWin c = cell_window(g, cell, H, W);
+    const int ww = c.x1 - c.x0, wh = c.y1 - c.y0, npx = ww * wh;
+    const int tid = threadIdx.x;
+
+    double val[NF_VPT];
+    unsigned long long binLo = 0ULL, binHi = 0ULL;   // 4-bit bin index of each held value
+    unsigned int validMask = 0u;                       // bit j: held value j is a valid (non-zero) pixel
+    double cnt = 0.0, wmin = INFINITY, wmax = -INFINITY;
+    // element j of thread tid is window pixel j * 1024 + tid (consecutive lanes -> consecutive x)
+    int r0 = tid / ww, x0 = tid - r0 * ww;
+    const int dr = NF_REG_THREADS / ww, dx = NF_REG_THREADS - dr * ww;
+    {
+        int rr = r0, xx = x0;
+#pragma unroll
+        for (int j = 0; j < NF_VPT; ++j) {
+            double t = 0.0;
+            if (j * NF_REG_THREADS + tid < npx) {
+                const long long q = (long long)(c.y0 + rr) * W + c.x0 + xx;
+                t = (double)v[q];
+                if (t != 0.0) {
+                    validMask |= 1u << j;
+                    cnt += 1.0;
+                    double wv = (double)wts[q];
+                    wmin = fmin(wmin, wv);
+                    wmax = fmax(wmax, wv);
+                }
+            }
+            val[j] = t;
+            rr += dr;
+            xx += dx;
+            if (xx >= ww) {
+                xx -= ww;
+                rr += 1;
+            }
+        }
+    }
+    const double ngood = block_sum(cnt, red);
+    if (ngood == 0.0) {
+        if (tid == 0) rec[0] = 0.0;
+        return;
+    }
+    wmin = block_min(wmin, red);
+    wmax = block_max(wmax, red);
+
+    if (nb == 1) {
+        if (tid == 0) {
+            edges[0] = wmin;
+            edges[1] = wmax + 1e-6;
+        }
+    } else if (!ONEBIN) {
+        const int nr = 2 * nb;
+        if (tid < nr) {
+            double q = quantiles[tid / 2];
+            double vi = __dsub_rn(__dadd_rn(__dmul_rn(ngood, q), __dsub_rn(1.0, q)), 1.0);
+            double fl = floor(vi);
+            long long r = (long long)fl + (tid & 1);
+            if (r > (long long)ngood - 1) r = (long long)ngood - 1;
+            if (r < 0) r = 0;
+            rankLeft[tid] = (unsigned int)r;
+            prefix[tid] = 0ULL;
+        }
+        __syncthreads();
+        for (int shift = 56; shift >= 0; shift -= 8) {
+            for (int i = tid; i < nr * 256; i += NF_REG_THREADS) (&hist[0][0])[i] = 0u;
+            __syncthreads();
+            int rr = r0, xx = x0;
+#pragma unroll 1
+            for (int j = 0; j < NF_VPT; ++j) {
+                if ((validMask >> j) & 1u) {
+                    const long long q = (long long)(c.y0 + rr) * W + c.x0 + xx;
+                    unsigned long long key = key_of((double)wts[q]);
+                    unsigned long long hiBits = (shift == 56) ? 0ULL : (key >> (shift + 8));
+                    unsigned int digit = (unsigned int)((key >> shift) & 0xFFULL);
+                    for (int rk = 0; rk < nr; ++rk)
+                        if (hiBits == prefix[rk]) atomicAdd(&hist[rk][digit], 1u);
+                }
+                rr += dr;
+                xx += dx;
+                if (xx >= ww) {
+                    xx -= ww;
+                    rr += 1;
                 }
             }
             __syncthreads();
@@ -166,77 +376,148 @@ __global__ void k_noise_cells(const VT* __restrict__ v, const WT* __restrict__ w
             double diff = __dsub_rn(b, a);
             double lerp = __dadd_rn(a, __dmul_rn(diff, t));
             if (t >= 0.5) lerp = __dsub_rn(b, __dmul_rn(diff, __dsub_rn(1.0, t)));
-            rec[1 + tid] = lerp;
+            edges[tid] = lerp;
         }
-        if (tid == 0) rec[1 + nb] = wmax + 1e-6;
+        if (tid == 0) edges[nb] = wmax + 1e-6;
     }
     __syncthreads();
-    __threadfence_block();
+    if (tid <= nb) rec[1 + tid] = edges[tid];
 
-    // ---- per-bin clipped standard deviation ----
+    if (!ONEBIN) {
+        // bin of every held value: the LAST b with edges[b] <= w < edges[b+1] is irrelevant - bins are disjoint unless
+        // edges repeat, and then the reference's later bins overwrite earlier ones only in the paint step (per-bin sets
+        // are still "w >= lo and w < hi"), so a value may belong to no bin (15 = none) but never to two non-empty ones
+        int rr = r0, xx = x0;
+#pragma unroll 1
+        for (int j = 0; j < NF_VPT; ++j) {
+            unsigned long long bsel = 15ULL;
+            if ((validMask >> j) & 1u) {
+                const long long q = (long long)(c.y0 + rr) * W + c.x0 + xx;
+                const double wv = (double)wts[q];
+                for (int b = 0; b < nb; ++b)
+                    if (wv >= edges[b] && wv < edges[b + 1]) bsel = (unsigned long long)b;
+            }
+            if (j < 16)
+                binLo |= bsel << (4 * (j & 15));
+            else
+                binHi |= bsel << (4 * (j & 15));
+            rr += dr;
+            xx += dx;
+            if (xx >= ww) {
+                xx -= ww;
+                rr += 1;
+            }
+        }
+    }
+
+#define NF_HELD_IN_BIN(j, b) (val[j] != 0.0 && (ONEBIN || (int)(((j) < 16 ? (binLo >> (4 * (j))) : (binHi >> (4 * ((j) - 16)))) & 15ULL) == (b)))
     for (int b = 0; b < nb; ++b) {
-        const double lo = rec[1 + b], hi = rec[2 + b];
-        // first pass: all valid pixels of the bin
-        double thr = INFINITY;  // |v| < thr ; the first evaluation takes everything
+        double thr = INFINITY;
         double mean = 0.0, rms = 0.0;
         bool have = false;
         for (int it = 0; it <= 10; ++it) {
-            double s = 0.0, n = 0.0;
-            for (int i = tid; i < npx; i += NF_NOISE_THREADS) {
-                long long q = (long long)(c.y0 + i / ww) * W + c.x0 + i % ww;
-                double val = (double)v[q];
-                double wv = (double)wts[q];
-                if (val != 0.0 && wv >= lo && wv < hi && (it == 0 || fabs(val) < thr)) {
-                    s += val;
-                    n += 1.0;
-                }
+            double m, r, n;
+            if (it == 0) {
+                double s = 0.0, nn = 0.0;
+#pragma unroll
+                for (int j = 0; j < NF_VPT; ++j)
+                    if (NF_HELD_IN_BIN(j, b)) {
+                        s += val[j];
+                        nn += 1.0;
+                    }
+                s = block_sum(s, red);
+                n = block_sum(nn, red);
+                if (n == 0.0) break;
+                m = s / n;
+                double ss = 0.0;
+#pragma unroll
+                for (int j = 0; j < NF_VPT; ++j)
+                    if (NF_HELD_IN_BIN(j, b)) {
+                        double d = val[j] - m;
+                        ss += d * d;
+                    }
+                ss = block_sum(ss, red);
+                r = sqrt(ss / n);
+            } else {
+                const double c0 = mean;
+                double s = 0.0, ss = 0.0, nn = 0.0;
+#pragma unroll
+                for (int j = 0; j < NF_VPT; ++j)
+                    if (fabs(val[j]) < thr && NF_HELD_IN_BIN(j, b)) {
+                        double d = val[j] - c0;
+                        s += d;
+                        ss += d * d;
+                        nn += 1.0;
+                    }
+                s = block_sum(s, red);
+                ss = block_sum(ss, red);
+                n = block_sum(nn, red);
+                if (n == 0.0) continue;
+                const double dm = s / n;
+                m = c0 + dm;
+                double var = ss / n - dm * dm;
+                r = sqrt(var > 0.0 ? var : 0.0);
             }
-            s = block_sum(s, red);
-            n = block_sum(n, red);
-            if (n == 0.0) {
-                if (it == 0) break;   // empty bin -> rms 0
-                continue;             // "if mask.sum() > 0" fails: keep previous mean / rms, same threshold next time
-            }
-            const double m = s / n;
-            double ss = 0.0;
-            for (int i = tid; i < npx; i += NF_NOISE_THREADS) {
-                long long q = (long long)(c.y0 + i / ww) * W + c.x0 + i % ww;
-                double val = (double)v[q];
-                double wv = (double)wts[q];
-                if (val != 0.0 && wv >= lo && wv < hi && (it == 0 || fabs(val) < thr)) {
-                    double d = val - m;
-                    ss += d * d;
-                }
-            }
-            ss = block_sum(ss, red);
-            const double r = sqrt(ss / n);
             const bool same = have && (m == mean) && (r == rms);
             mean = m;
             rms = r;
             have = true;
             thr = fabs(mean + 3.0 * rms);
-            if (same) break;          // fixed point: all remaining iterations reproduce these values
+            if (same) break;
         }
         if (tid == 0) rec[2 + nb + b] = have ? rms : 0.0;
     }
+#undef NF_HELD_IN_BIN
     if (tid == 0) rec[0] = 1.0;
+}
+
+// index range [lo, hi] of the cells whose widened window contains coordinate t along one axis (edges ascending)
+__device__ __forceinline__ void cell_range(const int* __restrict__ e, int ncell, int overlap, int t, int* lo, int* hi) {
+    // hi: last cell with e[i] - overlap <= t
+    int a = 0, b = ncell - 1, h = -1;
+    while (a <= b) {
+        int mid = (a + b) >> 1;
+        if (e[mid] - overlap <= t) {
+            h = mid;
+            a = mid + 1;
+        } else
+            b = mid - 1;
+    }
+    // lo: first cell with t < e[i+1] + overlap
+    a = 0;
+    b = ncell - 1;
+    int l = ncell;
+    while (a <= b) {
+        int mid = (a + b) >> 1;
+        if (t < e[mid + 1] + overlap) {
+            l = mid;
+            b = mid - 1;
+        } else
+            a = mid + 1;
+    }
+    *lo = l;
+    *hi = h;
 }
 
 template <typename WT>
 __global__ void k_noise_paint(const WT* __restrict__ wts, float* __restrict__ rmsMap, int H, int W, NoiseGrid g,
                               const double* __restrict__ stats) {
-    const long long n = (long long)H * W;
     const int nb = g.numBins;
     const int stride = cell_stride(nb);
-    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x) {
-        const int y = (int)(p / W), x = (int)(p % W);
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= W) return;
+    int kLo, kHi;
+    cell_range(g.xEdges, g.nx, g.overlap, x, &kLo, &kHi);
+    for (int y = blockIdx.y; y < H; y += gridDim.y) {
+        int iLo, iHi;
+        cell_range(g.yEdges, g.ny, g.overlap, y, &iLo, &iHi);
+        const long long p = (long long)y * W + x;
         const double wv = (double)wts[p];
         float outv = 0.0f;
         bool done = false;
-        for (int i = g.ny - 1; i >= 0 && !done; --i) {
-            if (y < g.yEdges[i] - g.overlap || y >= g.yEdges[i + 1] + g.overlap) continue;
-            for (int k = g.nx - 1; k >= 0 && !done; --k) {
-                if (x < g.xEdges[k] - g.overlap || x >= g.xEdges[k + 1] + g.overlap) continue;
+        // the reference writes cells in (i, k, bin) order and later writes win: scan candidates backwards
+        for (int i = iHi; i >= iLo && !done; --i) {
+            for (int k = kHi; k >= kLo && !done; --k) {
                 const double* rec = stats + (long long)(i * g.nx + k) * stride;
                 if (rec[0] == 0.0) continue;
                 for (int b = nb - 1; b >= 0; --b) {
@@ -317,21 +598,36 @@ int noise_map(int vtype, const void* filtered, const void* weights, int wtype, f
     }
     double* stats = (double*)cellStats;
     dim3 gc(g.ny * g.nx), bc(NF_NOISE_THREADS);
-#define NF_NC(VT, WT) \
-    hipLaunchKernelGGL((k_noise_cells<VT, WT>), gc, bc, 0, s, (const VT*)filtered, (const WT*)weights, H, W, g, stats)
+    // widest possible window: (largest cell + 2 * overlap)^2; cells differ by at most one pixel (np.linspace(dtype=int))
+    const long long maxH = (long long)(H / g.ny + 1) + 2LL * g.overlap, maxW = (long long)(W / g.nx + 1) + 2LL * g.overlap;
+    const bool inRegs = (maxH < H ? maxH : H) * (maxW < W ? maxW : W) <= (long long)NF_VPT * NF_REG_THREADS;
+    if (inRegs) bc = dim3(NF_REG_THREADS);
+#define NF_NC(VT, WT)                                                                                                        \
+    do {                                                                                                                     \
+        if (inRegs && g.numBins == 1)                                                                                        \
+            hipLaunchKernelGGL((k_noise_cells_reg<VT, WT, true>), gc, bc, 0, s, (const VT*)filtered, (const WT*)weights, H,  \
+                               W, g, stats);                                                                                 \
+        else if (inRegs)                                                                                                     \
+            hipLaunchKernelGGL((k_noise_cells_reg<VT, WT, false>), gc, bc, 0, s, (const VT*)filtered, (const WT*)weights, H, \
+                               W, g, stats);                                                                                 \
+        else if (g.numBins == 1)                                                                                             \
+            hipLaunchKernelGGL((k_noise_cells<VT, WT, true>), gc, bc, 0, s, (const VT*)filtered, (const WT*)weights, H, W, g, \
+                               stats);                                                                                       \
+        else                                                                                                                 \
+            hipLaunchKernelGGL((k_noise_cells<VT, WT, false>), gc, bc, 0, s, (const VT*)filtered, (const WT*)weights, H, W,  \
+                               g, stats);                                                                                    \
+    } while (0)
     if (vtype == NF_F64 && wtype == NF_F64) NF_NC(double, double);
     else if (vtype == NF_F64 && wtype == NF_F32) NF_NC(double, float);
     else if (vtype == NF_F32 && wtype == NF_F64) NF_NC(float, double);
     else NF_NC(float, float);
 #undef NF_NC
     NF_CHECK_LAUNCH("k_noise_cells");
-    long long n = (long long)H * W;
-    long long gp = (n + 255) / 256;
-    if (gp > 4096) gp = 4096;
+    dim3 gp(nf_div_up(W, 256), H < 1024 ? H : 1024);
     if (wtype == NF_F64)
-        hipLaunchKernelGGL(k_noise_paint<double>, dim3((int)gp), dim3(256), 0, s, (const double*)weights, rms, H, W, g, stats);
+        hipLaunchKernelGGL(k_noise_paint<double>, gp, dim3(256), 0, s, (const double*)weights, rms, H, W, g, stats);
     else
-        hipLaunchKernelGGL(k_noise_paint<float>, dim3((int)gp), dim3(256), 0, s, (const float*)weights, rms, H, W, g, stats);
+        hipLaunchKernelGGL(k_noise_paint<float>, gp, dim3(256), 0, s, (const float*)weights, rms, H, W, g, stats);
     NF_CHECK_LAUNCH("k_noise_paint");
     return NF_OK;
 }

@@ -6,16 +6,28 @@
 
 namespace nf {
 
+// One butterfly stage of a line transform: radix R on elements base + k*L (k < R), base = (b / L) * L * R + b % L.
+struct StageInfo {
+    int R;
+    int L;           // product of the radices of the earlier (DIT order) stages
+    unsigned magic;  // ceil(2^32 / L): b / L == __umulhi(b, magic) for every b, L < 2^15   (unused when L == 1)
+    int twOff;       // stage twiddles in LinePlan::stw: [(k-1) * L + q] = exp(-2 pi i q k / (L R)), k = 1..R-1, q < L
+    int rootOff;     // R-th roots of unity in LinePlan::stw (odd radices > 3 only)
+};
+
 template <typename T>
 struct LinePlan {
     int n;          // logical transform length
     int m;          // working length in LDS (== n, or the padded Bluestein length)
+    int mPad;       // m rounded up to a multiple of 32 (the LDS swizzle permutes within 32-element blocks)
     int bluestein;  // 1 if n has a prime factor > 13
-    int nfac;
-    int fac[NF_MAXFAC];     // radices of m, applied in this order by the DIT pass
-    const cpx<T>* tw;       // [m]  exp(-2 pi i k / m)
-    const cpx<T>* chirp;    // [n]  exp(-i pi k^2 / n)                        (Bluestein only)
-    const cpx<T>* chirpFp;  // [m]  FFT_m(conj chirp, wrapped) / m, digit-reversed positions (Bluestein only)
+    int nst;
+    StageInfo st[NF_MAXFAC];    // DIT order: st[0].L == 1
+    const cpx<T>* stw;          // stage twiddles and small-root tables
+    const unsigned short* rev;  // [m] digit-reversed position of natural index i
+    const unsigned short* src;  // [m] natural index held at digit-reversed position e (inverse of rev)
+    const cpx<T>* chirp;        // [n]  exp(-i pi k^2 / n)                        (Bluestein only)
+    const cpx<T>* chirpFp;      // [m]  FFT_m(conj chirp, wrapped) / m, digit-reversed positions (Bluestein only)
 };
 
 template <typename T>
@@ -27,13 +39,12 @@ struct LineArgs {
     long long inElemStride, inLineStride, inBatchStride;
     long long outElemStride, outLineStride, outBatchStride;
     int nLines;
-    int linesPerWG;
-    int lineFast;   // LDS layout: 1 = [element][line] (column tiles), 0 = [line][element] (rows)
-    int lineIsRow;  // which apod table applies to the line index (1: apodLine is the axis -2 profile)
-    int conjIn, conjOut;
-    int scaleDiv;
-    double scale;
-    const double* apodLine;  // optional per-line apodisation factors (length nLines)
+    int linesPerWG;  // rows kernel: lines staged per workgroup; columns kernel: adjacent columns per tile (power of two)
+    int tb;          // rows kernel: threads along the butterfly index (the rest of the workgroup strides over lines)
+    int nTiles;      // columns kernel: number of column tiles
+    double conjInSign, conjOutSign;  // -1 conjugates the complex input / output (inverse = conj FFT conj), else +1
+    double scale;    // multiplier applied at the store (1 / sqrt(H*W) for unitary transforms, else 1)
+    const double* apodLine;  // optional per-line apodisation factors (length nLines); rows kernel, real input only
     const double* apodElem;  // optional per-element apodisation factors (length n)
 };
 
@@ -41,7 +52,7 @@ template <typename T>
 struct Plan2D {
     int H, W;
     LinePlan<T> row, col;
-    int rowsPerWG, colsPerWG, threadsRow, threadsCol;
+    int rowsPerWG, colsPerWG, threadsRow, tbRow, threadsCol;
     int init(int H, int W);
     void destroy();
     int forward(const void* in, int inType, void* out, int batch, const double* apodY, const double* apodX,

@@ -3,13 +3,23 @@
 // Replaces enmap.fft / enmap.ifft (pixell) at nemo/filters.py:525,548,559,615,646,662,679,847 and the
 // transforms inside enmap.apply_window (nemo/filters.py:100,644).
 //
-// Structure: a 2-D transform is two "line" passes (rows, then columns, or the reverse for the inverse).
-// One workgroup stages a bundle of lines in LDS (rows: whole contiguous rows; columns: a tile of
-// adjacent columns so that every global access is a run of contiguous bytes), runs an in-place
-// mixed-radix Cooley-Tukey on them (radices 2,3,4,5,7,8,11,13; digit-reversed placement is folded into
-// the global->LDS load, so no second LDS buffer is needed), and writes them back.  Lengths with a
-// larger prime factor (1031 and 1032 = 8*3*43 are real nemo tile dimensions) go through Bluestein's
-// chirp-z algorithm, still inside LDS: DIF forward (natural -> digit-reversed), pointwise multiply by the
+// Structure: a 2-D transform is two "line" passes (rows, then columns, or the reverse for the inverse), each
+// reading and writing the plane once.  A workgroup keeps a bundle of lines in LDS and runs an in-place
+// mixed-radix decimation-in-time FFT on it (radices 2,3,4,5,7,8,11,13):
+//   * rows kernel: whole contiguous rows; the digit-reversed placement is folded into the global -> LDS copy
+//     (table lookup), the last stage stores straight from registers to global memory (natural order,
+//     consecutive lanes -> consecutive elements);
+//   * columns kernel: a tile of adjacent columns, so that every global access is a run of contiguous bytes;
+//     the FIRST stage loads its operands straight from global memory (row src[e] for digit-reversed position
+//     e - for a column tile any row order is equally coalesced) and the LAST stage stores straight to global
+//     memory, so a transform of S stages crosses LDS only S-1 times; tiles are dealt to the XCDs so that
+//     neighbouring tiles (which share 128-byte lines when the tile is narrow) run on the same XCD / L2.
+// Stage twiddles come from per-stage tables laid out [k][q] (consecutive lanes read consecutive entries and a
+// thread reuses them for every line it owns); b / L and b % L use a multiply-high by a precomputed reciprocal;
+// LDS element e lives at e ^ (((e >> 3) ^ (e >> 9)) & 31), which keeps the stride-1, stride-8 and stride-64/512
+// access patterns of the radix-8 stages free of bank conflicts without padding.
+// Lengths with a prime factor > 13 (1031 and 1032 = 8*3*43 are real nemo tile dimensions) go through
+// Bluestein's chirp-z algorithm inside LDS: DIF forward (natural -> digit-reversed), pointwise multiply by the
 // pre-permuted chirp spectrum, DIT back (digit-reversed -> natural).
 //
 // The inverse direction uses conj(FFT(conj(x))), applied at load/store, so only forward twiddles exist.
@@ -21,24 +31,16 @@
 #pragma clang fp contract(fast)
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
+
+#define NF_FFT_MAXTHREADS 512
+#define NF_STAGE_IN 8
 
 // ------------------------------------------------------------------------------------------------------
 // device engine
 // ------------------------------------------------------------------------------------------------------
-template <typename T>
-__device__ __forceinline__ int digit_reverse(int i, const nf::LinePlan<T>& p) {
-    int pos = 0, rem = i, blk = p.m;
-    for (int j = p.nfac - 1; j >= 0; --j) {
-        int r = p.fac[j];
-        blk /= r;
-        pos += (rem % r) * blk;
-        rem /= r;
-    }
-    return pos;
-}
-
 template <typename T, int R>
 struct Dft;
 
@@ -138,105 +140,35 @@ struct Dft {
     }
 };
 
-// One in-place stage over all lines of the bundle.  DIT: twiddle inputs then butterfly; DIF: butterfly then twiddle.
-template <typename T, int R, bool DIT>
-__device__ __forceinline__ void fft_stage(cpx<T>* buf, const nf::LinePlan<T>& p, int L, int nl, int lpw, bool lineFast) {
-    const int m = p.m;
-    const int nb = m / R;
-    const int Lp = L * R;
-    const int twstep = m / Lp;
-    cpx<T> wR[R];
-    if (R != 2 && R != 4 && R != 8 && R != 3) {
-#pragma unroll
-        for (int j = 0; j < R; ++j) wR[j] = p.tw[(long long)j * (m / R)];
-    }
-    const int total = nb * nl;
-    for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
-        int b, c;
-        if (lineFast) {
-            c = idx % nl;
-            b = idx / nl;
-        } else {
-            b = idx % nb;
-            c = idx / nb;
-        }
-        const int q = b % L, g = b / L;
-        const int base = g * Lp + q;
-        cpx<T> a[R];
-#pragma unroll
-        for (int k = 0; k < R; ++k) {
-            int e = base + k * L;
-            a[k] = buf[lineFast ? e * lpw + c : c * m + e];
-        }
-        if (DIT && L > 1) {
-#pragma unroll
-            for (int k = 1; k < R; ++k) a[k] = cmul(a[k], p.tw[q * k * twstep]);
-        }
-        Dft<T, R>::run(a, wR);
-        if (!DIT && L > 1) {
-#pragma unroll
-            for (int k = 1; k < R; ++k) a[k] = cmul(a[k], p.tw[q * k * twstep]);
-        }
-#pragma unroll
-        for (int k = 0; k < R; ++k) {
-            int e = base + k * L;
-            buf[lineFast ? e * lpw + c : c * m + e] = a[k];
-        }
-    }
-    __syncthreads();
+__device__ __forceinline__ int swz(int e) {
+    return e ^ (int)(__builtin_amdgcn_ubfe((unsigned)e, 3u, 5u) ^ __builtin_amdgcn_ubfe((unsigned)e, 9u, 5u));
 }
 
-template <typename T, bool DIT>
-__device__ __forceinline__ void fft_stage_dispatch(cpx<T>* buf, const nf::LinePlan<T>& p, int r, int L, int nl, int lpw,
-                                                   bool lineFast) {
-    switch (r) {
-        case 2: fft_stage<T, 2, DIT>(buf, p, L, nl, lpw, lineFast); break;
-        case 3: fft_stage<T, 3, DIT>(buf, p, L, nl, lpw, lineFast); break;
-        case 4: fft_stage<T, 4, DIT>(buf, p, L, nl, lpw, lineFast); break;
-        case 5: fft_stage<T, 5, DIT>(buf, p, L, nl, lpw, lineFast); break;
-        case 7: fft_stage<T, 7, DIT>(buf, p, L, nl, lpw, lineFast); break;
-        case 8: fft_stage<T, 8, DIT>(buf, p, L, nl, lpw, lineFast); break;
-        case 11: fft_stage<T, 11, DIT>(buf, p, L, nl, lpw, lineFast); break;
-        case 13: fft_stage<T, 13, DIT>(buf, p, L, nl, lpw, lineFast); break;
-        default: break;
-    }
-}
+// what a thread needs to know about where its lines live
+struct Geo {
+    int nl;               // valid lines of this workgroup
+    int tb, TB;           // butterfly lane and stride
+    int tl, TL;           // rows kernel: line lane and stride;  columns kernel: tl = column within the tile, TL = tile width
+    int line0;            // first global line of the workgroup
+    long long inBase, outBase;
+};
 
-// digit-reversed input -> natural output
-template <typename T>
-__device__ void fft_dit(cpx<T>* buf, const nf::LinePlan<T>& p, int nl, int lpw, bool lineFast) {
-    int L = 1;
-    for (int j = 0; j < p.nfac; ++j) {
-        fft_stage_dispatch<T, true>(buf, p, p.fac[j], L, nl, lpw, lineFast);
-        L *= p.fac[j];
-    }
-}
-// natural input -> digit-reversed output
-template <typename T>
-__device__ void fft_dif(cpx<T>* buf, const nf::LinePlan<T>& p, int nl, int lpw, bool lineFast) {
-    int L = p.m;
-    for (int j = p.nfac - 1; j >= 0; --j) {
-        L /= p.fac[j];
-        fft_stage_dispatch<T, false>(buf, p, p.fac[j], L, nl, lpw, lineFast);
-    }
-}
-
-template <typename T>
-__device__ __forceinline__ cpx<T> load_elem(const nf::LineArgs<T>& a, long long off, int line, int i) {
+// IT: 0 complex<T>, 1 real float64, 2 real float32, 3 / 4 the same two with apodisation (rows kernel only: `fl` is the
+// axis -2 profile value of the row, apodElem the axis -1 profile).  OT: 0 complex<T>, 1 real float64, 2 real float32.
+// Compile-time so that the per-element code has no branches.
+template <typename T, int IT>
+__device__ __forceinline__ cpx<T> load_elem(const nf::LineArgs<T>& a, long long off, double fl, int i) {
     cpx<T> v;
-    if (a.inType == 0) {
+    if (IT == 0) {
         v = ((const cpx<T>*)a.in)[off];
+        v.y *= (T)a.conjInSign;
     } else {
-        double x = (a.inType == 1) ? ((const double*)a.in)[off] : (double)((const float*)a.in)[off];
-        if (a.apodLine != nullptr) {
+        constexpr bool F32 = (IT == 2 || IT == 4);
+        double x = F32 ? (double)((const float*)a.in)[off] : ((const double*)a.in)[off];
+        if (IT >= 3) {
             // enmap.apod: axis -2 profile first, then axis -1, each multiply rounded to the map dtype
-            double fl = a.apodLine[line], fe = a.apodElem[i];
-            if (a.lineIsRow == 0) {
-                double t = fl;
-                fl = fe;
-                fe = t;
-            }
-            if (a.inType == 2) {
+            const double fe = a.apodElem[i];
+            if (F32) {
                 x = (double)(float)(x * fl);
                 x = (double)(float)(x * fe);
             } else {
@@ -247,93 +179,261 @@ __device__ __forceinline__ cpx<T> load_elem(const nf::LineArgs<T>& a, long long 
         v.x = (T)x;
         v.y = (T)0;
     }
-    if (a.conjIn) v.y = -v.y;
     return v;
 }
 
-template <typename T, bool LINEFAST>
-__global__ void k_fft_lines(nf::LineArgs<T> a) {
+template <typename T, int OT, bool BLUE>
+__device__ __forceinline__ void store_elem(const nf::LineArgs<T>& a, long long off, int i, cpx<T> v) {
+    const nf::LinePlan<T>& p = a.plan;
+    if (BLUE) v = cmul(cconj(v), p.chirp[i]);
+    // multiplication by the rounded reciprocal of sqrt(H*W): within 1 ulp of the reference's division, exact when
+    // H*W is a power of four; 1 when the transform is not scaled
+    const T r = (T)a.scale;
+    if (OT == 0) {
+        v.x *= r;
+        v.y *= r * (T)a.conjOutSign;
+        ((cpx<T>*)a.out)[off] = v;
+    } else if (OT == 1) {
+        ((double*)a.out)[off] = (double)(v.x * r);
+    } else {
+        ((float*)a.out)[off] = (float)(v.x * r);
+    }
+}
+
+// One in-place stage.  DIT (dif == false): twiddle the inputs, then the butterfly; DIF: butterfly, then twiddle the
+// outputs.  srcG: operands come from global memory (columns kernel, first DIT stage: row src[e]); dstG: results go
+// to global memory (last DIT stage: natural index e).
+template <typename T, int R, bool COLS, bool BLUE>
+__device__ __forceinline__ void fft_stage(cpx<T>* __restrict__ buf, const nf::LineArgs<T>& a, const nf::StageInfo st,
+                                          const bool dif, const bool srcG, const bool dstG, const Geo& G) {
+    const nf::LinePlan<T>& p = a.plan;
+    const unsigned L = (unsigned)st.L, LR = L * R;
+    const unsigned nb = (unsigned)p.m / R;
+    const unsigned lineMul = COLS ? 1u : (unsigned)p.mPad;   // LDS index = line * lineMul + swz(e) * elemMul
+    const unsigned elemMul = COLS ? (unsigned)G.TL : 1u;
+    const cpx<T>* __restrict__ twp = p.stw + st.twOff;
+    cpx<T> wR[R];
+    if (R != 2 && R != 4 && R != 8 && R != 3) {
+#pragma unroll
+        for (int j = 0; j < R; ++j) wR[j] = p.stw[st.rootOff + j];
+    }
+    for (unsigned b = (unsigned)G.tb; b < nb; b += (unsigned)G.TB) {
+        unsigned g = b, q = 0;
+        if (L > 1) {
+            g = __umulhi(b, st.magic);
+            q = b - g * L;
+        }
+        const unsigned base = g * LR + q;
+        cpx<T> w[R - 1];
+        if (L > 1) {
+#pragma unroll
+            for (int k = 1; k < R; ++k) w[k - 1] = twp[(unsigned)(k - 1) * L + q];
+        }
+        unsigned idx[R];   // LDS element index, or (srcG) the global row
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const unsigned e = base + (unsigned)k * L;
+            idx[k] = srcG ? (unsigned)p.src[e] : (unsigned)swz((int)e) * elemMul;
+        }
+        for (int line = G.tl; line < G.nl; line += (COLS ? G.nl : G.TL)) {
+            cpx<T>* __restrict__ lb = buf + (unsigned)line * lineMul;
+            cpx<T> x[R];
+            if (srcG) {
+                const long long lo = G.inBase + (long long)(G.line0 + line) * a.inLineStride;
+#pragma unroll
+                for (int k = 0; k < R; ++k)
+                    x[k] = load_elem<T, 0>(a, lo + (long long)idx[k] * a.inElemStride, 1.0, (int)idx[k]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < R; ++k) x[k] = lb[idx[k]];
+            }
+            if (L > 1 && !dif) {
+#pragma unroll
+                for (int k = 1; k < R; ++k) x[k] = cmul(x[k], w[k - 1]);
+            }
+            Dft<T, R>::run(x, wR);
+            if (L > 1 && dif) {
+#pragma unroll
+                for (int k = 1; k < R; ++k) x[k] = cmul(x[k], w[k - 1]);
+            }
+            if (dstG) {
+                const long long lo = G.outBase + (long long)(G.line0 + line) * a.outLineStride;
+#define NF_STORE_ALL(OT)                                                                                          \
+    _Pragma("unroll") for (int k = 0; k < R; ++k) {                                                               \
+        const unsigned e = base + (unsigned)k * L;                                                                \
+        if (!BLUE || e < (unsigned)p.n) store_elem<T, OT, BLUE>(a, lo + (long long)e * a.outElemStride, (int)e, x[k]); \
+    }
+                if (a.outType == 0) {
+                    NF_STORE_ALL(0)
+                } else if (a.outType == 1) {
+                    NF_STORE_ALL(1)
+                } else {
+                    NF_STORE_ALL(2)
+                }
+#undef NF_STORE_ALL
+            } else if (srcG) {
+#pragma unroll
+                for (int k = 0; k < R; ++k) lb[(unsigned)swz((int)(base + (unsigned)k * L)) * elemMul] = x[k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < R; ++k) lb[idx[k]] = x[k];
+            }
+        }
+    }
+    if (!dstG) __syncthreads();
+}
+
+// BIG == false: instantiates only the radices up to 8 (fewer registers: every nemo tile length without a factor 11 or
+// 13 runs this variant)
+template <typename T, bool COLS, int MODE>
+__device__ __forceinline__ void fft_stage_dispatch(cpx<T>* buf, const nf::LineArgs<T>& a, int s, bool dif, bool srcG,
+                                                   bool dstG, const Geo& G) {
+    const nf::StageInfo st = a.plan.st[s];
+    constexpr bool BIG = MODE == 1;
+    if (!BIG && st.R > 8) return;
+    switch (st.R) {
+        case 2: fft_stage<T, 2, COLS, MODE == 2>(buf, a, st, dif, srcG, dstG, G); break;
+        case 3: fft_stage<T, 3, COLS, MODE == 2>(buf, a, st, dif, srcG, dstG, G); break;
+        case 4: fft_stage<T, 4, COLS, MODE == 2>(buf, a, st, dif, srcG, dstG, G); break;
+        case 5: fft_stage<T, 5, COLS, MODE == 2>(buf, a, st, dif, srcG, dstG, G); break;
+        case 7: fft_stage<T, 7, COLS, MODE == 2>(buf, a, st, dif, srcG, dstG, G); break;
+        case 8: fft_stage<T, 8, COLS, MODE == 2>(buf, a, st, dif, srcG, dstG, G); break;
+        case 11: if (BIG) fft_stage<T, 11, COLS, MODE == 2>(buf, a, st, dif, srcG, dstG, G); break;
+        case 13: if (BIG) fft_stage<T, 13, COLS, MODE == 2>(buf, a, st, dif, srcG, dstG, G); break;
+        default: break;
+    }
+}
+
+// Bluestein middle: natural order data in LDS -> DIF -> multiply by the chirp spectrum (conjugated: the way back is a
+// forward transform of the conjugate) -> ready for the DIT stages.
+template <typename T, bool COLS, int MODE>
+__device__ __forceinline__ void bluestein_middle(cpx<T>* buf, const nf::LineArgs<T>& a, const Geo& G) {
+    const nf::LinePlan<T>& p = a.plan;
+    for (int s = p.nst - 1; s >= 0; --s) fft_stage_dispatch<T, COLS, MODE>(buf, a, s, true, false, false, G);
+    for (int e = G.tb; e < p.m; e += G.TB) {
+        const cpx<T> cf = p.chirpFp[e];
+        for (int line = G.tl; line < G.nl; line += (COLS ? G.nl : G.TL)) {
+            const int at = COLS ? swz(e) * G.TL + line : line * p.mPad + swz(e);
+            buf[at] = cconj(cmul(buf[at], cf));
+        }
+    }
+    __syncthreads();
+}
+
+template <typename T, int IT, bool BLUE>
+__device__ __forceinline__ void stage_in_rows(cpx<T>* __restrict__ buf, const nf::LineArgs<T>& a, const Geo& G) {
+    const nf::LinePlan<T>& p = a.plan;
+    const int nIn = BLUE ? p.m : p.n;
+    for (int line = G.tl; line < G.nl; line += G.TL) {
+        const long long lineOff = G.inBase + (long long)(G.line0 + line) * a.inLineStride;
+        cpx<T>* __restrict__ lb = buf + line * p.mPad;
+        const double fl = IT >= 3 ? a.apodLine[G.line0 + line] : 1.0;
+        for (int i0 = G.tb; i0 < nIn; i0 += NF_STAGE_IN * G.TB) {
+            // branch-free load phase (indices clamped to the line) so that all loads are in flight together
+            cpx<T> v[NF_STAGE_IN], ch[BLUE ? NF_STAGE_IN : 1];
+            int pos[NF_STAGE_IN];
+#pragma unroll
+            for (int j = 0; j < NF_STAGE_IN; ++j) {
+                const int i = min(i0 + j * G.TB, p.n - 1);
+                v[j] = load_elem<T, IT>(a, lineOff + (long long)i * a.inElemStride, fl, i);
+                if (BLUE)
+                    ch[j] = p.chirp[i];
+                else
+                    pos[j] = p.rev[i];
+            }
+#pragma unroll
+            for (int j = 0; j < NF_STAGE_IN; ++j) {
+                const int i = i0 + j * G.TB;
+                if (i < nIn) {
+                    cpx<T> t = v[j];
+                    if (BLUE) {
+                        t = cmul(t, ch[j]);
+                        if (i >= p.n) {
+                            t.x = 0;
+                            t.y = 0;
+                        }
+                        lb[swz(i)] = t;
+                    } else {
+                        lb[swz(pos[j])] = t;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// Rows: lines are contiguous in memory (elemStride 1).  LDS layout [line][swz(e)].
+template <typename T, int MODE>
+__global__ void __launch_bounds__(NF_FFT_MAXTHREADS) k_fft_rows(nf::LineArgs<T> a) {
     extern __shared__ __align__(16) unsigned char nf_smem[];
     cpx<T>* buf = (cpx<T>*)nf_smem;
     const nf::LinePlan<T>& p = a.plan;
-    const int n = p.n, m = p.m, lpw = a.linesPerWG;
-    constexpr bool lineFast = LINEFAST;
-    const int line0 = blockIdx.x * lpw;
-    const int nl = min(lpw, a.nLines - line0);
-    const long long inBase = (long long)blockIdx.y * a.inBatchStride;
-    const long long outBase = (long long)blockIdx.y * a.outBatchStride;
+    Geo G;
+    G.line0 = blockIdx.x * a.linesPerWG;
+    G.nl = min(a.linesPerWG, a.nLines - G.line0);
+    G.TB = a.tb;
+    G.TL = blockDim.x / a.tb;
+    G.tl = threadIdx.x / a.tb;
+    G.tb = threadIdx.x - G.tl * a.tb;
+    G.inBase = (long long)blockIdx.y * a.inBatchStride;
+    G.outBase = (long long)blockIdx.y * a.outBatchStride;
 
-    // ---- load (digit-reversed placement unless Bluestein) ----
-    const int totalIn = (p.bluestein ? m : n) * nl;
-    for (int idx = threadIdx.x; idx < totalIn; idx += blockDim.x) {
-        int i, c;
-        if (lineFast) {
-            c = idx % nl;
-            i = idx / nl;
-        } else {
-            i = idx % (p.bluestein ? m : n);
-            c = idx / (p.bluestein ? m : n);
-        }
-        cpx<T> v;
-        if (i < n) {
-            long long off = inBase + (long long)(line0 + c) * a.inLineStride + (long long)i * a.inElemStride;
-            v = load_elem<T>(a, off, line0 + c, i);
-            if (p.bluestein) v = cmul(v, p.chirp[i]);
-        } else {
-            v.x = 0;
-            v.y = 0;
-        }
-        int pos = p.bluestein ? i : digit_reverse<T>(i, p);
-        buf[lineFast ? pos * lpw + c : c * m + pos] = v;
+    // global -> LDS in batches of NF_STAGE_IN loads per thread, all issued before the first LDS store: the copy is
+    // latency-bound otherwise (one HBM round trip per element and thread)
+    const int it = a.inType == 0 ? 0 : a.inType + (a.apodLine != nullptr ? 2 : 0);
+    switch (it) {
+        case 0: stage_in_rows<T, 0, MODE == 2>(buf, a, G); break;
+        case 1: stage_in_rows<T, 1, MODE == 2>(buf, a, G); break;
+        case 2: stage_in_rows<T, 2, MODE == 2>(buf, a, G); break;
+        case 3: stage_in_rows<T, 3, MODE == 2>(buf, a, G); break;
+        default: stage_in_rows<T, 4, MODE == 2>(buf, a, G); break;
     }
     __syncthreads();
+    if (MODE == 2) bluestein_middle<T, false, MODE>(buf, a, G);
+    for (int s = 0; s < p.nst; ++s) fft_stage_dispatch<T, false, MODE>(buf, a, s, false, false, s == p.nst - 1, G);
+}
 
-    if (!p.bluestein) {
-        fft_dit<T>(buf, p, nl, lpw, lineFast);
-    } else {
-        fft_dif<T>(buf, p, nl, lpw, lineFast);
-        const int tot = m * nl;
-        for (int idx = threadIdx.x; idx < tot; idx += blockDim.x) {
-            int i, c;
-            if (lineFast) {
-                c = idx % nl;
-                i = idx / nl;
-            } else {
-                i = idx % m;
-                c = idx / m;
+// Columns: a tile of TL = linesPerWG adjacent lines (elemStride = row pitch, lineStride 1).  LDS layout [swz(e)][line].
+template <typename T, int MODE>
+__global__ void __launch_bounds__(NF_FFT_MAXTHREADS) k_fft_cols(nf::LineArgs<T> a) {
+    extern __shared__ __align__(16) unsigned char nf_smem[];
+    cpx<T>* buf = (cpx<T>*)nf_smem;
+    const nf::LinePlan<T>& p = a.plan;
+    // blocks b, b + 8, b + 16 ... share an XCD (round-robin dispatch): give them neighbouring tiles
+    const int per = (a.nTiles + 7) >> 3;
+    const int tile = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (tile >= a.nTiles) return;
+    Geo G;
+    G.TL = a.linesPerWG;
+    G.line0 = tile * G.TL;
+    const int nvalid = min(G.TL, a.nLines - G.line0);
+    G.tl = threadIdx.x & (G.TL - 1);
+    G.tb = threadIdx.x / G.TL;
+    G.TB = blockDim.x / G.TL;
+    // a lane whose column lies beyond the map takes no part (nl = 0 empties its line loops); barriers stay uniform
+    G.nl = G.tl < nvalid ? G.tl + 1 : 0;
+    G.inBase = (long long)blockIdx.y * a.inBatchStride;
+    G.outBase = (long long)blockIdx.y * a.outBatchStride;
+
+    if (MODE == 2) {
+        if (G.nl > 0) {
+            for (int i = G.tb; i < p.m; i += G.TB) {
+                cpx<T> v;
+                if (i < p.n) {
+                    const long long off = G.inBase + (long long)(G.line0 + G.tl) * a.inLineStride + (long long)i * a.inElemStride;
+                    v = cmul(load_elem<T, 0>(a, off, 1.0, i), p.chirp[i]);
+                } else {
+                    v.x = 0;
+                    v.y = 0;
+                }
+                buf[swz(i) * G.TL + G.tl] = v;
             }
-            int at = lineFast ? i * lpw + c : c * m + i;
-            buf[at] = cconj(cmul(buf[at], p.chirpFp[i]));
         }
         __syncthreads();
-        fft_dit<T>(buf, p, nl, lpw, lineFast);
-    }
-
-    // ---- store ----
-    const int totalOut = n * nl;
-    for (int idx = threadIdx.x; idx < totalOut; idx += blockDim.x) {
-        int i, c;
-        if (lineFast) {
-            c = idx % nl;
-            i = idx / nl;
-        } else {
-            i = idx % n;
-            c = idx / n;
-        }
-        cpx<T> v = buf[lineFast ? i * lpw + c : c * m + i];
-        if (p.bluestein) v = cmul(cconj(v), p.chirp[i]);
-        if (a.conjOut) v.y = -v.y;
-        if (a.scaleDiv) {
-            v.x = (T)(v.x / (T)a.scale);
-            v.y = (T)(v.y / (T)a.scale);
-        }
-        long long off = outBase + (long long)(line0 + c) * a.outLineStride + (long long)i * a.outElemStride;
-        if (a.outType == 0)
-            ((cpx<T>*)a.out)[off] = v;
-        else if (a.outType == 1)
-            ((double*)a.out)[off] = (double)v.x;
-        else
-            ((float*)a.out)[off] = (float)v.x;
+        bluestein_middle<T, true, MODE>(buf, a, G);
+        for (int s = 0; s < p.nst; ++s) fft_stage_dispatch<T, true, MODE>(buf, a, s, false, false, s == p.nst - 1, G);
+    } else {
+        for (int s = 0; s < p.nst; ++s) fft_stage_dispatch<T, true, MODE>(buf, a, s, false, s == 0, s == p.nst - 1, G);
     }
 }
 
@@ -417,30 +517,83 @@ static void host_fft(std::vector<long double>& re, std::vector<long double>& im)
     }
 }
 
+template <typename V>
+static int upload_vec(const std::vector<V>& v, const V** dst) {
+    void* d = nullptr;
+    NF_HIP(hipMalloc(&d, v.size() * sizeof(V)));
+    NF_HIP(hipMemcpy(d, v.data(), v.size() * sizeof(V), hipMemcpyHostToDevice));
+    *dst = (const V*)d;
+    return NF_OK;
+}
+
 template <typename T>
 int make_line_plan(int n, LinePlan<T>* p) {
     memset(p, 0, sizeof(*p));
     p->n = n;
     const long double pi = 3.141592653589793238462643383279502884L;
-    if (factorize(n, p->fac, &p->nfac)) {
+    int fac[NF_MAXFAC], nfac = 0;
+    if (factorize(n, fac, &nfac)) {
         p->m = n;
         p->bluestein = 0;
     } else {
         p->bluestein = 1;
         p->m = next_smooth(2 * n - 1);
-        if (!factorize(p->m, p->fac, &p->nfac)) {
+        if (!factorize(p->m, fac, &nfac)) {
             nf_set_error("internal: smooth length failed to factorize");
             return NF_ERR_SIZE;
         }
     }
     const int m = p->m;
-    std::vector<cpx<T>> tw(m);
-    for (int k = 0; k < m; ++k) {
-        long double ang = -2.0L * pi * (long double)k / (long double)m;
-        tw[k].x = (T)cosl(ang);
-        tw[k].y = (T)sinl(ang);
+    if (m >= 32768) {
+        nf_set_error("FFT line too long for the single-pass LDS transform");
+        return NF_ERR_SIZE;
     }
-    int rc = upload<T>(tw, &p->tw);
+    p->mPad = (m + 31) & ~31;
+    p->nst = nfac;
+    // stage tables
+    std::vector<cpx<T>> stw;
+    int L = 1;
+    for (int s = 0; s < nfac; ++s) {
+        StageInfo& st = p->st[s];
+        st.R = fac[s];
+        st.L = L;
+        st.magic = L > 1 ? (unsigned)((0x100000000ULL + (unsigned long long)L - 1ULL) / (unsigned long long)L) : 0u;
+        st.twOff = (int)stw.size();
+        if (L > 1) {
+            const long long span = (long long)L * st.R;
+            for (int k = 1; k < st.R; ++k)
+                for (int q = 0; q < L; ++q) {
+                    long double ang = -2.0L * pi * (long double)(((long long)q * k) % span) / (long double)span;
+                    cpx<T> w;
+                    w.x = (T)cosl(ang);
+                    w.y = (T)sinl(ang);
+                    stw.push_back(w);
+                }
+        }
+        st.rootOff = (int)stw.size();
+        if (st.R > 4 && st.R != 8) {
+            for (int j = 0; j < st.R; ++j) {
+                long double ang = -2.0L * pi * (long double)j / (long double)st.R;
+                cpx<T> w;
+                w.x = (T)cosl(ang);
+                w.y = (T)sinl(ang);
+                stw.push_back(w);
+            }
+        }
+        L *= st.R;
+    }
+    if (stw.empty()) stw.resize(1);
+    int rc = upload_vec<cpx<T>>(stw, &p->stw);
+    if (rc) return rc;
+    std::vector<unsigned short> rev(m), src(m);
+    for (int i = 0; i < m; ++i) {
+        int pos = host_digit_reverse(i, m, fac, nfac);
+        rev[i] = (unsigned short)pos;
+        src[pos] = (unsigned short)i;
+    }
+    rc = upload_vec<unsigned short>(rev, &p->rev);
+    if (rc) return rc;
+    rc = upload_vec<unsigned short>(src, &p->src);
     if (rc) return rc;
     if (p->bluestein) {
         std::vector<cpx<T>> chirp(n);
@@ -460,13 +613,13 @@ int make_line_plan(int n, LinePlan<T>* p) {
         host_fft(bre, bim);
         std::vector<cpx<T>> cf(m);
         for (int f = 0; f < m; ++f) {
-            int pos = host_digit_reverse(f, m, p->fac, p->nfac);
+            int pos = rev[f];
             cf[pos].x = (T)(bre[f] / (long double)m);
             cf[pos].y = (T)(bim[f] / (long double)m);
         }
-        rc = upload<T>(chirp, &p->chirp);
+        rc = upload_vec<cpx<T>>(chirp, &p->chirp);
         if (rc) return rc;
-        rc = upload<T>(cf, &p->chirpFp);
+        rc = upload_vec<cpx<T>>(cf, &p->chirpFp);
         if (rc) return rc;
     }
     return NF_OK;
@@ -474,7 +627,9 @@ int make_line_plan(int n, LinePlan<T>* p) {
 
 template <typename T>
 void free_line_plan(LinePlan<T>* p) {
-    if (p->tw) (void)hipFree((void*)p->tw);
+    if (p->stw) (void)hipFree((void*)p->stw);
+    if (p->rev) (void)hipFree((void*)p->rev);
+    if (p->src) (void)hipFree((void*)p->src);
     if (p->chirp) (void)hipFree((void*)p->chirp);
     if (p->chirpFp) (void)hipFree((void*)p->chirpFp);
     memset(p, 0, sizeof(*p));
@@ -482,33 +637,63 @@ void free_line_plan(LinePlan<T>* p) {
 
 static const int kMaxLds = 160 * 1024;
 
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    if (!v || !*v) return dflt;
+    return atoi(v);
+}
+
 template <typename T>
-int launch_lines(const LineArgs<T>& a, int batch, int threads, hipStream_t stream) {
-    size_t lds = (size_t)a.plan.m * a.linesPerWG * sizeof(cpx<T>);
+int launch_lines(const LineArgs<T>& a, bool cols, int batch, int threads, hipStream_t stream) {
+    size_t lds = (size_t)a.plan.mPad * a.linesPerWG * sizeof(cpx<T>);
     if (lds > (size_t)kMaxLds) {
         nf_set_error("FFT line of this length does not fit in LDS");
         return NF_ERR_SIZE;
     }
+    if (cols && a.inType != 0) {
+        nf_set_error("internal: the column pass takes complex input");
+        return NF_ERR_ARG;
+    }
     static bool attrSet[2] = {false, false};
     int which = sizeof(T) == 8 ? 1 : 0;
     if (!attrSet[which]) {
-        NF_HIP(hipFuncSetAttribute((const void*)k_fft_lines<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
-        NF_HIP(hipFuncSetAttribute((const void*)k_fft_lines<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
+        NF_HIP(hipFuncSetAttribute((const void*)k_fft_rows<T, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
+        NF_HIP(hipFuncSetAttribute((const void*)k_fft_cols<T, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
+        NF_HIP(hipFuncSetAttribute((const void*)k_fft_rows<T, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
+        NF_HIP(hipFuncSetAttribute((const void*)k_fft_cols<T, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
+        NF_HIP(hipFuncSetAttribute((const void*)k_fft_rows<T, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
+        NF_HIP(hipFuncSetAttribute((const void*)k_fft_cols<T, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
         attrSet[which] = true;
     }
     const double npixTotal = (double)a.nLines * a.plan.n * batch;
     const double inB = a.inType == 0 ? sizeof(cpx<T>) : (a.inType == 1 ? 8.0 : 4.0);
     const double outB = a.outType == 0 ? sizeof(cpx<T>) : (a.outType == 1 ? 8.0 : 4.0);
-    const int tag = sizeof(T) == 8 ? (a.lineFast ? PT_FFT_COLS_F64 : PT_FFT_ROWS_F64) : (a.lineFast ? PT_FFT_COLS_F32 : PT_FFT_ROWS_F32);
+    const int tag = sizeof(T) == 8 ? (cols ? PT_FFT_COLS_F64 : PT_FFT_ROWS_F64) : (cols ? PT_FFT_COLS_F32 : PT_FFT_ROWS_F32);
     ProfScope ps(tag, stream, npixTotal * (inB + outB));
-    dim3 grid(nf_div_up(a.nLines, a.linesPerWG), batch);
-    if (a.lineFast)
-        hipLaunchKernelGGL((k_fft_lines<T, true>), grid, dim3(threads), lds, stream, a);
-    else
-        hipLaunchKernelGGL((k_fft_lines<T, false>), grid, dim3(threads), lds, stream, a);
+    int mode = a.plan.bluestein ? 2 : 0;
+    for (int s = 0; s < a.plan.nst; ++s)
+        if (a.plan.st[s].R > 8) mode = 1;
+    if (a.plan.bluestein && mode == 1) {
+        nf_set_error("internal: Bluestein length with a radix above 8");
+        return NF_ERR_SIZE;
+    }
+    dim3 grid = cols ? dim3(((a.nTiles + 7) / 8) * 8, batch) : dim3(nf_div_up(a.nLines, a.linesPerWG), batch);
+#define NF_LAUNCH(K, M) hipLaunchKernelGGL((K<T, M>), grid, dim3(threads), lds, stream, a)
+    if (cols) {
+        if (mode == 0) NF_LAUNCH(k_fft_cols, 0);
+        else if (mode == 1) NF_LAUNCH(k_fft_cols, 1);
+        else NF_LAUNCH(k_fft_cols, 2);
+    } else {
+        if (mode == 0) NF_LAUNCH(k_fft_rows, 0);
+        else if (mode == 1) NF_LAUNCH(k_fft_rows, 1);
+        else NF_LAUNCH(k_fft_rows, 2);
+    }
+#undef NF_LAUNCH
     NF_CHECK_LAUNCH("k_fft_lines");
     return NF_OK;
 }
+
+static int round_up64(int v) { return (v + 63) & ~63; }
 
 template <typename T>
 int Plan2D<T>::init(int H_, int W_) {
@@ -519,27 +704,38 @@ int Plan2D<T>::init(int H_, int W_) {
     rc = make_line_plan<T>(H, &col);
     if (rc) return rc;
     const size_t es = sizeof(cpx<T>);
-    // rows: bundle enough rows for ~32 KB of LDS, at least one
-    size_t rowBytes = (size_t)row.m * es;
+    // ---- rows: bundle rows up to ~40 KB of LDS (>= 3 workgroups per CU), at least one ----
+    const size_t rowBytes = (size_t)row.mPad * es;
     if (rowBytes > (size_t)kMaxLds) {
         nf_set_error("row length too large for the single-pass LDS FFT");
         return NF_ERR_SIZE;
     }
-    rowsPerWG = (int)std::max<size_t>(1, std::min<size_t>(8, (32 * 1024) / rowBytes));
-    // columns: as many adjacent columns as fit in ~64 KB (8 * 16 B = 128 B contiguous when possible)
-    size_t colBytes = (size_t)col.m * es;
+    const size_t rowBudget = (size_t)env_int("NF_FFT_ROW_LDS_KB", 40) * 1024;
+    rowsPerWG = (int)std::max<size_t>(1, std::min<size_t>(16, rowBudget / rowBytes));
+    if (env_int("NF_FFT_ROWS_PER_WG", 0) > 0) rowsPerWG = env_int("NF_FFT_ROWS_PER_WG", 0);
+    rowsPerWG = std::min<int>(rowsPerWG, (int)((size_t)kMaxLds / rowBytes));
+    tbRow = std::max(64, std::min(256, round_up64(row.m / 8)));
+    if (env_int("NF_FFT_ROW_TB", 0) > 0) tbRow = env_int("NF_FFT_ROW_TB", 0);
+    int tl = std::max(1, std::min(rowsPerWG, 256 / tbRow));
+    threadsRow = tbRow * tl;
+    // ---- columns: a power-of-two number of adjacent columns; 128-byte runs when they fit ~64 KB, else what fits ----
+    const size_t colBytes = (size_t)col.mPad * es;
     if (colBytes > (size_t)kMaxLds) {
         nf_set_error("column length too large for the single-pass LDS FFT");
         return NF_ERR_SIZE;
     }
-    size_t want = 128 / es;  // columns for a 128-byte run
-    size_t fit = (size_t)kMaxLds / colBytes;
-    size_t target = std::max<size_t>(1, (64 * 1024) / colBytes);
-    colsPerWG = (int)std::max<size_t>(1, std::min<size_t>(fit, std::max<size_t>(std::min<size_t>(want, fit), std::min<size_t>(target, 16))));
-    threadsRow = (row.m * rowsPerWG >= 2048) ? 256 : 128;
-    if ((size_t)row.m * rowsPerWG * es > 48 * 1024) threadsRow = 512;
-    threadsCol = (col.m * colsPerWG >= 2048) ? 256 : 128;
-    if ((size_t)col.m * colsPerWG * es > 48 * 1024) threadsCol = 512;
+    const size_t colBudget = (size_t)env_int("NF_FFT_COL_LDS_KB", 64) * 1024;
+    int c = 1;
+    while (c < 32 && (size_t)(2 * c) * colBytes <= colBudget) c *= 2;
+    // narrow tiles waste HBM bursts: below 64-byte runs take the whole LDS (one workgroup per CU) if that widens the tile
+    while ((size_t)c * es < 64 && (size_t)(2 * c) * colBytes <= (size_t)kMaxLds) c *= 2;
+    if (env_int("NF_FFT_COLS_PER_WG", 0) > 0) c = env_int("NF_FFT_COLS_PER_WG", 0);
+    while (c > 1 && (size_t)c * colBytes > (size_t)kMaxLds) c /= 2;
+    colsPerWG = c;
+    threadsCol = 256;
+    if ((size_t)c * colBytes > 80 * 1024) threadsCol = 512;
+    if (env_int("NF_FFT_COL_THREADS", 0) > 0) threadsCol = env_int("NF_FFT_COL_THREADS", 0);
+    threadsCol = std::max(threadsCol, colsPerWG);
     return NF_OK;
 }
 
@@ -549,51 +745,63 @@ void Plan2D<T>::destroy() {
     free_line_plan<T>(&col);
 }
 
+template <typename T>
+static LineArgs<T> row_args(const Plan2D<T>& P, const void* in, void* out, int inType, int outType) {
+    LineArgs<T> a;
+    memset(&a, 0, sizeof(a));
+    a.plan = P.row;
+    a.in = in;
+    a.out = out;
+    a.inType = inType;
+    a.outType = outType;
+    a.inElemStride = 1;
+    a.inLineStride = P.W;
+    a.inBatchStride = (long long)P.H * P.W;
+    a.outElemStride = 1;
+    a.outLineStride = P.W;
+    a.outBatchStride = (long long)P.H * P.W;
+    a.conjInSign = a.conjOutSign = a.scale = 1.0;
+    a.nLines = P.H;
+    a.linesPerWG = P.rowsPerWG;
+    a.tb = P.tbRow;
+    return a;
+}
+
+template <typename T>
+static LineArgs<T> col_args(const Plan2D<T>& P, const void* in, void* out) {
+    LineArgs<T> c;
+    memset(&c, 0, sizeof(c));
+    c.plan = P.col;
+    c.in = in;
+    c.out = out;
+    c.inType = 0;
+    c.outType = 0;
+    c.inElemStride = P.W;
+    c.inLineStride = 1;
+    c.inBatchStride = (long long)P.H * P.W;
+    c.outElemStride = P.W;
+    c.outLineStride = 1;
+    c.outBatchStride = (long long)P.H * P.W;
+    c.conjInSign = c.conjOutSign = c.scale = 1.0;
+    c.nLines = P.W;
+    c.linesPerWG = P.colsPerWG;
+    c.nTiles = nf_div_up(P.W, P.colsPerWG);
+    return c;
+}
+
 // forward: in (real f32/f64 or complex<T>) -> out complex<T> [batch][H][W]; optional apodisation of real input;
 // result divided by `scale` if scaleDiv (enmap.fft: sqrt(H*W)).
 template <typename T>
 int Plan2D<T>::forward(const void* in, int inType, void* out, int batch, const double* apodY, const double* apodX,
                        int scaleDiv, double scale, hipStream_t stream) {
-    LineArgs<T> a;
-    memset(&a, 0, sizeof(a));
-    a.plan = row;
-    a.in = in;
-    a.out = out;
-    a.inType = inType;
-    a.outType = 0;
-    a.inElemStride = 1;
-    a.inLineStride = W;
-    a.inBatchStride = (long long)H * W;
-    a.outElemStride = 1;
-    a.outLineStride = W;
-    a.outBatchStride = (long long)H * W;
-    a.nLines = H;
-    a.linesPerWG = rowsPerWG;
-    a.lineFast = 0;
-    a.lineIsRow = 1;
+    LineArgs<T> a = row_args<T>(*this, in, out, inType, 0);
     a.apodLine = apodY;
     a.apodElem = apodX;
-    int rc = launch_lines<T>(a, batch, threadsRow, stream);
+    int rc = launch_lines<T>(a, false, batch, threadsRow, stream);
     if (rc) return rc;
-    LineArgs<T> c;
-    memset(&c, 0, sizeof(c));
-    c.plan = col;
-    c.in = out;
-    c.out = out;
-    c.inType = 0;
-    c.outType = 0;
-    c.inElemStride = W;
-    c.inLineStride = 1;
-    c.inBatchStride = (long long)H * W;
-    c.outElemStride = W;
-    c.outLineStride = 1;
-    c.outBatchStride = (long long)H * W;
-    c.nLines = W;
-    c.linesPerWG = colsPerWG;
-    c.lineFast = 1;
-    c.scaleDiv = scaleDiv;
-    c.scale = scale;
-    return launch_lines<T>(c, batch, threadsCol, stream);
+    LineArgs<T> c = col_args<T>(*this, out, out);
+    if (scaleDiv) c.scale = 1.0 / scale;
+    return launch_lines<T>(c, true, batch, threadsCol, stream);
 }
 
 // inverse (unnormalised backward sum, then optional division by `scale`): complex<T> in -> work (complex, same
@@ -601,46 +809,14 @@ int Plan2D<T>::forward(const void* in, int inType, void* out, int batch, const d
 template <typename T>
 int Plan2D<T>::inverse(const void* in, void* work, void* out, int outType, int batch, int scaleDiv, double scale,
                        hipStream_t stream) {
-    LineArgs<T> c;
-    memset(&c, 0, sizeof(c));
-    c.plan = col;
-    c.in = in;
-    c.out = work;
-    c.inType = 0;
-    c.outType = 0;
-    c.inElemStride = W;
-    c.inLineStride = 1;
-    c.inBatchStride = (long long)H * W;
-    c.outElemStride = W;
-    c.outLineStride = 1;
-    c.outBatchStride = (long long)H * W;
-    c.nLines = W;
-    c.linesPerWG = colsPerWG;
-    c.lineFast = 1;
-    c.conjIn = 1;  // conj(FFT(conj x)): the conj between the two passes cancels, so only ends matter
-    int rc = launch_lines<T>(c, batch, threadsCol, stream);
+    LineArgs<T> c = col_args<T>(*this, in, work);
+    c.conjInSign = -1.0;  // conj(FFT(conj x)): the conj between the two passes cancels, so only the ends matter
+    int rc = launch_lines<T>(c, true, batch, threadsCol, stream);
     if (rc) return rc;
-    LineArgs<T> a;
-    memset(&a, 0, sizeof(a));
-    a.plan = row;
-    a.in = work;
-    a.out = out;
-    a.inType = 0;
-    a.outType = outType;
-    a.inElemStride = 1;
-    a.inLineStride = W;
-    a.inBatchStride = (long long)H * W;
-    a.outElemStride = 1;
-    a.outLineStride = W;
-    a.outBatchStride = (long long)H * W;
-    a.nLines = H;
-    a.linesPerWG = rowsPerWG;
-    a.lineFast = 0;
-    a.lineIsRow = 1;
-    a.conjOut = 1;
-    a.scaleDiv = scaleDiv;
-    a.scale = scale;
-    return launch_lines<T>(a, batch, threadsRow, stream);
+    LineArgs<T> a = row_args<T>(*this, work, out, 0, outType);
+    a.conjOutSign = -1.0;
+    if (scaleDiv) a.scale = 1.0 / scale;
+    return launch_lines<T>(a, false, batch, threadsRow, stream);
 }
 
 template struct Plan2D<float>;

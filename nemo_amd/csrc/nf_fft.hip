@@ -35,7 +35,7 @@
 #include <cstring>
 #include <vector>
 
-#define NF_FFT_MAXTHREADS 512
+#define NF_FFT_MAXTHREADS 1024
 #define NF_STAGE_IN 8
 
 // ------------------------------------------------------------------------------------------------------
@@ -150,21 +150,22 @@ struct Geo {
     int tb, TB;           // butterfly lane and stride
     int tl, TL;           // rows kernel: line lane and stride;  columns kernel: tl = column within the tile, TL = tile width
     int line0;            // first global line of the workgroup
-    long long inBase, outBase;
+    const void* inP;      // a.in / a.out advanced to this workgroup's plane (offsets inside a plane fit 32 bits)
+    void* outP;
 };
 
 // IT: 0 complex<T>, 1 real float64, 2 real float32, 3 / 4 the same two with apodisation (rows kernel only: `fl` is the
 // axis -2 profile value of the row, apodElem the axis -1 profile).  OT: 0 complex<T>, 1 real float64, 2 real float32.
 // Compile-time so that the per-element code has no branches.
 template <typename T, int IT>
-__device__ __forceinline__ cpx<T> load_elem(const nf::LineArgs<T>& a, long long off, double fl, int i) {
+__device__ __forceinline__ cpx<T> load_elem(const nf::LineArgs<T>& a, const void* inP, unsigned off, double fl, int i) {
     cpx<T> v;
     if (IT == 0) {
-        v = ((const cpx<T>*)a.in)[off];
+        v = ((const cpx<T>*)inP)[off];
         v.y *= (T)a.conjInSign;
     } else {
         constexpr bool F32 = (IT == 2 || IT == 4);
-        double x = F32 ? (double)((const float*)a.in)[off] : ((const double*)a.in)[off];
+        double x = F32 ? (double)((const float*)inP)[off] : ((const double*)inP)[off];
         if (IT >= 3) {
             // enmap.apod: axis -2 profile first, then axis -1, each multiply rounded to the map dtype
             const double fe = a.apodElem[i];
@@ -183,7 +184,7 @@ __device__ __forceinline__ cpx<T> load_elem(const nf::LineArgs<T>& a, long long 
 }
 
 template <typename T, int OT, bool BLUE>
-__device__ __forceinline__ void store_elem(const nf::LineArgs<T>& a, long long off, int i, cpx<T> v) {
+__device__ __forceinline__ void store_elem(const nf::LineArgs<T>& a, void* outP, unsigned off, int i, cpx<T> v) {
     const nf::LinePlan<T>& p = a.plan;
     if (BLUE) v = cmul(cconj(v), p.chirp[i]);
     // multiplication by the rounded reciprocal of sqrt(H*W): within 1 ulp of the reference's division, exact when
@@ -192,11 +193,11 @@ __device__ __forceinline__ void store_elem(const nf::LineArgs<T>& a, long long o
     if (OT == 0) {
         v.x *= r;
         v.y *= r * (T)a.conjOutSign;
-        ((cpx<T>*)a.out)[off] = v;
+        ((cpx<T>*)outP)[off] = v;
     } else if (OT == 1) {
-        ((double*)a.out)[off] = (double)(v.x * r);
+        ((double*)outP)[off] = (double)(v.x * r);
     } else {
-        ((float*)a.out)[off] = (float)(v.x * r);
+        ((float*)outP)[off] = (float)(v.x * r);
     }
 }
 
@@ -239,10 +240,10 @@ __device__ __forceinline__ void fft_stage(cpx<T>* __restrict__ buf, const nf::Li
             cpx<T>* __restrict__ lb = buf + (unsigned)line * lineMul;
             cpx<T> x[R];
             if (srcG) {
-                const long long lo = G.inBase + (long long)(G.line0 + line) * a.inLineStride;
+                const unsigned lo = (unsigned)(G.line0 + line) * (unsigned)a.inLineStride;
 #pragma unroll
                 for (int k = 0; k < R; ++k)
-                    x[k] = load_elem<T, 0>(a, lo + (long long)idx[k] * a.inElemStride, 1.0, (int)idx[k]);
+                    x[k] = load_elem<T, 0>(a, G.inP, lo + idx[k] * (unsigned)a.inElemStride, 1.0, (int)idx[k]);
             } else {
 #pragma unroll
                 for (int k = 0; k < R; ++k) x[k] = lb[idx[k]];
@@ -257,11 +258,11 @@ __device__ __forceinline__ void fft_stage(cpx<T>* __restrict__ buf, const nf::Li
                 for (int k = 1; k < R; ++k) x[k] = cmul(x[k], w[k - 1]);
             }
             if (dstG) {
-                const long long lo = G.outBase + (long long)(G.line0 + line) * a.outLineStride;
+                const unsigned lo = (unsigned)(G.line0 + line) * (unsigned)a.outLineStride;
 #define NF_STORE_ALL(OT)                                                                                          \
     _Pragma("unroll") for (int k = 0; k < R; ++k) {                                                               \
         const unsigned e = base + (unsigned)k * L;                                                                \
-        if (!BLUE || e < (unsigned)p.n) store_elem<T, OT, BLUE>(a, lo + (long long)e * a.outElemStride, (int)e, x[k]); \
+        if (!BLUE || e < (unsigned)p.n) store_elem<T, OT, BLUE>(a, G.outP, lo + e * (unsigned)a.outElemStride, (int)e, x[k]); \
     }
                 if (a.outType == 0) {
                     NF_STORE_ALL(0)
@@ -325,7 +326,7 @@ __device__ __forceinline__ void stage_in_rows(cpx<T>* __restrict__ buf, const nf
     const nf::LinePlan<T>& p = a.plan;
     const int nIn = BLUE ? p.m : p.n;
     for (int line = G.tl; line < G.nl; line += G.TL) {
-        const long long lineOff = G.inBase + (long long)(G.line0 + line) * a.inLineStride;
+        const unsigned lineOff = (unsigned)(G.line0 + line) * (unsigned)a.inLineStride;
         cpx<T>* __restrict__ lb = buf + line * p.mPad;
         const double fl = IT >= 3 ? a.apodLine[G.line0 + line] : 1.0;
         for (int i0 = G.tb; i0 < nIn; i0 += NF_STAGE_IN * G.TB) {
@@ -335,7 +336,7 @@ __device__ __forceinline__ void stage_in_rows(cpx<T>* __restrict__ buf, const nf
 #pragma unroll
             for (int j = 0; j < NF_STAGE_IN; ++j) {
                 const int i = min(i0 + j * G.TB, p.n - 1);
-                v[j] = load_elem<T, IT>(a, lineOff + (long long)i * a.inElemStride, fl, i);
+                v[j] = load_elem<T, IT>(a, G.inP, lineOff + (unsigned)i * (unsigned)a.inElemStride, fl, i);
                 if (BLUE)
                     ch[j] = p.chirp[i];
                 else
@@ -375,8 +376,12 @@ __global__ void __launch_bounds__(NF_FFT_MAXTHREADS) k_fft_rows(nf::LineArgs<T> 
     G.TL = blockDim.x / a.tb;
     G.tl = threadIdx.x / a.tb;
     G.tb = threadIdx.x - G.tl * a.tb;
-    G.inBase = (long long)blockIdx.y * a.inBatchStride;
-    G.outBase = (long long)blockIdx.y * a.outBatchStride;
+    {
+        const size_t inEs = a.inType == 0 ? sizeof(cpx<T>) : (a.inType == 1 ? 8 : 4);
+        const size_t outEs = a.outType == 0 ? sizeof(cpx<T>) : (a.outType == 1 ? 8 : 4);
+        G.inP = (const char*)a.in + (size_t)blockIdx.y * (size_t)a.inBatchStride * inEs;
+        G.outP = (char*)a.out + (size_t)blockIdx.y * (size_t)a.outBatchStride * outEs;
+    }
 
     // global -> LDS in batches of NF_STAGE_IN loads per thread, all issued before the first LDS store: the copy is
     // latency-bound otherwise (one HBM round trip per element and thread)
@@ -412,16 +417,20 @@ __global__ void __launch_bounds__(NF_FFT_MAXTHREADS) k_fft_cols(nf::LineArgs<T> 
     G.TB = blockDim.x / G.TL;
     // a lane whose column lies beyond the map takes no part (nl = 0 empties its line loops); barriers stay uniform
     G.nl = G.tl < nvalid ? G.tl + 1 : 0;
-    G.inBase = (long long)blockIdx.y * a.inBatchStride;
-    G.outBase = (long long)blockIdx.y * a.outBatchStride;
+    {
+        const size_t inEs = a.inType == 0 ? sizeof(cpx<T>) : (a.inType == 1 ? 8 : 4);
+        const size_t outEs = a.outType == 0 ? sizeof(cpx<T>) : (a.outType == 1 ? 8 : 4);
+        G.inP = (const char*)a.in + (size_t)blockIdx.y * (size_t)a.inBatchStride * inEs;
+        G.outP = (char*)a.out + (size_t)blockIdx.y * (size_t)a.outBatchStride * outEs;
+    }
 
     if (MODE == 2) {
         if (G.nl > 0) {
             for (int i = G.tb; i < p.m; i += G.TB) {
                 cpx<T> v;
                 if (i < p.n) {
-                    const long long off = G.inBase + (long long)(G.line0 + G.tl) * a.inLineStride + (long long)i * a.inElemStride;
-                    v = cmul(load_elem<T, 0>(a, off, 1.0, i), p.chirp[i]);
+                    const unsigned off = (unsigned)(G.line0 + G.tl) * (unsigned)a.inLineStride + (unsigned)i * (unsigned)a.inElemStride;
+                    v = cmul(load_elem<T, 0>(a, G.inP, off, 1.0, i), p.chirp[i]);
                 } else {
                     v.x = 0;
                     v.y = 0;
@@ -650,6 +659,10 @@ int launch_lines(const LineArgs<T>& a, bool cols, int batch, int threads, hipStr
         nf_set_error("FFT line of this length does not fit in LDS");
         return NF_ERR_SIZE;
     }
+    if ((double)a.nLines * a.plan.n >= 2147483648.0) {
+        nf_set_error("map plane too large (offsets inside a plane are 32-bit)");
+        return NF_ERR_SIZE;
+    }
     if (cols && a.inType != 0) {
         nf_set_error("internal: the column pass takes complex input");
         return NF_ERR_ARG;
@@ -704,36 +717,38 @@ int Plan2D<T>::init(int H_, int W_) {
     rc = make_line_plan<T>(H, &col);
     if (rc) return rc;
     const size_t es = sizeof(cpx<T>);
-    // ---- rows: bundle rows up to ~40 KB of LDS (>= 3 workgroups per CU), at least one ----
+    // ---- rows: bundle rows up to ~32 KB of LDS (several workgroups per CU hide each other's latencies), at least one ----
     const size_t rowBytes = (size_t)row.mPad * es;
     if (rowBytes > (size_t)kMaxLds) {
         nf_set_error("row length too large for the single-pass LDS FFT");
         return NF_ERR_SIZE;
     }
-    const size_t rowBudget = (size_t)env_int("NF_FFT_ROW_LDS_KB", 40) * 1024;
+    const size_t rowBudget = (size_t)env_int("NF_FFT_ROW_LDS_KB", 32) * 1024;
     rowsPerWG = (int)std::max<size_t>(1, std::min<size_t>(16, rowBudget / rowBytes));
     if (env_int("NF_FFT_ROWS_PER_WG", 0) > 0) rowsPerWG = env_int("NF_FFT_ROWS_PER_WG", 0);
     rowsPerWG = std::min<int>(rowsPerWG, (int)((size_t)kMaxLds / rowBytes));
     tbRow = std::max(64, std::min(256, round_up64(row.m / 8)));
+    if (rowBytes > 40 * 1024 && row.m / 8 >= 512) tbRow = 512;   // at most two workgroups fit a CU: make them wider
     if (env_int("NF_FFT_ROW_TB", 0) > 0) tbRow = env_int("NF_FFT_ROW_TB", 0);
-    int tl = std::max(1, std::min(rowsPerWG, 256 / tbRow));
+    int tl = std::max(1, std::min(rowsPerWG, std::max(1, 256 / tbRow)));
     threadsRow = tbRow * tl;
-    // ---- columns: a power-of-two number of adjacent columns; 128-byte runs when they fit ~64 KB, else what fits ----
+    // ---- columns: a power-of-two number of adjacent columns.  Measured on MI355X (tools/fftsweep.sh): small tiles win -
+    // more resident workgroups hide the HBM and twiddle latencies, and the XCD-aware tile order lets the L2 merge the
+    // short runs of neighbouring tiles - so aim at ~32 KB of LDS; long columns take what gives at least 32-byte runs ----
     const size_t colBytes = (size_t)col.mPad * es;
     if (colBytes > (size_t)kMaxLds) {
         nf_set_error("column length too large for the single-pass LDS FFT");
         return NF_ERR_SIZE;
     }
-    const size_t colBudget = (size_t)env_int("NF_FFT_COL_LDS_KB", 64) * 1024;
+    const size_t colBudget = (size_t)env_int("NF_FFT_COL_LDS_KB", 32) * 1024;
     int c = 1;
     while (c < 32 && (size_t)(2 * c) * colBytes <= colBudget) c *= 2;
-    // narrow tiles waste HBM bursts: below 64-byte runs take the whole LDS (one workgroup per CU) if that widens the tile
-    while ((size_t)c * es < 64 && (size_t)(2 * c) * colBytes <= (size_t)kMaxLds) c *= 2;
+    while ((size_t)c * es < 32 && (size_t)(2 * c) * colBytes <= (size_t)kMaxLds) c *= 2;
     if (env_int("NF_FFT_COLS_PER_WG", 0) > 0) c = env_int("NF_FFT_COLS_PER_WG", 0);
     while (c > 1 && (size_t)c * colBytes > (size_t)kMaxLds) c /= 2;
     colsPerWG = c;
     threadsCol = 256;
-    if ((size_t)c * colBytes > 80 * 1024) threadsCol = 512;
+    if ((size_t)c * colBytes > 80 * 1024) threadsCol = 1024;      // one workgroup per CU: fill it
     if (env_int("NF_FFT_COL_THREADS", 0) > 0) threadsCol = env_int("NF_FFT_COL_THREADS", 0);
     threadsCol = std::max(threadsCol, colsPerWG);
     return NF_OK;

@@ -30,6 +30,31 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
     for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += red[i];
     return t;
 }
+// three sums in one pass: one barrier pair instead of three (red3: 3 * 16 doubles)
+__device__ __forceinline__ void block_sum3(double& a, double& b, double& c, double* red3) {
+    for (int off = 32; off > 0; off >>= 1) {
+        a += __shfl_down(a, off, 64);
+        b += __shfl_down(b, off, 64);
+        c += __shfl_down(c, off, 64);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) {
+        red3[wave] = a;
+        red3[16 + wave] = b;
+        red3[32 + wave] = c;
+    }
+    __syncthreads();
+    double ta = 0.0, tb = 0.0, tc = 0.0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) {
+        ta += red3[i];
+        tb += red3[16 + i];
+        tc += red3[32 + i];
+    }
+    a = ta;
+    b = tb;
+    c = tc;
+}
 __device__ __forceinline__ double block_min(double v, double* red) {
     for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_down(v, off, 64));
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -263,12 +288,15 @@ template <typename VT, typename WT, bool ONEBIN>
 __global__ void __launch_bounds__(NF_REG_THREADS)
 k_noise_cells_reg(const VT* __restrict__ v, const WT* __restrict__ wts, int H, int W, NoiseGrid g, double* __restrict__ stats) {
     const double* quantiles = g.quantiles;
-    __shared__ double red[16];
+    __shared__ double red[48];
     __shared__ unsigned int hist[ONEBIN ? 1 : 2 * NF_MAXBINS][256];
     __shared__ unsigned long long prefix[2 * NF_MAXBINS];
     __shared__ unsigned int rankLeft[2 * NF_MAXBINS];
     __shared__ double edges[NF_MAXBINS + 1];
-    const int cell = blockIdx.x;
+    // blocks b, b + 8, ... share an XCD: give them consecutive cells, whose windows overlap by half (L2 reuse)
+    const int ncell = g.ny * g.nx, per = (ncell + 7) >> 3;
+    const int cell = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (cell >= ncell) return;
     const int nb = ONEBIN ? 1 : g.numBins;
     double* rec = stats + (long long)cell * cell_stride(nb);
     const CellWin c = cell_window(g, cell, H, W);
@@ -283,27 +311,40 @@ k_noise_cells_reg(const VT* __restrict__ v, const WT* __restrict__ wts, int H, i
     int r0 = tid / ww, x0 = tid - r0 * ww;
     const int dr = NF_REG_THREADS / ww, dx = NF_REG_THREADS - dr * ww;
     {
+        // loads in branch-free groups of 8 (indices beyond the window are clamped to its first pixel and the value
+        // discarded afterwards), so that 16 loads per thread are in flight instead of one dependent pair at a time
         int rr = r0, xx = x0;
+        const long long qSafe = (long long)c.y0 * W + c.x0;
 #pragma unroll
-        for (int j = 0; j < NF_VPT; ++j) {
-            double t = 0.0;
-            if (j * NF_REG_THREADS + tid < npx) {
-                const long long q = (long long)(c.y0 + rr) * W + c.x0 + xx;
-                t = (double)v[q];
+        for (int j0 = 0; j0 < NF_VPT; j0 += 8) {
+            VT tv[8];
+            WT tw[8];
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                const bool in = (j0 + jj) * NF_REG_THREADS + tid < npx;
+                const long long q = in ? (long long)(c.y0 + rr) * W + c.x0 + xx : qSafe;
+                tv[jj] = v[q];
+                tw[jj] = wts[q];
+                rr += dr;
+                xx += dx;
+                if (xx >= ww) {
+                    xx -= ww;
+                    rr += 1;
+                }
+            }
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                const int j = j0 + jj;
+                const bool in = j * NF_REG_THREADS + tid < npx;
+                const double t = in ? (double)tv[jj] : 0.0;
                 if (t != 0.0) {
                     validMask |= 1u << j;
                     cnt += 1.0;
-                    double wv = (double)wts[q];
+                    const double wv = (double)tw[jj];
                     wmin = fmin(wmin, wv);
                     wmax = fmax(wmax, wv);
                 }
-            }
-            val[j] = t;
-            rr += dr;
-            xx += dx;
-            if (xx >= ww) {
-                xx -= ww;
-                rr += 1;
+                val[j] = t;
             }
         }
     }
@@ -425,8 +466,9 @@ k_noise_cells_reg(const VT* __restrict__ v, const WT* __restrict__ wts, int H, i
                         s += val[j];
                         nn += 1.0;
                     }
-                s = block_sum(s, red);
-                n = block_sum(nn, red);
+                double zero = 0.0;
+                block_sum3(s, nn, zero, red);
+                n = nn;
                 if (n == 0.0) break;
                 m = s / n;
                 double ss = 0.0;
@@ -449,9 +491,8 @@ k_noise_cells_reg(const VT* __restrict__ v, const WT* __restrict__ wts, int H, i
                         ss += d * d;
                         nn += 1.0;
                     }
-                s = block_sum(s, red);
-                ss = block_sum(ss, red);
-                n = block_sum(nn, red);
+                block_sum3(s, ss, nn, red);
+                n = nn;
                 if (n == 0.0) continue;
                 const double dm = s / n;
                 m = c0 + dm;
@@ -601,7 +642,10 @@ int noise_map(int vtype, const void* filtered, const void* weights, int wtype, f
     // widest possible window: (largest cell + 2 * overlap)^2; cells differ by at most one pixel (np.linspace(dtype=int))
     const long long maxH = (long long)(H / g.ny + 1) + 2LL * g.overlap, maxW = (long long)(W / g.nx + 1) + 2LL * g.overlap;
     const bool inRegs = (maxH < H ? maxH : H) * (maxW < W ? maxW : W) <= (long long)NF_VPT * NF_REG_THREADS;
-    if (inRegs) bc = dim3(NF_REG_THREADS);
+    if (inRegs) {
+        bc = dim3(NF_REG_THREADS);
+        gc = dim3(((g.ny * g.nx + 7) / 8) * 8);   // the register kernel permutes cells over the XCDs in groups of 8
+    }
 #define NF_NC(VT, WT)                                                                                                        \
     do {                                                                                                                     \
         if (inRegs && g.numBins == 1)                                                                                        \

@@ -84,10 +84,11 @@ int nf_window_mul(int prec, void* F_d, const double* wy_d, const double* wx_d, i
 
 /* Template painter standing where pixell.pointsrcs.sim_objects stands (nemo/signals.py:681,691): float32 map of
  * sign * float32(amp * profile(theta)); hav(theta) = A[y] + B[y]*C[x] (device tables), profile by linear
- * interpolation on the log-uniform table r_d/prof_d (ntab entries, r[k] = r0*exp(k*dlnr)). */
+ * interpolation on the log-uniform table r_d/prof_d (ntab entries, r[k] = r0*exp(k*dlnr)).  slope_d (optional, may be
+ * NULL): ntab-1 doubles (prof[k+1]-prof[k])/(r[k+1]-r[k]), which saves the kernel one float64 division per pixel. */
 int nf_paint_radial(float* out_d, int H, int W, const double* A_d, const double* B_d, const double* C_d,
-                    const double* r_d, const double* prof_d, int ntab, double r0, double dlnr, double amp, double sign,
-                    void* stream);
+                    const double* r_d, const double* prof_d, const double* slope_d, int ntab, double r0, double dlnr,
+                    double amp, double sign, void* stream);
 
 /* nemo/filters.py:853 + :714: out = float32 map * signalNorm * psMask, in float64 (vtype NF_F64: signalNorm is a
  * float64 scalar, 'yc') or float32 (vtype NF_F32: 'uK').  psMask_d may be NULL. */
@@ -140,7 +141,9 @@ int nf_object_stats(int vtype, const void* sn_d, int negate, const int* labels_d
                     double* stats_d, void* stream);
 
 /* ndarray.max() / np.argmax of a whole map (nemo/filters.py:661,684; nemo/filters.py:1017-1019,1198): out_d holds
- * 4 doubles - [0] maximum, [1] flat index of its first occurrence, [2..3] scratch. */
+ * NF_MAP_MAX_DOUBLES doubles - [0] maximum, [1] flat index of its first occurrence, the rest is scratch (per-workgroup
+ * partial results). */
+#define NF_MAP_MAX_DOUBLES (4 + 2 * 2048)
 int nf_map_max(int vtype, const void* map_d, long long n, double* out_d, void* stream);
 
 /* nemo/photometry.py:69-73: isRing_d[id] = 1 if component id has > minRingPix pixels and its centre of mass is

@@ -41,7 +41,7 @@ SIGNATURES = {
     'nf_build_filter': (c_int, [c_int, c_int, c_void_p, c_void_p, ctypes.POINTER(c_double), c_void_p, c_int, c_ll, c_void_p]),
     'nf_apply_filter': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_ll, c_void_p]),
     'nf_window_mul': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
-    'nf_paint_radial': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_double,
+    'nf_paint_radial': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_double,
                                 c_double, c_double, c_double, c_void_p]),
     'nf_scale_mask': (c_int, [c_int, c_void_p, c_void_p, c_double, c_void_p, c_ll, c_void_p]),
     'nf_noise_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),

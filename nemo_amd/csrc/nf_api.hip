@@ -258,13 +258,14 @@ int nf_window_mul(int prec, void* F, const double* wy, const double* wx, int H, 
 }
 
 int nf_paint_radial(float* out, int H, int W, const double* A, const double* B, const double* C, const double* r,
-                    const double* prof, int ntab, double r0, double dlnr, double amp, double sign, void* stream) {
+                    const double* prof, const double* slope, int ntab, double r0, double dlnr, double amp, double sign,
+                    void* stream) {
     if (!out || !A || !B || !C || !r || !prof || ntab < 2 || H < 1 || W < 1 || !(dlnr > 0) || !(r0 > 0)) {
         nf_set_error("nf_paint_radial: bad arguments");
         return NF_ERR_ARG;
     }
     nf::ProfScope ps(nf::PT_PAINT, S(stream), (double)H * W * 4.0);
-    return nf::paint_radial(out, H, W, A, B, C, r, prof, ntab, r0, dlnr, amp, sign, S(stream));
+    return nf::paint_radial(out, H, W, A, B, C, r, prof, slope, ntab, r0, dlnr, amp, sign, S(stream));
 }
 
 int nf_scale_mask(int vtype, const float* in, void* out, double norm, const unsigned char* psMask, long long n, void* stream) {

@@ -289,45 +289,82 @@ int object_stats(int vtype, const void* sn, int negate, const int* labels, int H
 
 // ---------------------------------------------------------------------------------------------------
 // np.argmax / ndarray.max of a whole map (nemo/filters.py:661,684): maximum value and FIRST raster index attaining it.
-template <typename VT>
-__global__ void k_map_max(const VT* __restrict__ m, long long n, unsigned long long* __restrict__ key) {
-    double best = -INFINITY;
-    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x)
-        best = fmax(best, (double)m[p]);
-    for (int off = 32; off > 0; off >>= 1) best = fmax(best, __shfl_down(best, off, 64));
-    if ((threadIdx.x & 63) == 0) atomicMax(key, ordered_key(best));
-}
-template <typename VT>
-__global__ void k_map_argmax(const VT* __restrict__ m, long long n, const unsigned long long* __restrict__ key,
-                             unsigned long long* __restrict__ arg) {
-    const unsigned long long k = *key;
-    unsigned long long best = 0xFFFFFFFFFFFFFFFFULL;
-    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x)
-        if (ordered_key((double)m[p]) == k && (unsigned long long)p < best) best = (unsigned long long)p;
-    if (best != 0xFFFFFFFFFFFFFFFFULL) atomicMin(arg, best);
-}
-__global__ void k_map_max_finish(double* out) {
-    unsigned long long k = ((unsigned long long*)out)[2];
-    unsigned long long b = (k & 0x8000000000000000ULL) ? (k & 0x7FFFFFFFFFFFFFFFULL) : ~k;
-    out[0] = __longlong_as_double((long long)b);
-    out[1] = (double)((unsigned long long*)out)[3];
+// One pass: every thread keeps (value, first index) of its grid-stride share, the workgroup reduces with wavefront
+// shuffles + LDS and writes ONE partial; a second single-workgroup launch reduces the partials.  No atomics (65536
+// wavefronts hammering one 8-byte word made the first version atomics-bound: 218 us for a 67 MB map).
+#define NF_MAXRED_BLOCKS 2048
+#define NF_MAXRED_THREADS 256
+
+__device__ __forceinline__ void max_first(double& v, long long& i, double ov, long long oi) {
+    // maximum value; among equals the smallest index (np.argmax returns the first occurrence)
+    if (ov > v || (ov == v && oi < i)) {
+        v = ov;
+        i = oi;
+    }
 }
 
-// out: 4 doubles on the device: [0] max value, [1] first index of the max, [2..3] scratch
-int map_max(int vtype, const void* m, long long n, double* out, hipStream_t s) {
-    unsigned long long* key = (unsigned long long*)out + 2;
-    unsigned long long* arg = key + 1;
-    NF_HIP(hipMemsetAsync(key, 0, sizeof(unsigned long long), s));
-    NF_HIP(hipMemsetAsync(arg, 0xFF, sizeof(unsigned long long), s));
-    dim3 g(grid_for(n, 256)), b(256);
-    if (vtype == NF_F64) {
-        hipLaunchKernelGGL(k_map_max<double>, g, b, 0, s, (const double*)m, n, key);
-        hipLaunchKernelGGL(k_map_argmax<double>, g, b, 0, s, (const double*)m, n, key, arg);
-    } else {
-        hipLaunchKernelGGL(k_map_max<float>, g, b, 0, s, (const float*)m, n, key);
-        hipLaunchKernelGGL(k_map_argmax<float>, g, b, 0, s, (const float*)m, n, key, arg);
+__device__ __forceinline__ void block_max_first(double& best, long long& arg) {
+    __shared__ double sv[NF_MAXRED_THREADS / 64];
+    __shared__ long long si[NF_MAXRED_THREADS / 64];
+    for (int off = 32; off > 0; off >>= 1) {
+        double ov = __shfl_down(best, off, 64);
+        long long oi = __shfl_down(arg, off, 64);
+        max_first(best, arg, ov, oi);
     }
-    hipLaunchKernelGGL(k_map_max_finish, dim3(1), dim3(1), 0, s, out);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        sv[wave] = best;
+        si[wave] = arg;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < NF_MAXRED_THREADS / 64; ++w) max_first(best, arg, sv[w], si[w]);
+    }
+}
+
+template <typename VT>
+__global__ void __launch_bounds__(NF_MAXRED_THREADS) k_map_max(const VT* __restrict__ m, long long n, double* __restrict__ pv,
+                                                                long long* __restrict__ pi) {
+    double best = -INFINITY;
+    long long arg = 0x7FFFFFFFFFFFFFFFLL;
+    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x) {
+        const double v = (double)m[p];
+        if (v > best) {      // indices grow along the loop: strict > keeps the first occurrence
+            best = v;
+            arg = p;
+        }
+    }
+    block_max_first(best, arg);
+    if (threadIdx.x == 0) {
+        pv[blockIdx.x] = best;
+        pi[blockIdx.x] = arg;
+    }
+}
+__global__ void __launch_bounds__(NF_MAXRED_THREADS) k_map_max_finish(const double* __restrict__ pv, const long long* __restrict__ pi,
+                                                                       int nPart, double* __restrict__ out) {
+    double best = -INFINITY;
+    long long arg = 0x7FFFFFFFFFFFFFFFLL;
+    for (int k = threadIdx.x; k < nPart; k += blockDim.x) max_first(best, arg, pv[k], pi[k]);
+    block_max_first(best, arg);
+    if (threadIdx.x == 0) {
+        out[0] = best;
+        out[1] = (double)arg;
+    }
+}
+
+// out: NF_MAP_MAX_DOUBLES (= 4 + 2 * 2048) doubles on the device, owned by the caller: [0] max value, [1] first index of
+// the max, [4..] per-workgroup partials (values, then indices)
+int map_max(int vtype, const void* m, long long n, double* out, hipStream_t s) {
+    double* pv = out + 4;
+    long long* pi = (long long*)(pv + NF_MAXRED_BLOCKS);
+    long long want = (n + NF_MAXRED_THREADS * 8LL - 1) / (NF_MAXRED_THREADS * 8LL);
+    const int nPart = (int)(want < 1 ? 1 : (want > NF_MAXRED_BLOCKS ? NF_MAXRED_BLOCKS : want));
+    dim3 g(nPart), b(NF_MAXRED_THREADS);
+    if (vtype == NF_F64)
+        hipLaunchKernelGGL(k_map_max<double>, g, b, 0, s, (const double*)m, n, pv, pi);
+    else
+        hipLaunchKernelGGL(k_map_max<float>, g, b, 0, s, (const float*)m, n, pv, pi);
+    hipLaunchKernelGGL(k_map_max_finish, dim3(1), b, 0, s, pv, pi, nPart, out);
     NF_CHECK_LAUNCH("map_max");
     return NF_OK;
 }
@@ -357,6 +394,96 @@ int ring_flags(const int* ringLabels, const double* ringStats, int numRing, int 
                        H, W, isRing);
     NF_CHECK_LAUNCH("k_ring_flags");
     return NF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+#define NF_SPL_MAXN 72
+
+// Points further than halfWin + 2 pixels from every map edge: the second derivatives of the interpolating cubic spline
+// on a uniform grid are M_i = sum_j G(i - j) d_j with d_j = 6 (y_{j-1} - 2 y_j + y_{j+1}) and the Green's function of the
+// (1, 4, 1) system, G(k) = rho^|k| / (2 sqrt 3), rho = sqrt 3 - 2: the boundary conditions are forgotten like
+// |rho|^distance (0.268^33 ~ 1e-19), which is why a +-32 pixel window reproduces the whole-map FITPACK fit
+// (SURVEY.md Appendix A).  The value at (py, px) is then a separable weighted sum over the window - no sequential
+// tridiagonal solves, one wavefront-parallel dot product per point.
+__device__ __forceinline__ bool spline_interior(int iy, int ix, int H, int W, int halfWin) {
+    return iy - halfWin - 1 >= 0 && iy + halfWin + 2 <= H - 1 && ix - halfWin - 1 >= 0 && ix + halfWin + 2 <= W - 1;
+}
+
+__device__ __forceinline__ double ipow(double b, int k) {
+    double r = 1.0;
+    while (k > 0) {
+        if (k & 1) r *= b;
+        b *= b;
+        k >>= 1;
+    }
+    return r;
+}
+
+// weights w[m], m = 0 .. 2K+3, of samples i-K-1 .. i+K+2 for an evaluation at i + t  (c[] = scratch of 2K+4 doubles)
+__device__ __forceinline__ void spline_weights(double t, int K, double* c, double* w, int lane, int nlanes) {
+    const double rho = -0.26794919243112270647255365849413;    // sqrt(3) - 2
+    const double A = 0.28867513459481288225457439025098;       // 1 / (2 sqrt(3))
+    const double t1 = 1.0 - t;
+    const double a = t1 * t1 * t1 / 6.0 - t1 / 6.0, b = t * t * t / 6.0 - t / 6.0;
+    const int n = 2 * K + 4;
+    // c_j for j = i-K-1 .. i+K+2 (index m = j - (i-K-1)); zero on the two outermost samples
+    for (int m = lane; m < n; m += nlanes) {
+        double v = 0.0;
+        if (m >= 1 && m <= n - 2) {
+            const int k0 = abs(m - (K + 1));       // |i - j|
+            const int k1 = abs(m - (K + 2));       // |i + 1 - j|
+            v = A * (a * ipow(rho, k0) + b * ipow(rho, k1));
+        }
+        c[m] = v;
+    }
+    __syncthreads();
+    for (int m = lane; m < n; m += nlanes) {
+        const double cm = c[m], cl = m > 0 ? c[m - 1] : 0.0, cr = m < n - 1 ? c[m + 1] : 0.0;
+        double v = 6.0 * (cl - 2.0 * cm + cr);
+        if (m == K + 1) v += t1;
+        if (m == K + 2) v += t;
+        w[m] = v;
+    }
+    __syncthreads();
+}
+
+template <typename VT>
+__device__ __forceinline__ void spline_eval_interior(const VT* __restrict__ map, int negate, int W, double py, double px, int iy,
+                                                     int ix, int K, double* lds /* 3 * NF_SPL_MAXN + 2 doubles */,
+                                                     double* __restrict__ outp) {
+    double *cbuf = lds, *wy = lds + NF_SPL_MAXN, *wx = lds + 2 * NF_SPL_MAXN, *red = lds + 3 * NF_SPL_MAXN;
+    const int n = 2 * K + 4;
+    spline_weights(py - (double)iy, K, cbuf, wy, threadIdx.x, blockDim.x);
+    spline_weights(px - (double)ix, K, cbuf, wx, threadIdx.x, blockDim.x);
+    const int y0 = iy - K - 1, x0 = ix - K - 1;
+    double acc = 0.0;
+    if ((int)threadIdx.x < n) {
+        const VT* col = map + (long long)y0 * W + x0 + threadIdx.x;
+        // 16 independent row loads in flight per round (the loop is latency-bound otherwise: one HBM round trip per row)
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int r = 0;
+        for (; r + 15 < n; r += 16) {
+            double v[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = (double)col[(long long)(r + j) * W];
+#pragma unroll
+            for (int j = 0; j < 16; j += 4) {
+                s0 += wy[r + j] * v[j];
+                s1 += wy[r + j + 1] * v[j + 1];
+                s2 += wy[r + j + 2] * v[j + 2];
+                s3 += wy[r + j + 3] * v[j + 3];
+            }
+        }
+        for (; r < n; ++r) s0 += wy[r] * (double)col[(long long)r * W];
+        acc = ((s0 + s1) + (s2 + s3)) * wx[threadIdx.x];
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double v = red[0] + red[1];
+        *outp = negate ? -v : v;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -394,7 +521,6 @@ __device__ double nak_spline_eval(const double* y, int st, int n, double u, doub
     return M[i] * t1 * t1 * t1 / 6.0 + M[i + 1] * t * t * t / 6.0 + (y0 - M[i] / 6.0) * t1 + (y1 - M[i + 1] / 6.0) * t;
 }
 
-#define NF_SPL_MAXN 72
 
 template <typename VT>
 __global__ void k_spline_eval(const VT* __restrict__ map, int negate, int H, int W, const double* __restrict__ yx, int halfWin,
@@ -412,6 +538,10 @@ __global__ void k_spline_eval(const VT* __restrict__ map, int negate, int H, int
     double* cp = colv + NF_SPL_MAXN;                         // [NF_SPL_MAXN]
     if (!(py >= 0.0 && py <= (double)(H - 1) && px >= 0.0 && px <= (double)(W - 1)) || ny < 4 || nx < 4) {
         if (threadIdx.x == 0) out[blockIdx.x] = nan("");
+        return;
+    }
+    if (spline_interior(iy, ix, H, W, halfWin)) {            // uniform over the workgroup
+        spline_eval_interior<VT>(map, negate, W, py, px, iy, ix, halfWin, win, out + blockIdx.x);
         return;
     }
     for (int i = threadIdx.x; i < ny * nx; i += blockDim.x) {

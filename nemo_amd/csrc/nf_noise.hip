@@ -30,30 +30,48 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
     for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += red[i];
     return t;
 }
-// three sums in one pass: one barrier pair instead of three (red3: 3 * 16 doubles)
+// Cross-lane moves on the vector ALU (DPP) instead of the LDS crossbar (ds_bpermute, which __shfl_down lowers to): a
+// float64 is moved as its two halves.
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROWMASK, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROWMASK, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+// after this every lane of a row of 16 holds the sum of its row
+__device__ __forceinline__ double row16_sum(double v) {
+    v += dpp_f64<0xB1, 0xF>(v);    // quad_perm [1,0,3,2]
+    v += dpp_f64<0x4E, 0xF>(v);    // quad_perm [2,3,0,1]
+    v += dpp_f64<0x141, 0xF>(v);   // row_half_mirror
+    v += dpp_f64<0x140, 0xF>(v);   // row_mirror
+    return v;
+}
+// lane 63 ends up with the sum over the wavefront
+__device__ __forceinline__ double wave_sum_lane63(double v) {
+    v = row16_sum(v);
+    v += dpp_f64<0x142, 0xA>(v);   // row_bcast15 into rows 1 and 3
+    v += dpp_f64<0x143, 0xC>(v);   // row_bcast31 into rows 2 and 3
+    return v;
+}
+
+// three sums in one pass: one barrier pair instead of three (red3: 3 * 16 doubles; at most 16 wavefronts)
 __device__ __forceinline__ void block_sum3(double& a, double& b, double& c, double* red3) {
-    for (int off = 32; off > 0; off >>= 1) {
-        a += __shfl_down(a, off, 64);
-        b += __shfl_down(b, off, 64);
-        c += __shfl_down(c, off, 64);
-    }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    a = wave_sum_lane63(a);
+    b = wave_sum_lane63(b);
+    c = wave_sum_lane63(c);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     __syncthreads();
-    if (lane == 0) {
+    if (lane == 63) {
         red3[wave] = a;
         red3[16 + wave] = b;
         red3[32 + wave] = c;
     }
     __syncthreads();
-    double ta = 0.0, tb = 0.0, tc = 0.0;
-    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) {
-        ta += red3[i];
-        tb += red3[16 + i];
-        tc += red3[32 + i];
-    }
-    a = ta;
-    b = tb;
-    c = tc;
+    const int k = lane & 15;
+    a = row16_sum(k < nw ? red3[k] : 0.0);
+    b = row16_sum(k < nw ? red3[16 + k] : 0.0);
+    c = row16_sum(k < nw ? red3[32 + k] : 0.0);
 }
 __device__ __forceinline__ double block_min(double v, double* red) {
     for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_down(v, off, 64));

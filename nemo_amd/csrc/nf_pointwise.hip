@@ -261,15 +261,18 @@ __device__ __forceinline__ double theta_from_hav(double h) {
     return __dmul_rn(__dmul_rn(2.0, s), poly);
 }
 
-__global__ void k_paint_radial(float* __restrict__ out, int H, int W, const double* __restrict__ A, const double* __restrict__ B,
-                               const double* __restrict__ C, const double* __restrict__ r, const double* __restrict__ prof,
-                               int ntab, double r0, double dlnr, double amp, float sign) {
-    long long n = (long long)H * W;
+__global__ void __launch_bounds__(256) k_paint_radial(float* __restrict__ out, int H, int W, const double* __restrict__ A,
+                                                      const double* __restrict__ B, const double* __restrict__ C,
+                                                      const double* __restrict__ r, const double* __restrict__ prof,
+                                                      const double* __restrict__ slope, int ntab, float log2r0,
+                                                      float invDlog2, double amp, float sign) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= W) return;
     const double rlast = r[ntab - 1];
     const double rfirst = r[0];
-    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x) {
-        int y = (int)(p / W), x = (int)(p % W);
-        double h = __dadd_rn(A[y], __dmul_rn(B[y], C[x]));
+    const double cx = C[x];
+    for (int y = blockIdx.y; y < H; y += gridDim.y) {
+        double h = __dadd_rn(A[y], __dmul_rn(B[y], cx));
         double th = theta_from_hav(h);
         double val;
         if (th < rfirst) {
@@ -279,23 +282,26 @@ __global__ void k_paint_radial(float* __restrict__ out, int H, int W, const doub
         } else if (th == rlast) {
             val = prof[ntab - 1];
         } else {
-            int j = (int)(log(th / r0) / dlnr);
+            // interval index from a float32 log2 (the table is log-uniform); the two loops below make it exact
+            int j = (int)((__log2f((float)th) - log2r0) * invDlog2);
             if (j < 0) j = 0;
             if (j > ntab - 2) j = ntab - 2;
-            while (j > 0 && r[j] > th) --j;            // guard against log() rounding at interval edges
+            while (j > 0 && r[j] > th) --j;
             while (j < ntab - 2 && r[j + 1] <= th) ++j;
-            double slope = __ddiv_rn(__dsub_rn(prof[j + 1], prof[j]), __dsub_rn(r[j + 1], r[j]));
-            val = __dadd_rn(__dmul_rn(slope, __dsub_rn(th, r[j])), prof[j]);
+            const double sl = slope != nullptr ? slope[j] : __ddiv_rn(__dsub_rn(prof[j + 1], prof[j]), __dsub_rn(r[j + 1], r[j]));
+            val = __dadd_rn(__dmul_rn(sl, __dsub_rn(th, r[j])), prof[j]);
         }
         float v = (float)__dmul_rn(amp, val);
-        out[p] = (sign < 0.0f) ? v * -1.0f : v;
+        out[(long long)y * W + x] = (sign < 0.0f) ? v * -1.0f : v;
     }
 }
 
 int paint_radial(float* out, int H, int W, const double* A, const double* B, const double* C, const double* r,
-                 const double* prof, int ntab, double r0, double dlnr, double amp, double sign, hipStream_t s) {
-    hipLaunchKernelGGL(k_paint_radial, dim3(grid_for((long long)H * W, 256)), dim3(256), 0, s, out, H, W, A, B, C, r, prof, ntab,
-                       r0, dlnr, amp, (float)sign);
+                 const double* prof, const double* slope, int ntab, double r0, double dlnr, double amp, double sign,
+                 hipStream_t s) {
+    const int gy = H < 1024 ? H : 1024;
+    hipLaunchKernelGGL(k_paint_radial, dim3((W + 255) / 256, gy), dim3(256), 0, s, out, H, W, A, B, C, r, prof, slope, ntab,
+                       (float)(log(r0) / log(2.0)), (float)(1.0 / (dlnr / log(2.0))), amp, (float)sign);
     NF_CHECK_LAUNCH("k_paint_radial");
     return NF_OK;
 }

@@ -223,10 +223,11 @@ class TileEngine(object):
             self._geom = {key: tuple(to_dev(g) for g in geom)}
         A, B, C = self._geom[key]
         if not hasattr(table, '_dev'):
-            table._dev = (to_dev(table.r), to_dev(table.prof))
-        r, prof = table._dev
+            r_, p_ = np.asarray(table.r, dtype=np.float64), np.asarray(table.prof, dtype=np.float64)
+            table._dev = (to_dev(r_), to_dev(p_), to_dev((p_[1:] - p_[:-1]) / (r_[1:] - r_[:-1])))
+        r, prof, slope = table._dev
         out = t.empty((self.H, self.W), dtype=t.float32, device=self.dev)
-        check(self.lib.nf_paint_radial(ptr(out), self.H, self.W, ptr(A), ptr(B), ptr(C), ptr(r), ptr(prof), len(table.r),
+        check(self.lib.nf_paint_radial(ptr(out), self.H, self.W, ptr(A), ptr(B), ptr(C), ptr(r), ptr(prof), ptr(slope), len(table.r),
                                        table.r0, table.dlnr, table.amp, table.sign, stream_ptr()), "nf_paint_radial")
         return out
 
@@ -353,7 +354,7 @@ class TileEngine(object):
     def map_max(self, m):
         """(max value, flat index of its first occurrence) of a device map."""
         t = self.t
-        out = t.empty(4, dtype=t.float64, device=self.dev)
+        out = t.empty(4 + 2 * 2048, dtype=t.float64, device=self.dev)      # NF_MAP_MAX_DOUBLES
         check(self.lib.nf_map_max(prec_of(m), ptr(m), m.numel(), ptr(out), stream_ptr()), "nf_map_max")
         res = out[:2].cpu().numpy()
         return res[0], int(res[1])

@@ -11,6 +11,8 @@ the smoothed noise covariance are kept in HBM and shared by all filter scales of
 them for each scale - they do not depend on the template), and the filtered / S/N maps stay on the device for source
 finding.  Only catalogue rows reach the host.
 """
+import concurrent.futures
+import contextlib
 import os
 import time
 
@@ -97,6 +99,38 @@ def _gatherCatalogs(optimalCatalog, config):
     return tab
 
 
+def _detectAndMeasure(config, job, stream, invertMap, measureFluxes, photFilter, verbose):
+    """photometry.findObjects + measureFluxes for one (filter, tile) - nemo/pipelines.py:267-311.  With ``stream`` the
+    work is enqueued on that HIP stream (called from the detection worker thread) after the filtered maps are complete."""
+    label, f, filteredMapDict, photFilteredMapDict, ready = job
+    t = engine.torch()
+    ctx = t.cuda.stream(stream) if stream is not None else contextlib.nullcontext()
+    with ctx:
+        if stream is not None:
+            stream.wait_event(ready)
+        catalog = photometry.findObjects(filteredMapDict, threshold=config.parDict['thresholdSigma'],
+                                         minObjPix=config.parDict['minObjPix'],
+                                         findCenterOfMass=config.parDict['findCenterOfMass'],
+                                         flagRings=config.parDict['flagRings'],
+                                         ringFlagDistArcmin=config.parDict['ringFlagDistArcmin'],
+                                         ringFlagMinRingerSNR=config.parDict['ringFlagMinRingerSNR'],
+                                         ringThresholdSigma=config.parDict['ringThresholdSigma'],
+                                         rejectBorder=config.parDict['rejectBorder'],
+                                         objIdent=config.parDict['objIdent'], longNames=config.parDict['longNames'],
+                                         useInterpolator=config.parDict['useInterpolator'],
+                                         measureShapes=config.parDict['measureShapes'], invertMap=invertMap,
+                                         verbose=verbose)
+        if measureFluxes == True:
+            photometry.measureFluxes(catalog, filteredMapDict, config.diagnosticsDir, photFilteredMapDict=photFilteredMapDict,
+                                     useInterpolator=config.parDict['useInterpolator'])
+        elif photFilter is not None:
+            photometry.getSNRValues(catalog, photFilteredMapDict['SNMap'], filteredMapDict['wcs'], prefix='fixed_',
+                                    useInterpolator=config.parDict['useInterpolator'], invertMap=invertMap)
+        if stream is not None:
+            stream.synchronize()      # everything that reads the maps has finished before their memory can be reused
+    return catalog
+
+
 def filterMapsAndMakeCatalogs(config, rootOutDir=None, useCachedFilters=False, useCachedRMSMap=False,
                               useCachedFilteredMaps=False, measureFluxes=True, invertMap=False, verbose=True,
                               writeAreaMask=False, writeFlagMask=False):
@@ -167,6 +201,12 @@ def _filterMapsAndMakeCatalogs(config, rootOutDir=None, useCachedFilters=False, 
     config.stitchedFilteredMapDict, config.stitchedSNMapDict, config.stitchedRMSMapDict = {}, {}, {}
     keepDevice = filters.RETURN_DEVICE_ARRAYS
     filters.RETURN_DEVICE_ARRAYS = True
+    t = engine.torch()
+    engine.require_gpu()
+    pool, detStream, pending = None, None, []
+    if config.parDict.get('asyncDetection', True):
+        pool = concurrent.futures.ThreadPoolExecutor(max_workers=1)
+        detStream = t.cuda.Stream()
     try:
         for tileName in config.tileNames:
             if verbose == True:
@@ -192,33 +232,33 @@ def _filterMapsAndMakeCatalogs(config, rootOutDir=None, useCachedFilters=False, 
                     config.stitchedRMSMapDict[tileName] = filteredMapDict['RMSMap'].to(t.float32)
                 if f['label'] == photFilter:
                     photFilteredMapDict = {'SNMap': filteredMapDict['SNMap'], 'data': filteredMapDict['data']}
-                catalog = photometry.findObjects(filteredMapDict, threshold=config.parDict['thresholdSigma'],
-                                                 minObjPix=config.parDict['minObjPix'],
-                                                 findCenterOfMass=config.parDict['findCenterOfMass'],
-                                                 flagRings=config.parDict['flagRings'],
-                                                 ringFlagDistArcmin=config.parDict['ringFlagDistArcmin'],
-                                                 ringFlagMinRingerSNR=config.parDict['ringFlagMinRingerSNR'],
-                                                 ringThresholdSigma=config.parDict['ringThresholdSigma'],
-                                                 rejectBorder=config.parDict['rejectBorder'],
-                                                 objIdent=config.parDict['objIdent'], longNames=config.parDict['longNames'],
-                                                 useInterpolator=config.parDict['useInterpolator'],
-                                                 measureShapes=config.parDict['measureShapes'], invertMap=invertMap,
-                                                 verbose=verbose)
+                # Detection + photometry of this scale run on a second HIP stream from a worker thread, so that their host
+                # round trips (object count, catalogue rows) overlap the filtering of the next scale instead of idling the GPU.
                 if writeAreaMask == True and tileName not in config.areaMaskDict.keys():
                     config.areaMaskDict[tileName] = filteredMapDict['surveyMask']
                 if writeFlagMask == True and tileName not in config.flagMaskDict.keys():
                     config.flagMaskDict[tileName] = filteredMapDict['flagMask']
-                if measureFluxes == True:
-                    photometry.measureFluxes(catalog, filteredMapDict, diagnosticsDir, photFilteredMapDict=photFilteredMapDict,
-                                             useInterpolator=config.parDict['useInterpolator'])
-                elif photFilter is not None:
-                    photometry.getSNRValues(catalog, photFilteredMapDict['SNMap'], filteredMapDict['wcs'], prefix='fixed_',
-                                            useInterpolator=config.parDict['useInterpolator'], invertMap=invertMap)
+                ready = t.cuda.Event()
+                ready.record(t.cuda.current_stream())
+                job = (label, f, filteredMapDict, photFilteredMapDict, ready)
                 del filteredMapDict
-                catalogDict[label]['catalog'] = catalog
+                if pool is not None:
+                    pending.append((label, pool.submit(_detectAndMeasure, config, job, detStream, invertMap, measureFluxes,
+                                                       photFilter, verbose)))
+                else:
+                    catalogDict[label]['catalog'] = _detectAndMeasure(config, job, None, invertMap, measureFluxes, photFilter,
+                                                                      verbose)
+                del job
+                if len(pending) > 2:          # bound the maps kept alive for the worker to a few scales
+                    pending[-3][1].result()
+            for label, fut in pending:
+                catalogDict[label]['catalog'] = fut.result()
+            pending = []
             del tileCache
     finally:
         filters.RETURN_DEVICE_ARRAYS = keepDevice
+        if pool is not None:
+            pool.shutdown(wait=True)
 
     optimalCatalog = catalogs.makeOptimalCatalog(catalogDict, constraintsList=config.parDict['catalogCuts'],
                                                  photFilter=photFilter, method=config.parDict['optimalCatalogMethod'])

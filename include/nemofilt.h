@@ -58,6 +58,17 @@ int nf_fft2_forward(nf_plan* plan, int prec, const void* in_d, int inType, void*
 int nf_fft2_inverse(nf_plan* plan, int prec, const void* in_d, void* work_d, void* out_d, int outType, int batch,
                     int unitary, void* stream);
 
+/* nemo/filters.py:847 / :100,644 in one pass over the Fourier plane: the inverse transform of
+ *     win * sum_i in_i * filt_i          (nSum > 1: batch must be 1, in_d / filt_d hold nSum planes)
+ *     win * in_b * filt_b                (nSum == 1: per batch entry; filtPerBatch == 0 uses one filter plane for all)
+ * where filt_d (float32, may be NULL = 1) is the matched filter and win = wy[y] * wx[x] (float64 tables of
+ * enmap.apply_window already raised to the power wanted; both NULL = 1).  The products are formed while the column pass
+ * loads its operands, so nf_apply_filter / nf_window_mul and their extra read + write of the plane are not needed.
+ * Other arguments as nf_fft2_inverse. */
+int nf_fft2_inverse_fused(nf_plan* plan, int prec, const void* in_d, const float* filt_d, int nSum, int filtPerBatch,
+                          const double* wy_d, const double* wx_d, void* work_d, void* out_d, int outType, int batch,
+                          int unitary, void* stream);
+
 /* nemo/filters.py:573: NP[i][j] = Re(F_i conj F_j) for all i, j;  F [N][npix] complex, NP [N][N][npix] real. */
 int nf_cross_power(int prec, const void* F_d, void* NP_d, int N, long long npix, void* stream);
 

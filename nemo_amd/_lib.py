@@ -35,6 +35,8 @@ SIGNATURES = {
     'nf_plan_destroy': (c_int, [c_void_p]),
     'nf_fft2_forward': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     'nf_fft2_inverse': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    'nf_fft2_inverse_fused': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                      c_int, c_int, c_int, c_void_p]),
     'nf_cross_power': (c_int, [c_int, c_void_p, c_void_p, c_int, c_ll, c_void_p]),
     'nf_gaussian_filter': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p,
                                    c_int, c_void_p]),

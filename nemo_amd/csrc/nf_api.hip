@@ -201,6 +201,22 @@ int nf_fft2_inverse(nf_plan* p, int prec, const void* in, void* work, void* out,
     return p->pd.inverse(in, work, out, outType, batch, unitary ? 1 : 0, scale, S(stream));
 }
 
+int nf_fft2_inverse_fused(nf_plan* p, int prec, const void* in, const float* filt, int nSum, int filtPerBatch,
+                          const double* wy, const double* wx, void* work, void* out, int outType, int batch, int unitary,
+                          void* stream) {
+    if (!p || !in || !work || !out || batch < 1 || outType < 0 || outType > 2 || nSum < 1 || (nSum > 1 && (!filt || batch != 1)) ||
+        ((wy == nullptr) != (wx == nullptr))) {
+        nf_set_error("nf_fft2_inverse_fused: bad arguments");
+        return NF_ERR_ARG;
+    }
+    int rc = ensure_prec(p, prec);
+    if (rc) return rc;
+    double scale = std::sqrt((double)p->H * (double)p->W);
+    const long long fbs = (filt && filtPerBatch) ? (long long)p->H * p->W : 0;
+    if (prec == NF_F32) return p->pf.inverse(in, work, out, outType, batch, unitary ? 1 : 0, scale, S(stream), filt, nSum, fbs, wy, wx);
+    return p->pd.inverse(in, work, out, outType, batch, unitary ? 1 : 0, scale, S(stream), filt, nSum, fbs, wy, wx);
+}
+
 int nf_cross_power(int prec, const void* F, void* NP, int N, long long npix, void* stream) {
     if (!F || !NP || N < 1 || npix < 1) {
         nf_set_error("nf_cross_power: bad arguments");

@@ -44,6 +44,14 @@ struct LineArgs {
     int nTiles;      // columns kernel: number of column tiles
     double conjInSign, conjOutSign;  // -1 conjugates the complex input / output (inverse = conj FFT conj), else +1
     double scale;    // multiplier applied at the store (1 / sqrt(H*W) for unitary transforms, else 1)
+    // pointwise work fused into the columns kernel's load (inverse transforms): see fused_ops() in nf_fft.hip
+    int fused;               // any of the following present
+    const float* mulF32;     // float32 filter, indexed like the input plane
+    long long mulBatchStride;  // filter plane offset per batch entry (elements; 0 = the same filter for every batch entry)
+    int nSum;                // planes summed as sum_i in_i * mul_i (1 = none)
+    long long sumStride;     // plane pitch of in / mul for the sum (elements)
+    const double* winLine;   // pixel-window table along the line index (columns kernel: wx[col]) and
+    const double* winElem;   //   along the element index (wy[row]); both NULL = no window
     const double* apodLine;  // optional per-line apodisation factors (length nLines); rows kernel, real input only
     const double* apodElem;  // optional per-element apodisation factors (length n)
 };
@@ -58,7 +66,8 @@ struct Plan2D {
     int forward(const void* in, int inType, void* out, int batch, const double* apodY, const double* apodX,
                 int scaleDiv, double scale, hipStream_t stream);
     int inverse(const void* in, void* work, void* out, int outType, int batch, int scaleDiv, double scale,
-                hipStream_t stream);
+                hipStream_t stream, const float* filt = nullptr, int nSum = 1, long long filtBatchStride = 0,
+                const double* winY = nullptr, const double* winX = nullptr);
 };
 
 }  // namespace nf

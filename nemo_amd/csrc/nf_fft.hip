@@ -201,6 +201,39 @@ __device__ __forceinline__ void store_elem(const nf::LineArgs<T>& a, void* outP,
     }
 }
 
+// Pointwise work fused into the column kernel's global load (the pass that would otherwise read and write the whole
+// plane once more): pixel-window factor (enmap.apply_window, nemo/filters.py:100,644: product of the two 1-D tables
+// formed first, applied in float64, rounded to T) and / or the float32 filter with the frequency sum
+// (nemo/filters.py:847, sum moved in front of the inverse transform).  `line` = column, `row` = element index.
+template <typename T>
+__device__ __forceinline__ cpx<T> fused_ops(const nf::LineArgs<T>& a, const Geo& G, cpx<T> v, unsigned off, int line, int row) {
+    double win = 1.0;
+    if (a.winElem != nullptr) {
+        win = a.winElem[row] * a.winLine[line];
+        v.x = (T)((double)v.x * win);
+        v.y = (T)((double)v.y * win);
+    }
+    if (a.mulF32 != nullptr) {
+        const float* mul = a.mulF32 + (size_t)blockIdx.y * (size_t)a.mulBatchStride;
+        T h = (T)mul[off];
+        T re = v.x * h, im = v.y * h;
+        for (int pl = 1; pl < a.nSum; ++pl) {
+            cpx<T> f = ((const cpx<T>*)G.inP)[(size_t)pl * (size_t)a.sumStride + off];
+            f.y *= (T)a.conjInSign;
+            if (a.winElem != nullptr) {
+                f.x = (T)((double)f.x * win);
+                f.y = (T)((double)f.y * win);
+            }
+            h = (T)mul[(size_t)pl * (size_t)a.sumStride + off];
+            re += f.x * h;
+            im += f.y * h;
+        }
+        v.x = re;
+        v.y = im;
+    }
+    return v;
+}
+
 // One in-place stage.  DIT (dif == false): twiddle the inputs, then the butterfly; DIF: butterfly, then twiddle the
 // outputs.  srcG: operands come from global memory (columns kernel, first DIT stage: row src[e]); dstG: results go
 // to global memory (last DIT stage: natural index e).
@@ -244,6 +277,11 @@ __device__ __forceinline__ void fft_stage(cpx<T>* __restrict__ buf, const nf::Li
 #pragma unroll
                 for (int k = 0; k < R; ++k)
                     x[k] = load_elem<T, 0>(a, G.inP, lo + idx[k] * (unsigned)a.inElemStride, 1.0, (int)idx[k]);
+                if (a.fused) {      // uniform: after the plain loads, so that those stay batched
+#pragma unroll
+                    for (int k = 0; k < R; ++k)
+                        x[k] = fused_ops<T>(a, G, x[k], lo + idx[k] * (unsigned)a.inElemStride, G.line0 + line, (int)idx[k]);
+                }
             } else {
 #pragma unroll
                 for (int k = 0; k < R; ++k) x[k] = lb[idx[k]];
@@ -430,7 +468,9 @@ __global__ void __launch_bounds__(NF_FFT_MAXTHREADS) k_fft_cols(nf::LineArgs<T> 
                 cpx<T> v;
                 if (i < p.n) {
                     const unsigned off = (unsigned)(G.line0 + G.tl) * (unsigned)a.inLineStride + (unsigned)i * (unsigned)a.inElemStride;
-                    v = cmul(load_elem<T, 0>(a, G.inP, off, 1.0, i), p.chirp[i]);
+                    v = load_elem<T, 0>(a, G.inP, off, 1.0, i);
+                    if (a.fused) v = fused_ops<T>(a, G, v, off, G.line0 + G.tl, i);
+                    v = cmul(v, p.chirp[i]);
                 } else {
                     v.x = 0;
                     v.y = 0;
@@ -682,7 +722,8 @@ int launch_lines(const LineArgs<T>& a, bool cols, int batch, int threads, hipStr
     const double inB = a.inType == 0 ? sizeof(cpx<T>) : (a.inType == 1 ? 8.0 : 4.0);
     const double outB = a.outType == 0 ? sizeof(cpx<T>) : (a.outType == 1 ? 8.0 : 4.0);
     const int tag = sizeof(T) == 8 ? (cols ? PT_FFT_COLS_F64 : PT_FFT_ROWS_F64) : (cols ? PT_FFT_COLS_F32 : PT_FFT_ROWS_F32);
-    ProfScope ps(tag, stream, npixTotal * (inB + outB));
+    const double fusedIn = cols ? ((a.nSum > 1 ? a.nSum : 1) * (inB + (a.mulF32 ? 4.0 : 0.0))) : inB;
+    ProfScope ps(tag, stream, npixTotal * (fusedIn + outB));
     int mode = a.plan.bluestein ? 2 : 0;
     for (int s = 0; s < a.plan.nst; ++s)
         if (a.plan.st[s].R > 8) mode = 1;
@@ -823,9 +864,17 @@ int Plan2D<T>::forward(const void* in, int inType, void* out, int batch, const d
 // size, may alias `in` if the caller allows clobbering) -> out (complex<T>, or real part as f64 / f32).
 template <typename T>
 int Plan2D<T>::inverse(const void* in, void* work, void* out, int outType, int batch, int scaleDiv, double scale,
-                       hipStream_t stream) {
+                       hipStream_t stream, const float* filt, int nSum, long long filtBatchStride, const double* winY,
+                       const double* winX) {
     LineArgs<T> c = col_args<T>(*this, in, work);
     c.conjInSign = -1.0;  // conj(FFT(conj x)): the conj between the two passes cancels, so only the ends matter
+    c.mulF32 = filt;
+    c.mulBatchStride = filtBatchStride;
+    c.nSum = nSum < 1 ? 1 : nSum;
+    c.sumStride = (long long)H * W;
+    c.winLine = winX;
+    c.winElem = winY;
+    c.fused = (filt != nullptr || winY != nullptr) ? 1 : 0;
     int rc = launch_lines<T>(c, true, batch, threadsCol, stream);
     if (rc) return rc;
     LineArgs<T> a = row_args<T>(*this, work, out, 0, outType);

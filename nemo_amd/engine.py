@@ -143,11 +143,17 @@ class TileEngine(object):
                                        1 if unitary else 0, stream_ptr()), "nf_fft2_forward")
         return out.reshape(x.shape)
 
-    def ifft(self, X, out='complex', unitary=False, clobber=False):
-        """enmap.ifft; ``out`` in {'complex', 'f64', 'f32'} (the latter two keep the real part only)."""
+    def ifft(self, X, out='complex', unitary=False, clobber=False, filt=None, sum=False, window=None):
+        """enmap.ifft; ``out`` in {'complex', 'f64', 'f32'} (the latter two keep the real part only).
+
+        ``filt`` (float32 [N,H,W] or [H,W]) and ``window`` (power of the pixel window) are multiplied in while the
+        transform loads its input (nemo/filters.py:847 and enmap.apply_window); with ``sum`` the N planes of X are summed
+        after the product and one map comes out."""
         t = self.t
         X3 = X.reshape(-1, self.H, self.W)
         prec = prec_of(X3)
+        if filt is not None or window is not None:
+            return self._ifft_fused(X3, X.shape, out, unitary, clobber, filt, sum, window)
         work = X3 if clobber else t.empty_like(X3)
         if out == 'complex':
             res = t.empty_like(X3)
@@ -161,6 +167,40 @@ class TileEngine(object):
         check(self.lib.nf_fft2_inverse(self.plan, prec, ptr(X3), ptr(work), ptr(res), outType, X3.shape[0],
                                        1 if unitary else 0, stream_ptr()), "nf_fft2_inverse")
         return res.reshape(X.shape)
+
+    def _ifft_fused(self, X3, shape, out, unitary, clobber, filt, sum, window):
+        t = self.t
+        prec = prec_of(X3)
+        N = X3.shape[0]
+        nSum = N if sum else 1
+        batch = 1 if sum else N
+        f3 = None
+        perBatch = 0
+        if filt is not None:
+            f3 = filt.reshape(-1, self.H, self.W)
+            if f3.dtype != t.float32 or not f3.is_contiguous():
+                raise NemoFiltError("the fused filter must be a contiguous float32 tensor")
+            if f3.shape[0] not in (1, N) or (sum and f3.shape[0] != N):
+                raise NemoFiltError("filter cube and Fourier cube have different numbers of planes")
+            perBatch = 1 if (not sum and f3.shape[0] == N and N > 1) else 0
+        wy = wx = None
+        if window is not None:
+            wy, wx = self.window(window)
+        cdt = X3.dtype
+        outShape = (1, self.H, self.W) if sum else tuple(X3.shape)
+        work = X3 if clobber else t.empty(outShape, dtype=cdt, device=self.dev)
+        if out == 'complex':
+            res, outType = t.empty(outShape, dtype=cdt, device=self.dev), IN_COMPLEX
+        elif out == 'f64':
+            res, outType = t.empty(outShape, dtype=t.float64, device=self.dev), IN_REAL64
+        else:
+            res, outType = t.empty(outShape, dtype=t.float32, device=self.dev), IN_REAL32
+        check(self.lib.nf_fft2_inverse_fused(self.plan, prec, ptr(X3), ptr(f3), nSum, perBatch, ptr(wy), ptr(wx), ptr(work),
+                                             ptr(res), outType, batch, 1 if unitary else 0, stream_ptr()),
+              "nf_fft2_inverse_fused")
+        if sum:
+            return res.reshape(self.H, self.W)
+        return res.reshape(shape)
 
     # ---- Fourier-domain pointwise --------------------------------------------------------------------------
     def cross_power(self, F):
@@ -210,8 +250,7 @@ class TileEngine(object):
     def apply_window(self, m, pow):
         """enmap.apply_window(m, pow): real [H,W] map in, real map of the same dtype out."""
         F = self.fft(m, unitary=True)
-        self.window_mul_(F, pow)
-        return self.ifft(F, out='f64' if m.dtype == self.t.float64 else 'f32', unitary=True, clobber=True)
+        return self.ifft(F, out='f64' if m.dtype == self.t.float64 else 'f32', unitary=True, clobber=True, window=pow)
 
     # ---- templates -----------------------------------------------------------------------------------------
     def paint(self, geom, table):

@@ -355,13 +355,17 @@ class MatchedFilter(MapFilter):
                     shared[('noiseCov', method)] = noiseCov
 
             w = self._frequencyWeights()                                          # :587-608
-            fSignals = t.stack([eng.fft(self._paintTemplate(m['beamFileName']))   # :611-618  K20+K2
-                                for m in self.unfilteredMapsDictList])
+            fSignals = [eng.fft(self._paintTemplate(m['beamFileName'])) for m in self.unfilteredMapsDictList]   # :611-618
+            fSignals = t.stack(fSignals) if N > 1 else fSignals[0].reshape(1, *self.shape)
             self._dFilt = eng.build_filter(noiseCov, fSignals, w)                 # :621-627  K6
-            del fSignals, noiseCov
+            del noiseCov
 
             if self.params['outputUnits'] == 'yc':                                # :632-668
                 y0 = 2e-4
+                # The reference pushes the amplitude-scaled template through enmap.apply_window (FFT . W . IFFT, :644)
+                # and transforms it again (:646).  FFT(template) . W is Hermitian, so that inverse / forward pair is the
+                # identity up to float32 round-off: here the window is multiplied into the spectrum directly, together
+                # with the filter, while the inverse transform of :847 loads it.
                 fSignalMaps = []
                 for mapDict in self.unfilteredMapsDictList:
                     if mapDict['units'] == 'yc':
@@ -369,10 +373,9 @@ class MatchedFilter(MapFilter):
                     else:
                         deltaT0 = maps.convertToDeltaT(y0, mapDict['obsFreqGHz'])
                         signalMap = self._paintTemplate(mapDict['beamFileName'], amplitude=deltaT0)
-                    signalMap = eng.apply_window(signalMap, 1.0)                   # :644  K8
-                    fSignalMaps.append(eng.fft(signalMap))
-                fSignalMaps = t.stack(fSignalMaps)
-                filteredSignal = self._applyFilterDevice(fSignalMaps)
+                    fSignalMaps.append(eng.fft(signalMap))                         # :644-646  K8
+                fSignalMaps = t.stack(fSignalMaps) if N > 1 else fSignalMaps[0].reshape(1, *self.shape)
+                filteredSignal = self._applyFilterDevice(fSignalMaps, window=1.0)
                 cRADeg, cDecDeg = self.wcs.getCentreWCSCoords()
                 cx, cy = self.wcs.wcs2pix(cRADeg, cDecDeg)
                 peakFilteredSignal = eng.spline_eval(filteredSignal, [[cy, cx]])[0]             # :654-657  K9
@@ -380,20 +383,24 @@ class MatchedFilter(MapFilter):
                 maxValue, maxIndex = eng.map_max(filteredSignal)                  # :661
                 totalSignal = np.float32(maxValue)
                 self.fRelWeights = {}
-                for i, mapDict in enumerate(self.unfilteredMapsDictList):         # :662-667
-                    plane = eng.ifft(eng.apply_filter(fSignalMaps[i:i + 1], self._dFilt[i:i + 1]), out='f32')
-                    planeValue = np.float32(plane.reshape(-1)[maxIndex].item())
-                    self.fRelWeights[mapDict['obsFreqGHz']] = planeValue / totalSignal
+                bckSub = 'bckSub' in self.params.keys() and 'bckSubScaleArcmin' in self.params.keys() and self.params['bckSub'] == True
+                if N == 1 and not bckSub:
+                    # one frequency, no background subtraction: the per-frequency plane of :662 is the filtered signal itself
+                    self.fRelWeights[self.unfilteredMapsDictList[0]['obsFreqGHz']] = totalSignal / totalSignal
+                else:
+                    planes = eng.ifft(fSignalMaps, out='f32', filt=self._dFilt, window=1.0)       # :662-667
+                    vals = planes.reshape(N, -1)[:, maxIndex].cpu().numpy()
+                    for i, mapDict in enumerate(self.unfilteredMapsDictList):
+                        self.fRelWeights[mapDict['obsFreqGHz']] = np.float32(vals[i]) / totalSignal
                 del fSignalMaps
             elif self.params['outputUnits'] == 'uK':                              # :669-685
-                fSignalMaps = t.stack([eng.fft(self._paintTemplate(m['beamFileName']))
-                                       for m in self.unfilteredMapsDictList])
-                filteredSignal = self._applyFilterDevice(fSignalMaps)
+                # the reference paints and transforms the unit templates a second time (:672-679): same values as fSignals
+                filteredSignal = self._applyFilterDevice(fSignals)
                 maxValue, maxIndex = eng.map_max(filteredSignal)
                 self.signalNorm = np.float32(1.0) / np.float32(maxValue)
-                del fSignalMaps
             else:
                 raise Exception('need to specify "outputUnits" ("yc" or "uK") in filter params')
+            del fSignals
         else:
             print("... loading cached filter")
             if self._dFilt is None or haveFile:
@@ -471,9 +478,11 @@ class MatchedFilter(MapFilter):
         raise NotImplementedError("reshapeFilter (nemo/filters.py:793-817) is only reached when map and filter shapes "
                                   "differ; not part of this build yet")
 
-    def _applyFilterDevice(self, cube, scale=True):
+    def _applyFilterDevice(self, cube, scale=True, window=None):
         """Device form of applyFilter: complex (Fourier) or real [N,H,W] tensor in, float32 [H,W] map out; with
-        ``scale`` the map is multiplied by signalNorm exactly as nemo/filters.py:853 does (numpy promotion)."""
+        ``scale`` the map is multiplied by signalNorm exactly as nemo/filters.py:853 does (numpy promotion).  The
+        product with the filter, the frequency sum (moved in front of the inverse transform, which is linear) and an
+        optional pixel-window factor are applied while the inverse transform loads the Fourier planes."""
         eng = self.engine
         t = engine.torch()
         if tuple(cube.shape[-2:]) != self.shape:
@@ -482,8 +491,8 @@ class MatchedFilter(MapFilter):
             fMaps = cube
         else:
             fMaps = eng.fft(cube, apod=True)                                      # :845
-        G = eng.apply_filter(fMaps.reshape(-1, *self.shape), self._dFilt, sum=True)             # K7
-        out = eng.ifft(G, out='f32', unitary=False, clobber=True)                 # :847  K3
+        out = eng.ifft(fMaps.reshape(-1, *self.shape), out='f32', unitary=False, filt=self._dFilt, sum=True,
+                       window=window)                                            # :847  K7 + K3
         if 'bckSub' in self.params.keys() and 'bckSubScaleArcmin' in self.params.keys() and self.params['bckSub'] == True:
             out = maps.subtractBackground(out, self.wcs, smoothScaleDeg=self.params['bckSubScaleArcmin'] / 60.)   # :850-851
         if scale:

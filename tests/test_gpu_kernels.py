@@ -104,6 +104,43 @@ def test_cross_power_gauss_build_apply(dtype, N):
     assert np.abs(Gp - F * rf).max() <= (1e-15 if dtype == np.float64 else 1e-6) * np.abs(refG).max()
 
 
+@pytest.mark.parametrize("shape", [(96, 120), (64, 1031), (840, 1440)])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("N", [1, 3])
+def test_fused_inverse(shape, dtype, N):
+    """nf_fft2_inverse_fused: filter product, frequency sum and pixel-window factor folded into the inverse transform's
+    load - against the separate numpy statements (nemo/filters.py:847, enmap.apply_window)."""
+    rng = np.random.default_rng(21)
+    eng = _eng(shape)
+    ctype = np.complex128 if dtype == np.float64 else np.complex64
+    F = (rng.standard_normal((N,) + shape) + 1j * rng.standard_normal((N,) + shape)).astype(ctype)
+    filt = rng.standard_normal((N,) + shape).astype(np.float32)
+    wy = np.sinc(np.fft.fftfreq(shape[0]))
+    wx = np.sinc(np.fft.fftfreq(shape[1]))
+    win = wy[:, None] * wx[None, :]
+    tol = 1e-12 if dtype == np.float64 else 3e-5
+    dF, dfilt = engine.to_dev(F), engine.to_dev(filt)
+    # filter + sum (the matched-filter application)
+    ref = np.real(enmap.ifft(F * filt, normalize=False)).sum(axis=0)
+    got = _np(eng.ifft(dF, out='f64' if dtype == np.float64 else 'f32', filt=dfilt, sum=True))
+    assert got.shape == shape
+    assert np.abs(got - ref).max() <= tol * np.abs(ref).max()
+    # window + filter + sum (the normalisation path), complex output
+    ref = enmap.ifft(F * win * filt, normalize=False).sum(axis=0)
+    got = _np(eng.ifft(dF, out='complex', filt=dfilt, sum=True, window=1.0))
+    assert np.abs(got - ref).max() <= tol * np.abs(ref).max()
+    # per-plane products (fRelWeights), unitary scaling
+    ref = enmap.ifft(F * filt)
+    got = _np(eng.ifft(dF, out='complex', unitary=True, filt=dfilt))
+    assert got.shape == F.shape
+    assert np.abs(got - ref).max() <= tol * np.abs(ref).max()
+    # window only (pixel-window undo); the input must survive when clobber is off
+    ref = np.real(enmap.ifft(F * win ** -1.0))
+    got = _np(eng.ifft(dF, out='f64' if dtype == np.float64 else 'f32', unitary=True, window=-1.0))
+    assert np.abs(got - ref).max() <= tol * np.abs(ref).max()
+    assert np.array_equal(_np(dF), F)
+
+
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_gaussian_filter_and_background(dtype):
     shape = (211, 256)

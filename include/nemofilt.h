@@ -105,6 +105,11 @@ int nf_paint_radial(float* out_d, int H, int W, const double* A_d, const double*
  * float64 scalar, 'yc') or float32 (vtype NF_F32: 'uK').  psMask_d may be NULL. */
 int nf_scale_mask(int vtype, const float* in_d, void* out_d, double signalNorm, const unsigned char* psMask_d,
                   long long n, void* stream);
+/* The same with the normalisation read from device memory (one float64; for NF_F32 maps it holds the float32-rounded
+ * value): lets the caller keep signalNorm = y0 / peak (nemo/filters.py:659) or 1 / max (:684) on the device and go on
+ * enqueueing work without waiting for it. */
+int nf_scale_mask_dev(int vtype, const float* in_d, void* out_d, const double* signalNorm_d, const unsigned char* psMask_d,
+                      long long n, void* stream);
 
 /* MapFilter.makeNoiseMap, grid mode (nemo/filters.py:407-478): local clipped RMS in ny x nx cells (edges as
  * np.linspace(..., dtype=int), device int arrays of ny+1 / nx+1 entries), each widened by `overlap` pixels,

@@ -290,7 +290,17 @@ int nf_scale_mask(int vtype, const float* in, void* out, double norm, const unsi
         return NF_ERR_ARG;
     }
     nf::ProfScope ps(nf::PT_SCALE_MASK, S(stream), (double)n * (4.0 + (vtype == NF_F32 ? 4.0 : 8.0) + (psMask ? 1.0 : 0.0)));
-    return nf::scale_mask(vtype, in, out, norm, psMask, n, S(stream));
+    return nf::scale_mask(vtype, in, out, norm, nullptr, psMask, n, S(stream));
+}
+
+int nf_scale_mask_dev(int vtype, const float* in, void* out, const double* norm_d, const unsigned char* psMask, long long n,
+                      void* stream) {
+    if (!in || !out || !norm_d || n < 1) {
+        nf_set_error("nf_scale_mask_dev: bad arguments");
+        return NF_ERR_ARG;
+    }
+    nf::ProfScope ps(nf::PT_SCALE_MASK, S(stream), (double)n * (4.0 + (vtype == NF_F32 ? 4.0 : 8.0) + (psMask ? 1.0 : 0.0)));
+    return nf::scale_mask(vtype, in, out, 1.0, norm_d, psMask, n, S(stream));
 }
 
 size_t nf_noise_workspace_bytes(int ny, int nx, int numBins) {

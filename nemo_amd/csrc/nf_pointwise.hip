@@ -310,8 +310,9 @@ int paint_radial(float* out, int H, int W, const double* A, const double* B, con
 // filtered(VT) = float32 map * signalNorm * psMask.  VT = double when signalNorm is a float64 scalar
 // ('yc' mode under numpy >= 2 promotion), float when it is a float32 scalar ('uK' mode).
 template <typename VT>
-__global__ void k_scale_mask(const float* __restrict__ in, VT* __restrict__ out, double norm, const unsigned char* __restrict__ psMask,
-                             long long n) {
+__global__ void k_scale_mask(const float* __restrict__ in, VT* __restrict__ out, double norm, const double* __restrict__ normDev,
+                             const unsigned char* __restrict__ psMask, long long n) {
+    if (normDev != nullptr) norm = *normDev;      // normalisation left on the device by the caller (no host round trip)
     for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x) {
         VT v = (VT)in[p] * (VT)norm;
         if (psMask != nullptr) v = v * (VT)psMask[p];
@@ -319,12 +320,13 @@ __global__ void k_scale_mask(const float* __restrict__ in, VT* __restrict__ out,
     }
 }
 
-int scale_mask(int vtype, const float* in, void* out, double norm, const unsigned char* psMask, long long n, hipStream_t s) {
+int scale_mask(int vtype, const float* in, void* out, double norm, const double* normDev, const unsigned char* psMask,
+               long long n, hipStream_t s) {
     dim3 g(grid_for(n, 256)), b(256);
     if (vtype == NF_F64)
-        hipLaunchKernelGGL(k_scale_mask<double>, g, b, 0, s, in, (double*)out, norm, psMask, n);
+        hipLaunchKernelGGL(k_scale_mask<double>, g, b, 0, s, in, (double*)out, norm, normDev, psMask, n);
     else
-        hipLaunchKernelGGL(k_scale_mask<float>, g, b, 0, s, in, (float*)out, norm, psMask, n);
+        hipLaunchKernelGGL(k_scale_mask<float>, g, b, 0, s, in, (float*)out, norm, normDev, psMask, n);
     NF_CHECK_LAUNCH("k_scale_mask");
     return NF_OK;
 }

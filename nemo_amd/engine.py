@@ -40,6 +40,9 @@ def ptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
+_PINNED_COPY_MAX = 4 << 20
+
+
 def to_dev(x, dtype=None):
     """numpy array or torch tensor -> contiguous tensor on the current HIP device."""
     t = torch()
@@ -50,7 +53,12 @@ def to_dev(x, dtype=None):
         a = np.ascontiguousarray(x)
         if a.dtype == np.bool_:
             a = a.astype(np.uint8)
-        out = t.from_numpy(a).to(dev)
+        if 0 < a.nbytes <= _PINNED_COPY_MAX:
+            # small tables (profiles, grid edges, evaluation points): through pinned memory and asynchronously, because a
+            # pageable copy makes the host wait for everything already queued on the stream
+            out = t.from_numpy(a).pin_memory().to(dev, non_blocking=True)
+        else:
+            out = t.from_numpy(a).to(dev)
     if dtype is not None and out.dtype != dtype:
         out = out.to(dtype)
     return out.contiguous()
@@ -72,6 +80,23 @@ def gaussian_kernel1d(sigma, truncate=4.0):
     x = np.arange(-radius, radius + 1)
     phi = np.exp(-0.5 / (sd * sd) * x ** 2)
     return phi / phi.sum(), radius
+
+
+class DeviceScalar(object):
+    """A float64 / float32 scalar that lives on the device until somebody needs it on the host (``value``): keeps the
+    host from waiting for the GPU in the middle of a filter build.  ``wide`` = numpy float64 semantics (else float32)."""
+
+    def __init__(self, tensor, wide):
+        self.tensor = tensor          # float64 tensor with one element (holds the float32-rounded value if not wide)
+        self.wide = wide
+        self._host = None
+
+    @property
+    def value(self):
+        if self._host is None:
+            v = float(self.tensor.reshape(-1)[0].item())
+            self._host = np.float64(v) if self.wide else np.float32(v)
+        return self._host
 
 
 class TileEngine(object):
@@ -109,6 +134,7 @@ class TileEngine(object):
         self._win = {}
         self._gauss = {}
         self._geom = {}
+        self._geom2 = {}
 
     # ---- tables --------------------------------------------------------------------------------------------
     def window(self, pow):
@@ -273,6 +299,12 @@ class TileEngine(object):
     # ---- real-space tail -----------------------------------------------------------------------------------
     def scale_mask(self, m32, signalNorm, psMask):
         t = self.t
+        if isinstance(signalNorm, DeviceScalar):
+            wide = signalNorm.wide
+            out = t.empty((self.H, self.W), dtype=t.float64 if wide else t.float32, device=self.dev)
+            check(self.lib.nf_scale_mask_dev(NF_F64 if wide else NF_F32, ptr(m32), ptr(out), ptr(signalNorm.tensor), ptr(psMask),
+                                             self.npix, stream_ptr()), "nf_scale_mask_dev")
+            return out
         # numpy >= 2 promotion: float32 array * np.float64 scalar -> float64; * Python float / np.float32 -> float32
         wide = isinstance(signalNorm, np.float64)
         vt = NF_F64 if wide else NF_F32
@@ -319,7 +351,10 @@ class TileEngine(object):
             return rms
         wbytes = self.lib.nf_noise_workspace_bytes(ncy, ncx, nb)
         work = t.empty(wbytes // 8 + 1, dtype=t.float64, device=self.dev)
-        yE, xE = to_dev(yEdges), to_dev(xEdges)
+        key = ('noiseEdges', yEdges.tobytes(), xEdges.tobytes())
+        if key not in self._geom2:
+            self._geom2[key] = (to_dev(yEdges), to_dev(xEdges))
+        yE, xE = self._geom2[key]
         check(self.lib.nf_noise_map(prec_of(filtered), ptr(filtered), ptr(medWeights), prec_of(medWeights), ptr(rms),
                                     self.H, self.W, ncy, ncx, ptr(yE), ptr(xE), overlap, nb, quant, 0, ptr(work),
                                     work.numel() * 8, stream_ptr()), "nf_noise_map")
@@ -390,15 +425,18 @@ class TileEngine(object):
               "nf_ring_flags")
         return isRing
 
-    def map_max(self, m):
-        """(max value, flat index of its first occurrence) of a device map."""
+    def map_max(self, m, to_host=True):
+        """(max value, flat index of its first occurrence) of a device map; with ``to_host=False`` the two stay on the
+        device (float64 tensor of 2 elements) and the call does not wait for the GPU."""
         t = self.t
         out = t.empty(4 + 2 * 2048, dtype=t.float64, device=self.dev)      # NF_MAP_MAX_DOUBLES
         check(self.lib.nf_map_max(prec_of(m), ptr(m), m.numel(), ptr(out), stream_ptr()), "nf_map_max")
+        if not to_host:
+            return out[:2]
         res = out[:2].cpu().numpy()
         return res[0], int(res[1])
 
-    def spline_eval(self, m, yx, negate=False, halfWin=32):
+    def spline_eval(self, m, yx, negate=False, halfWin=32, to_host=True):
         t = self.t
         yx = np.ascontiguousarray(np.asarray(yx, dtype=np.float64).reshape(-1, 2))
         if len(yx) == 0:
@@ -407,4 +445,6 @@ class TileEngine(object):
         out = t.empty(len(yx), dtype=t.float64, device=self.dev)
         check(self.lib.nf_spline_eval(prec_of(m), ptr(m), 1 if negate else 0, self.H, self.W, ptr(yx_d), len(yx), halfWin,
                                       ptr(out), stream_ptr()), "nf_spline_eval")
+        if not to_host:
+            return out
         return out.cpu().numpy()

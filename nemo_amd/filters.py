@@ -190,6 +190,17 @@ class MapFilter(object):
         return self._radiansMap
 
     @property
+    def signalNorm(self):
+        """Filter normalisation as the reference holds it (a numpy / Python float).  During a build it may still be on
+        the device (engine.DeviceScalar); reading it here waits for the GPU once."""
+        v = self._signalNorm
+        return v.value if isinstance(v, engine.DeviceScalar) else v
+
+    @signalNorm.setter
+    def signalNorm(self, value):
+        self._signalNorm = value
+
+    @property
     def flagMask(self):
         """Combined flag mask as the reference holds it: numpy int array [H, W] (nemo/filters.py:165-168)."""
         if self._flagMaskHost is None:
@@ -378,16 +389,18 @@ class MatchedFilter(MapFilter):
                 filteredSignal = self._applyFilterDevice(fSignalMaps, window=1.0)
                 cRADeg, cDecDeg = self.wcs.getCentreWCSCoords()
                 cx, cy = self.wcs.wcs2pix(cRADeg, cDecDeg)
-                peakFilteredSignal = eng.spline_eval(filteredSignal, [[cy, cx]])[0]             # :654-657  K9
-                self.signalNorm = np.float64(y0) / np.float64(peakFilteredSignal)
-                maxValue, maxIndex = eng.map_max(filteredSignal)                  # :661
-                totalSignal = np.float32(maxValue)
+                # signalNorm = y0 / peak stays on the device (float64 division there): the host goes on enqueueing
+                peak = eng.spline_eval(filteredSignal, [[cy, cx]], to_host=False)                # :654-657  K9
+                self._signalNorm = engine.DeviceScalar(float(y0) / peak.to(t.float64), wide=True)   # :659
                 self.fRelWeights = {}
                 bckSub = 'bckSub' in self.params.keys() and 'bckSubScaleArcmin' in self.params.keys() and self.params['bckSub'] == True
                 if N == 1 and not bckSub:
-                    # one frequency, no background subtraction: the per-frequency plane of :662 is the filtered signal itself
-                    self.fRelWeights[self.unfilteredMapsDictList[0]['obsFreqGHz']] = totalSignal / totalSignal
+                    # one frequency, no background subtraction: the per-frequency plane of :662 is the filtered signal
+                    # itself, so the relative weight is a float32 value divided by itself
+                    self.fRelWeights[self.unfilteredMapsDictList[0]['obsFreqGHz']] = np.float32(1.0)
                 else:
+                    maxValue, maxIndex = eng.map_max(filteredSignal)              # :661
+                    totalSignal = np.float32(maxValue)
                     planes = eng.ifft(fSignalMaps, out='f32', filt=self._dFilt, window=1.0)       # :662-667
                     vals = planes.reshape(N, -1)[:, maxIndex].cpu().numpy()
                     for i, mapDict in enumerate(self.unfilteredMapsDictList):
@@ -396,8 +409,8 @@ class MatchedFilter(MapFilter):
             elif self.params['outputUnits'] == 'uK':                              # :669-685
                 # the reference paints and transforms the unit templates a second time (:672-679): same values as fSignals
                 filteredSignal = self._applyFilterDevice(fSignals)
-                maxValue, maxIndex = eng.map_max(filteredSignal)
-                self.signalNorm = np.float32(1.0) / np.float32(maxValue)
+                mm = eng.map_max(filteredSignal, to_host=False)                   # :684, float32 arithmetic, on the device
+                self._signalNorm = engine.DeviceScalar((1.0 / mm[:1].to(t.float32)).to(t.float64), wide=False)
             else:
                 raise Exception('need to specify "outputUnits" ("yc" or "uK") in filter params')
             del fSignals
@@ -413,7 +426,7 @@ class MatchedFilter(MapFilter):
         filtered32 = self._applyFilterDevice(fMapsToFilter, scale=False)
         del fMapsToFilter
         mapUnits, combinedObsFreqGHz, beamSolidAngle_nsr = self._unitsInfo()
-        dFiltered = eng.scale_mask(filtered32, self.signalNorm, self._dPSMask)
+        dFiltered = eng.scale_mask(filtered32, self._signalNorm, self._dPSMask)
 
         if 'edgeTrimArcmin' in self.params.keys() and self.params['edgeTrimArcmin'] > 0:      # :725-733
             trimSizePix = int(round((self.params['edgeTrimArcmin'] / 60.) / self.wcs.getPixelSizeDeg()))

@@ -285,17 +285,20 @@ def _pairsWithin(RA1, dec1, RA2, dec2, radiusDeg, inclusive=False):
     if len(RA1) == 0 or len(RA2) == 0:
         return np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64)
     chord = 2.0 * np.sin(np.radians(radiusDeg) / 2.0) * 1.001 + 1e-12
+    sameSets = len(RA1) == len(RA2) and np.array_equal(np.asarray(RA1), np.asarray(RA2)) and \
+        np.array_equal(np.asarray(dec1), np.asarray(dec2))
     t1 = cKDTree(_unitVectors(RA1, dec1))
-    t2 = cKDTree(_unitVectors(RA2, dec2))
-    sp = t1.sparse_distance_matrix(t2, chord, output_type='coo_matrix')
-    i, j = sp.row.astype(np.int64), sp.col.astype(np.int64)
-    # zero-distance pairs are dropped by the sparse format: identical positions (incl. a row with itself) are added back
-    if len(RA1) == len(RA2) and np.array_equal(np.asarray(RA1), np.asarray(RA2)) and np.array_equal(np.asarray(dec1), np.asarray(dec2)):
-        pairs = t1.query_pairs(1e-15, output_type='ndarray')
+    if sameSets:
+        # a set against itself: unordered pairs from one tree (zero distances included), mirrored, plus every row with itself
+        pairs = t1.query_pairs(chord, output_type='ndarray').astype(np.int64)
         selfIdx = np.arange(len(RA1), dtype=np.int64)
-        i = np.concatenate([i, selfIdx, pairs[:, 0], pairs[:, 1]])
-        j = np.concatenate([j, selfIdx, pairs[:, 1], pairs[:, 0]])
+        i = np.concatenate([selfIdx, pairs[:, 0], pairs[:, 1]])
+        j = np.concatenate([selfIdx, pairs[:, 1], pairs[:, 0]])
     else:
+        t2 = cKDTree(_unitVectors(RA2, dec2))
+        sp = t1.sparse_distance_matrix(t2, chord, output_type='coo_matrix')
+        i, j = sp.row.astype(np.int64), sp.col.astype(np.int64)
+        # zero-distance pairs are dropped by the sparse format: identical positions are added back
         zi = t1.query_ball_tree(t2, 1e-15)
         zp = [(a, b) for a, lst in enumerate(zi) for b in lst]
         if len(zp) > 0:
@@ -303,11 +306,22 @@ def _pairsWithin(RA1, dec1, RA2, dec2, radiusDeg, inclusive=False):
             i = np.concatenate([i, zp[:, 0]])
             j = np.concatenate([j, zp[:, 1]])
     if len(i) > 0:
-        key = np.unique(i * np.int64(len(RA2)) + j)
+        key = i * np.int64(len(RA2)) + j
+        key = np.sort(key) if sameSets else np.unique(key)      # (i, j) pairs of the self-match are already distinct
         i, j = key // np.int64(len(RA2)), key % np.int64(len(RA2))
-    r = calcAngSepDeg(np.asarray(RA1, dtype=np.float64)[i], np.asarray(dec1, dtype=np.float64)[i],
-                      np.asarray(RA2, dtype=np.float64)[j], np.asarray(dec2, dtype=np.float64)[j])
-    ok = (r <= radiusDeg) if inclusive else (r < radiusDeg)
+    # Decision by the exact great-circle formula (what the reference evaluates) - but only for the pairs whose chord is
+    # within 1e-9 (relative) of the limit; the chord of two unit vectors is good to ~1e-12 of it, so the others are decided.
+    u1 = _unitVectors(RA1, dec1)
+    u2 = u1 if sameSets else _unitVectors(RA2, dec2)
+    d = u1[i] - u2[j]
+    chord2 = np.einsum('ij,ij->i', d, d)
+    lim = 2.0 * np.sin(np.radians(radiusDeg) / 2.0)
+    ok = chord2 < (lim * (1.0 - 1e-9)) ** 2
+    near = np.flatnonzero(~ok & (chord2 <= (lim * (1.0 + 1e-9)) ** 2))
+    if len(near) > 0:
+        r = calcAngSepDeg(np.asarray(RA1, dtype=np.float64)[i[near]], np.asarray(dec1, dtype=np.float64)[i[near]],
+                          np.asarray(RA2, dtype=np.float64)[j[near]], np.asarray(dec2, dtype=np.float64)[j[near]])
+        ok[near] = (r <= radiusDeg) if inclusive else (r < radiusDeg)
     return i[ok], j[ok]
 
 
@@ -317,11 +331,16 @@ def _bestPerGroup(i, j, SNR, n):
     count = np.bincount(i, minlength=n)
     best = np.full(n, -1, dtype=np.int64)
     if len(i) > 0:
-        order = np.lexsort((j, -np.asarray(SNR, dtype=np.float64)[j], i))
-        io, jo = i[order], j[order]
-        first = np.ones(len(io), dtype=bool)
-        first[1:] = io[1:] != io[:-1]
-        best[io[first]] = jo[first]
+        # pairs are sorted by (i, j): segmented maximum of SNR[j], then the first position attaining it (no sort needed)
+        starts = np.flatnonzero(np.concatenate([[True], i[1:] != i[:-1]]))
+        sj = np.asarray(SNR, dtype=np.float64)[j]
+        segMax = np.maximum.reduceat(sj, starts)
+        seg = np.cumsum(np.concatenate([[0], (i[1:] != i[:-1]).astype(np.int64)]))
+        pos = np.where(sj == segMax[seg], np.arange(len(i)), len(i))
+        firstPos = np.minimum.reduceat(pos, starts)
+        ok = firstPos < len(i)                 # a group whose SNRs are all NaN has no maximum position: argmax gives 0
+        firstPos = np.where(ok, firstPos, starts)
+        best[i[starts]] = j[firstPos]
     return count, best
 
 

@@ -50,6 +50,8 @@ SIGNATURES = {
     'nf_noise_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
     'nf_noise_map': (c_int, [c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                              c_int, c_int, ctypes.POINTER(c_double), c_int, c_void_p, c_size_t, c_void_p]),
+    'nf_noise_smart_workspace_bytes': (c_size_t, []),
+    'nf_noise_map_smart': (c_int, [c_int, c_void_p, c_void_p, c_int, c_void_p, c_ll, c_int, c_void_p, c_size_t, c_void_p]),
     'nf_median_stack': (c_int, [c_int, c_void_p, c_void_p, c_int, c_ll, c_void_p]),
     'nf_edge_check': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'nf_finalize': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,

@@ -327,12 +327,25 @@ int nf_noise_map(int vtype, const void* filtered, const void* weights, int wtype
     g.overlap = overlap;
     g.numBins = numBins;
     g.estimator = estimator;
+    g.pctQ = 68.3 / 100.0;      // np.percentile(a, 68.3): q = np.true_divide(68.3, 100)
     g.yEdges = yEdges;
     g.xEdges = xEdges;
     for (int i = 0; i < numBins && quantiles; ++i) g.quantiles[i] = quantiles[i];
     nf::ProfScope ps(nf::PT_NOISE_MAP, S(stream),
                      (double)H * W * ((vtype == NF_F32 ? 4.0 : 8.0) + (wtype == NF_F32 ? 4.0 : 8.0) + 4.0));
     return nf::noise_map(vtype, filtered, weights, wtype, rms, H, W, g, work, workBytes, S(stream));
+}
+
+size_t nf_noise_smart_workspace_bytes(void) { return nf::noise_smart_workspace_bytes(); }
+
+int nf_noise_map_smart(int vtype, const void* filtered, const void* weights, int wtype, float* rms, long long n, int numBins,
+                       void* work, size_t workBytes, void* stream) {
+    if (!filtered || !weights || !rms || !work || n < 1) {
+        nf_set_error("nf_noise_map_smart: bad arguments");
+        return NF_ERR_ARG;
+    }
+    nf::ProfScope ps(nf::PT_NOISE_MAP, S(stream), (double)n * ((vtype == NF_F32 ? 4.0 : 8.0) + (wtype == NF_F32 ? 4.0 : 8.0) + 4.0));
+    return nf::noise_map_smart(vtype, filtered, weights, wtype, rms, n, numBins, work, workBytes, S(stream));
 }
 
 int nf_median_stack(int rtype, const void* in, void* out, int N, long long n, void* stream) {

@@ -41,6 +41,7 @@ struct NoiseGrid {
     int overlap;         // pixels added on each side of a cell
     int numBins;
     int estimator;       // 0: 3-sigma clipped std, 1: 68.3 percentile of |v|
+    double pctQ;         // 68.3 / 100 as numpy forms it (estimator 1)
     const int* yEdges;   // device, ny+1
     const int* xEdges;   // device, nx+1
     double quantiles[16];  // percentile/100 of the lower edge of each weight bin (np.arange(0,100,100/numBins)/100)
@@ -48,6 +49,9 @@ struct NoiseGrid {
 int noise_map(int vtype, const void* filtered, const void* weights, int wtype, float* rms, int H, int W, const NoiseGrid& g,
               void* cellStats, size_t cellStatsBytes, hipStream_t s);
 size_t noise_workspace_bytes(const NoiseGrid& g);
+size_t noise_smart_workspace_bytes();
+int noise_map_smart(int vtype, const void* filtered, const void* weights, int wtype, float* rms, long long n, int numBins,
+                    void* work, size_t workBytes, hipStream_t s);
 int median_stack(int rtype, const void* in, void* out, int N, long long n, hipStream_t s);
 
 // nf_detect.hip

@@ -136,7 +136,7 @@ __global__ void k_noise_cells(const VT* __restrict__ v, const WT* __restrict__ w
                               double* __restrict__ stats) {
     const double* quantiles = g.quantiles;
     __shared__ double red[16];
-    __shared__ unsigned int hist[ONEBIN ? 1 : 2 * NF_MAXBINS][256];
+    __shared__ unsigned int hist[ONEBIN ? 2 : 2 * NF_MAXBINS][256];
     __shared__ unsigned long long prefix[2 * NF_MAXBINS];
     __shared__ unsigned int rankLeft[2 * NF_MAXBINS];
     __shared__ double edges[NF_MAXBINS + 1];
@@ -172,11 +172,11 @@ __global__ void k_noise_cells(const VT* __restrict__ v, const WT* __restrict__ w
             edges[1] = wmax + 1e-6;
         }
     } else if (!ONEBIN) {
-        // ranks needed: floor(vi) and floor(vi)+1 for each quantile, vi = n*q + (1 - q) - 1 (numpy's expression)
+        // ranks needed: floor(vi) and floor(vi)+1 for each quantile, vi = (n - 1) * q (numpy's expression for the 'linear' method)
         const int nr = 2 * nb;
         if (tid < nr) {
             double q = quantiles[tid / 2];
-            double vi = __dsub_rn(__dadd_rn(__dmul_rn(ngood, q), __dsub_rn(1.0, q)), 1.0);
+            double vi = __dmul_rn(__dsub_rn(ngood, 1.0), q);
             double fl = floor(vi);
             long long r = (long long)fl + (tid & 1);
             if (r > (long long)ngood - 1) r = (long long)ngood - 1;
@@ -213,7 +213,7 @@ __global__ void k_noise_cells(const VT* __restrict__ v, const WT* __restrict__ w
         }
         if (tid < nb) {
             double q = quantiles[tid];
-            double vi = __dsub_rn(__dadd_rn(__dmul_rn(ngood, q), __dsub_rn(1.0, q)), 1.0);
+            double vi = __dmul_rn(__dsub_rn(ngood, 1.0), q);
             double t = __dsub_rn(vi, floor(vi));
             double a = unkey(prefix[2 * tid]), b = unkey(prefix[2 * tid + 1]);
             double diff = __dsub_rn(b, a);
@@ -231,6 +231,68 @@ __global__ void k_noise_cells(const VT* __restrict__ v, const WT* __restrict__ w
 #define NF_IN_BIN(val, q) ((val) != 0.0 && (ONEBIN || ((double)wts[q] >= lo && (double)wts[q] < hi)))
     for (int b = 0; b < nb; ++b) {
         const double lo = edges[b], hi = edges[b + 1];
+        if (g.estimator == 1) {
+            // RMSEstimator 'percentile': np.percentile(abs(binValues), 68.3) (nemo/filters.py:459-460), linear method:
+            // the two order statistics around the virtual index by a radix select on the float64 keys of |v|
+            double nn = 0.0;
+            NF_CELL_LOOP(c, ww, wh, {
+                double val = (double)v[q];
+                if (NF_IN_BIN(val, q)) nn += 1.0;
+            })
+            const double n = block_sum(nn, red);
+            if (n == 0.0) {              // percentile of an empty set is NaN: "chunkRMS > 0" fails
+                if (tid == 0) rec[2 + nb + b] = 0.0;
+                continue;
+            }
+            const double q683 = g.pctQ;
+            const double vi = __dmul_rn(__dsub_rn(n, 1.0), q683);
+            __syncthreads();
+            if (tid < 2) {
+                long long r = (long long)floor(vi) + tid;
+                if (r > (long long)n - 1) r = (long long)n - 1;
+                if (r < 0) r = 0;
+                rankLeft[tid] = (unsigned int)r;
+                prefix[tid] = 0ULL;
+            }
+            __syncthreads();
+            for (int shift = 56; shift >= 0; shift -= 8) {
+                for (int i = tid; i < 2 * 256; i += NF_NOISE_THREADS) (&hist[0][0])[i] = 0u;
+                __syncthreads();
+                NF_CELL_LOOP(c, ww, wh, {
+                    double val = (double)v[q];
+                    if (NF_IN_BIN(val, q)) {
+                        unsigned long long key = key_of(fabs(val));
+                        unsigned long long hiBits = (shift == 56) ? 0ULL : (key >> (shift + 8));
+                        unsigned int digit = (unsigned int)((key >> shift) & 0xFFULL);
+                        if (hiBits == prefix[0]) atomicAdd(&hist[0][digit], 1u);
+                        if (hiBits == prefix[1]) atomicAdd(&hist[1][digit], 1u);
+                    }
+                })
+                __syncthreads();
+                if (tid < 2) {
+                    unsigned int left = rankLeft[tid], acc = 0;
+                    int d = 0;
+                    for (; d < 256; ++d) {
+                        unsigned int h = hist[tid][d];
+                        if (left < acc + h) break;
+                        acc += h;
+                    }
+                    rankLeft[tid] = left - acc;
+                    prefix[tid] = (prefix[tid] << 8) | (unsigned long long)d;
+                }
+                __syncthreads();
+            }
+            if (tid == 0) {
+                const double t = __dsub_rn(vi, floor(vi));
+                const double a = unkey(prefix[0]), bb = unkey(prefix[1]);
+                const double diff = __dsub_rn(bb, a);
+                double lerp = __dadd_rn(a, __dmul_rn(diff, t));
+                if (t >= 0.5) lerp = __dsub_rn(bb, __dmul_rn(diff, __dsub_rn(1.0, t)));
+                rec[2 + nb + b] = lerp > 0.0 ? lerp : 0.0;
+            }
+            __syncthreads();
+            continue;
+        }
         double thr = INFINITY;
         double mean = 0.0, rms = 0.0;
         bool have = false;
@@ -383,7 +445,7 @@ k_noise_cells_reg(const VT* __restrict__ v, const WT* __restrict__ wts, int H, i
         const int nr = 2 * nb;
         if (tid < nr) {
             double q = quantiles[tid / 2];
-            double vi = __dsub_rn(__dadd_rn(__dmul_rn(ngood, q), __dsub_rn(1.0, q)), 1.0);
+            double vi = __dmul_rn(__dsub_rn(ngood, 1.0), q);
             double fl = floor(vi);
             long long r = (long long)fl + (tid & 1);
             if (r > (long long)ngood - 1) r = (long long)ngood - 1;
@@ -429,7 +491,7 @@ k_noise_cells_reg(const VT* __restrict__ v, const WT* __restrict__ wts, int H, i
         }
         if (tid < nb) {
             double q = quantiles[tid];
-            double vi = __dsub_rn(__dadd_rn(__dmul_rn(ngood, q), __dsub_rn(1.0, q)), 1.0);
+            double vi = __dmul_rn(__dsub_rn(ngood, 1.0), q);
             double t = __dsub_rn(vi, floor(vi));
             double a = unkey(prefix[2 * tid]), b = unkey(prefix[2 * tid + 1]);
             double diff = __dsub_rn(b, a);
@@ -647,8 +709,8 @@ int noise_map(int vtype, const void* filtered, const void* weights, int wtype, f
         nf_set_error("noise_map: numNoiseBins must be in 1..16");
         return NF_ERR_ARG;
     }
-    if (g.estimator != 0) {
-        nf_set_error("noise_map: only the default clipped-std estimator is implemented on the GPU");
+    if (g.estimator != 0 && g.estimator != 1) {
+        nf_set_error("noise_map: estimator must be 0 (3-sigma clipped standard deviation) or 1 (68.3 percentile of |v|)");
         return NF_ERR_ARG;
     }
     if (cellStatsBytes < noise_workspace_bytes(g)) {
@@ -659,7 +721,7 @@ int noise_map(int vtype, const void* filtered, const void* weights, int wtype, f
     dim3 gc(g.ny * g.nx), bc(NF_NOISE_THREADS);
     // widest possible window: (largest cell + 2 * overlap)^2; cells differ by at most one pixel (np.linspace(dtype=int))
     const long long maxH = (long long)(H / g.ny + 1) + 2LL * g.overlap, maxW = (long long)(W / g.nx + 1) + 2LL * g.overlap;
-    const bool inRegs = (maxH < H ? maxH : H) * (maxW < W ? maxW : W) <= (long long)NF_VPT * NF_REG_THREADS;
+    const bool inRegs = g.estimator == 0 && (maxH < H ? maxH : H) * (maxW < W ? maxW : W) <= (long long)NF_VPT * NF_REG_THREADS;
     if (inRegs) {
         bc = dim3(NF_REG_THREADS);
         gc = dim3(((g.ny * g.nx + 7) / 8) * 8);   // the register kernel permutes cells over the XCDs in groups of 8
@@ -691,6 +753,208 @@ int noise_map(int vtype, const void* filtered, const void* weights, int wtype, f
     else
         hipLaunchKernelGGL(k_noise_paint<float>, gp, dim3(256), 0, s, (const float*)weights, rms, H, W, g, stats);
     NF_CHECK_LAUNCH("k_noise_paint");
+    return NF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// 'smart' mode (nemo/filters.py:363-404): noise measured over areas of similar weight, whole map at once.
+//   binEdges = np.linspace(w.min(), w.max(), numBins); bin i = {binEdges[i] < w < binEdges[i+1]} (strict);
+//   per bin the 3-sigma clipped standard deviation of the valid (non-zero) map values in it; RMSMap[bin] = rms if > 0.
+// Every clipping iteration is one streaming pass over map + weights that accumulates (sum d, sum d^2, n) for all bins
+// at once; per-workgroup partials are summed in a fixed order (deterministic), and the per-bin state (mean, rms,
+// threshold) lives on the device, so the 13 passes are enqueued without a host round trip.
+#define NF_SMART_BLOCKS 1024
+#define NF_SMART_THREADS 256
+#define NF_SMART_MAXB 15          // numNoiseBins <= 16 edges
+
+struct SmartState {               // device-resident, one per call (inside the workspace)
+    double wmin, wmax;
+    double edges[NF_SMART_MAXB + 1];
+    double mean[NF_SMART_MAXB], rms[NF_SMART_MAXB], thr[NF_SMART_MAXB];
+    int have[NF_SMART_MAXB];
+    int numEdges;
+};
+
+template <typename WT>
+__global__ void __launch_bounds__(NF_SMART_THREADS) k_smart_minmax(const WT* __restrict__ w, long long n, double* __restrict__ part) {
+    __shared__ double red[16];
+    double lo = INFINITY, hi = -INFINITY;
+    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x) {
+        const double x = (double)w[p];
+        lo = fmin(lo, x);
+        hi = fmax(hi, x);
+    }
+    lo = block_min(lo, red);
+    __syncthreads();
+    hi = block_max(hi, red);
+    if (threadIdx.x == 0) {
+        part[2 * blockIdx.x] = lo;
+        part[2 * blockIdx.x + 1] = hi;
+    }
+}
+
+__global__ void k_smart_edges(const double* __restrict__ part, int nPart, int numEdges, SmartState* st) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double lo = INFINITY, hi = -INFINITY;
+    for (int k = 0; k < nPart; ++k) {
+        lo = fmin(lo, part[2 * k]);
+        hi = fmax(hi, part[2 * k + 1]);
+    }
+    st->wmin = lo;
+    st->wmax = hi;
+    st->numEdges = numEdges;
+    // np.linspace(start, stop, num): step = (stop - start) / (num - 1); y = arange(num) * step + start; y[-1] = stop
+    const double step = numEdges > 1 ? __ddiv_rn(__dsub_rn(hi, lo), (double)(numEdges - 1)) : 0.0;
+    for (int i = 0; i < numEdges; ++i) st->edges[i] = __dadd_rn(__dmul_rn((double)i, step), lo);
+    if (numEdges > 1) st->edges[numEdges - 1] = hi;
+    for (int b = 0; b < NF_SMART_MAXB; ++b) {
+        st->mean[b] = 0.0;
+        st->rms[b] = 0.0;
+        st->thr[b] = INFINITY;
+        st->have[b] = 0;
+    }
+}
+
+__device__ __forceinline__ int smart_bin(const SmartState* st, double w, int nb) {
+    for (int b = 0; b < nb; ++b)
+        if (w > st->edges[b] && w < st->edges[b + 1]) return b;
+    return -1;
+}
+
+// phase 0: sums of v (about 0) and counts over the valid pixels of each bin; phase 1: sums of (v - mean)^2;
+// phase 2: clipped moments about the current mean.  part: [block][bin][3]
+template <typename VT, typename WT>
+__global__ void __launch_bounds__(NF_SMART_THREADS) k_smart_pass(const VT* __restrict__ v, const WT* __restrict__ w, long long n,
+                                                                  const SmartState* __restrict__ st, int phase,
+                                                                  double* __restrict__ part) {
+    __shared__ double red[48];
+    __shared__ SmartState ls;
+    if (threadIdx.x == 0) ls = *st;
+    __syncthreads();
+    const int nb = ls.numEdges - 1;
+    double s[NF_SMART_MAXB], ss[NF_SMART_MAXB], nn[NF_SMART_MAXB];
+#pragma unroll
+    for (int b = 0; b < NF_SMART_MAXB; ++b) s[b] = ss[b] = nn[b] = 0.0;
+    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x) {
+        const double val = (double)v[p];
+        if (val == 0.0) continue;
+        const int bin = smart_bin(&ls, (double)w[p], nb);
+        if (bin < 0) continue;
+        double d = 0.0, take = 1.0;
+        if (phase == 0) {
+            d = val;
+        } else if (phase == 1) {
+            d = val - ls.mean[bin];
+        } else {
+            d = val - ls.mean[bin];
+            if (!(fabs(val) < ls.thr[bin])) take = 0.0;
+        }
+        if (take != 0.0) {
+#pragma unroll
+            for (int b = 0; b < NF_SMART_MAXB; ++b)
+                if (b == bin) {
+                    s[b] += d;
+                    ss[b] += d * d;
+                    nn[b] += 1.0;
+                }
+        }
+    }
+    for (int b = 0; b < nb; ++b) {
+        double a = s[b], q = ss[b], c = nn[b];
+        block_sum3(a, q, c, red);
+        if (threadIdx.x == 0) {
+            double* o = part + ((long long)blockIdx.x * NF_SMART_MAXB + b) * 3;
+            o[0] = a;
+            o[1] = q;
+            o[2] = c;
+        }
+        __syncthreads();
+    }
+}
+
+// one thread per bin: fixed-order sum of the partials, then the state update of the reference's loop
+__global__ void k_smart_update(const double* __restrict__ part, int nPart, int phase, SmartState* st) {
+    const int b = threadIdx.x;
+    if (b >= st->numEdges - 1) return;
+    double s = 0.0, ss = 0.0, n = 0.0;
+    for (int k = 0; k < nPart; ++k) {
+        const double* o = part + ((long long)k * NF_SMART_MAXB + b) * 3;
+        s += o[0];
+        ss += o[1];
+        n += o[2];
+    }
+    if (phase == 0) {
+        st->have[b] = n > 0.0 ? 1 : 0;              // "np.not_equal(chunkValues, 0).sum() != 0"
+        st->mean[b] = n > 0.0 ? s / n : 0.0;
+    } else if (phase == 1) {
+        if (st->have[b]) {
+            st->rms[b] = sqrt(ss / n);
+            st->thr[b] = fabs(st->mean[b] + 3.0 * st->rms[b]);
+        }
+    } else {
+        if (st->have[b] && n > 0.0) {               // "if mask.sum() > 0"
+            const double dm = s / n;
+            const double var = ss / n - dm * dm;
+            st->mean[b] = st->mean[b] + dm;
+            st->rms[b] = sqrt(var > 0.0 ? var : 0.0);
+            st->thr[b] = fabs(st->mean[b] + 3.0 * st->rms[b]);
+        }
+    }
+}
+
+template <typename WT>
+__global__ void k_smart_paint(const WT* __restrict__ w, float* __restrict__ rmsMap, long long n, const SmartState* __restrict__ st) {
+    __shared__ SmartState ls;
+    if (threadIdx.x == 0) ls = *st;
+    __syncthreads();
+    const int nb = ls.numEdges - 1;
+    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x) {
+        const int bin = smart_bin(&ls, (double)w[p], nb);
+        float out = 0.0f;
+        if (bin >= 0 && ls.have[bin] && ls.rms[bin] > 0.0) out = (float)ls.rms[bin];
+        rmsMap[p] = out;
+    }
+}
+
+size_t noise_smart_workspace_bytes() {
+    return sizeof(SmartState) + 256 + (size_t)NF_SMART_BLOCKS * NF_SMART_MAXB * 3 * sizeof(double);
+}
+
+int noise_map_smart(int vtype, const void* filtered, const void* weights, int wtype, float* rms, long long n, int numBins,
+                    void* work, size_t workBytes, hipStream_t s) {
+    if (numBins < 2 || numBins > NF_SMART_MAXB + 1) {
+        nf_set_error("noise_map_smart: numNoiseBins must be in 2..16");
+        return NF_ERR_ARG;
+    }
+    if (workBytes < noise_smart_workspace_bytes()) {
+        nf_set_error("noise_map_smart: workspace too small");
+        return NF_ERR_SIZE;
+    }
+    SmartState* st = (SmartState*)work;
+    double* part = (double*)((char*)work + ((sizeof(SmartState) + 255) / 256) * 256);
+    long long want = (n + NF_SMART_THREADS * 4LL - 1) / (NF_SMART_THREADS * 4LL);
+    const int nPart = (int)(want < 1 ? 1 : (want > NF_SMART_BLOCKS ? NF_SMART_BLOCKS : want));
+    dim3 g(nPart), b(NF_SMART_THREADS);
+    if (wtype == NF_F64)
+        hipLaunchKernelGGL(k_smart_minmax<double>, g, b, 0, s, (const double*)weights, n, part);
+    else
+        hipLaunchKernelGGL(k_smart_minmax<float>, g, b, 0, s, (const float*)weights, n, part);
+    hipLaunchKernelGGL(k_smart_edges, dim3(1), dim3(1), 0, s, part, nPart, numBins, st);
+    for (int it = 0; it < 12; ++it) {
+        const int phase = it < 2 ? it : 2;
+#define NF_SP(VT, WT) hipLaunchKernelGGL((k_smart_pass<VT, WT>), g, b, 0, s, (const VT*)filtered, (const WT*)weights, n, st, phase, part)
+        if (vtype == NF_F64 && wtype == NF_F64) NF_SP(double, double);
+        else if (vtype == NF_F64 && wtype == NF_F32) NF_SP(double, float);
+        else if (vtype == NF_F32 && wtype == NF_F64) NF_SP(float, double);
+        else NF_SP(float, float);
+#undef NF_SP
+        hipLaunchKernelGGL(k_smart_update, dim3(1), dim3(64), 0, s, part, nPart, phase, st);
+    }
+    if (wtype == NF_F64)
+        hipLaunchKernelGGL(k_smart_paint<double>, g, b, 0, s, (const double*)weights, rms, n, st);
+    else
+        hipLaunchKernelGGL(k_smart_paint<float>, g, b, 0, s, (const float*)weights, rms, n, st);
+    NF_CHECK_LAUNCH("noise_map_smart");
     return NF_OK;
 }
 

@@ -326,11 +326,25 @@ class TileEngine(object):
     def noise_map(self, filtered, medWeights, noiseParams, pixSizeDeg):
         """MapFilter.makeNoiseMap, grid mode (nemo/filters.py:407-478)."""
         t = self.t
-        if noiseParams.get('noiseGridArcmin', None) == "smart":
-            raise NemoFiltError("noiseGridArcmin: 'smart' is not implemented on the GPU path yet")
         estimator = noiseParams.get('RMSEstimator', None)
-        if estimator is not None:
-            raise NemoFiltError("RMSEstimator '%s' is not implemented on the GPU path yet" % (estimator))
+        if estimator not in (None, 'percentile'):
+            # 'biweight' is astropy.stats.biweight_scale in the reference (nemo/filters.py:382,457): absent offline, unpinned
+            raise NemoFiltError("RMSEstimator '%s' is not available on the GPU path (default clipped RMS or 'percentile')" % (estimator))
+        if noiseParams.get('noiseGridArcmin', None) == "smart":                  # nemo/filters.py:363-404
+            if 'numNoiseBins' not in noiseParams:
+                raise Exception("Need to give numNoiseBins in noiseParams when using noiseGridArcmin = 'smart'")
+            if estimator is not None:
+                raise NemoFiltError("noiseGridArcmin: 'smart' is implemented for the default RMS estimator only")
+            numBins = int(noiseParams['numNoiseBins'])
+            rms = t.empty((self.H, self.W), dtype=t.float32, device=self.dev)
+            if numBins < 2:
+                rms.zero_()                      # np.linspace(..., 1) has no bins: the RMS map stays zero
+                return rms
+            wbytes = self.lib.nf_noise_smart_workspace_bytes()
+            work = t.empty(wbytes // 8 + 1, dtype=t.float64, device=self.dev)
+            check(self.lib.nf_noise_map_smart(prec_of(filtered), ptr(filtered), ptr(medWeights), prec_of(medWeights), ptr(rms),
+                                              self.npix, numBins, ptr(work), work.numel() * 8, stream_ptr()), "nf_noise_map_smart")
+            return rms
         if 'noiseGridArcmin' not in noiseParams or noiseParams['noiseGridArcmin'] is None:
             overlap, nx, ny = 0, 1, 1
         else:
@@ -356,7 +370,7 @@ class TileEngine(object):
             self._geom2[key] = (to_dev(yEdges), to_dev(xEdges))
         yE, xE = self._geom2[key]
         check(self.lib.nf_noise_map(prec_of(filtered), ptr(filtered), ptr(medWeights), prec_of(medWeights), ptr(rms),
-                                    self.H, self.W, ncy, ncx, ptr(yE), ptr(xE), overlap, nb, quant, 0, ptr(work),
+                                    self.H, self.W, ncy, ncx, ptr(yE), ptr(xE), overlap, nb, quant, 1 if estimator == 'percentile' else 0, ptr(work),
                                     work.numel() * 8, stream_ptr()), "nf_noise_map")
         return rms
 

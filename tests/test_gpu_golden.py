@@ -34,8 +34,6 @@ def test_noise_map_vs_reference():
     done = 0
     for k in range(int(g['ncases'])):
         params = json.loads(str(g['params%d' % k]))
-        if params.get('noiseGridArcmin') == 'smart' or params.get('RMSEstimator') is not None:
-            continue        # estimators / 'smart' mode: not on the GPU path yet (raise NemoFiltError there)
         m, w = g['map%d' % k], g['weights%d' % k]
         eng = engine.TileEngine.get(m.shape)
         dW = [engine.to_dev(x) for x in w]
@@ -53,7 +51,7 @@ def test_noise_map_vs_reference():
             # float64, so cells agree to float32 summation error, not bit for bit: stated tolerance 2e-6 relative
             assert np.abs(rms[differ] / ref[differ] - 1).max() < 2e-6
         done += 1
-    assert done >= 4
+    assert done == int(g['ncases'])      # grid mode (1-4 bins, no grid), 'percentile' estimator, 'smart' mode
 
 
 def test_realspace_convolution_vs_reference():

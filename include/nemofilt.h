@@ -143,6 +143,10 @@ int nf_finalize(int vtype, void* filtered_d, const float* rms_d, const unsigned 
                 const unsigned char* psMask_d, const unsigned char* edgeCheck_d, void* sn_d, float* rmsOut_d,
                 unsigned char* maskOut_d, int H, int W, int apodPix, int mulSurvey, void* stream);
 
+/* nemo/pipelines.py:244-247 (useCachedRMSMap branch of the driver): sn_d (float64) = data, divided by the cached RMS map
+ * (float32) where that is positive. */
+int nf_sn_cached(int vtype, const void* data_d, const float* rms_d, double* sn_d, long long n, void* stream);
+
 /* nemo/filters.py:99-101: data[ref == 0] = 0 after the pixel-window deconvolution. */
 int nf_restore_zeros(int vtype, void* data_d, const void* ref_d, long long n, void* stream);
 

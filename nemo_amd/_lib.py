@@ -56,6 +56,7 @@ SIGNATURES = {
     'nf_edge_check': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'nf_finalize': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                             c_int, c_int, c_int, c_void_p]),
+    'nf_sn_cached': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_ll, c_void_p]),
     'nf_restore_zeros': (c_int, [c_int, c_void_p, c_void_p, c_ll, c_void_p]),
     'nf_subtract': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_ll, c_void_p]),
     'nf_convolve2d': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),

@@ -336,6 +336,15 @@ int nf_noise_map(int vtype, const void* filtered, const void* weights, int wtype
     return nf::noise_map(vtype, filtered, weights, wtype, rms, H, W, g, work, workBytes, S(stream));
 }
 
+int nf_sn_cached(int vtype, const void* data, const float* rms, double* sn, long long n, void* stream) {
+    if (!data || !rms || !sn || n < 1) {
+        nf_set_error("nf_sn_cached: bad arguments");
+        return NF_ERR_ARG;
+    }
+    nf::ProfScope ps(nf::PT_FINALIZE, S(stream), (double)n * ((vtype == NF_F32 ? 4.0 : 8.0) + 4.0 + 8.0));
+    return nf::sn_cached(vtype, data, rms, sn, n, S(stream));
+}
+
 size_t nf_noise_smart_workspace_bytes(void) { return nf::noise_smart_workspace_bytes(); }
 
 int nf_noise_map_smart(int vtype, const void* filtered, const void* weights, int wtype, float* rms, long long n, int numBins,

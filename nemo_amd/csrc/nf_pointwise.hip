@@ -332,6 +332,28 @@ int scale_mask(int vtype, const float* in, void* out, double norm, const double*
 }
 
 // ---------------------------------------------------------------------------------------------------
+// nemo/pipelines.py:244-247 (cached RMS map branch): SN = float64(data); SN[RMS > 0] /= RMS
+template <typename VT>
+__global__ void k_sn_cached(const VT* __restrict__ data, const float* __restrict__ rms, double* __restrict__ sn, long long n) {
+    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x) {
+        double v = (double)data[p];
+        const float r = rms[p];
+        if (r > 0.0f) v = v / (double)r;
+        sn[p] = v;
+    }
+}
+
+int sn_cached(int vtype, const void* data, const float* rms, double* sn, long long n, hipStream_t s) {
+    dim3 g(grid_for(n, 256)), b(256);
+    if (vtype == NF_F64)
+        hipLaunchKernelGGL(k_sn_cached<double>, g, b, 0, s, (const double*)data, rms, sn, n);
+    else
+        hipLaunchKernelGGL(k_sn_cached<float>, g, b, 0, s, (const float*)data, rms, sn, n);
+    NF_CHECK_LAUNCH("k_sn_cached");
+    return NF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Tail of buildAndApply: S/N map, edge-check / survey / point-source / apodisation masks.
 //   SN = filtered / RMS where RMS > 0 (else filtered);  edge = edgeCheck (or 1)
 //   filtered' = filtered*edge [*surveyMask' if fourier variant];  surveyMask' = edge*surveyMask*psMask

@@ -392,6 +392,13 @@ class TileEngine(object):
                                    stream_ptr()), "nf_finalize")
         return filtered, sn, rmsOut, maskOut
 
+    def sn_cached(self, data, rms32):
+        """nemo/pipelines.py:244-247: float64 S/N map from a filtered map and a cached float32 RMS map."""
+        t = self.t
+        sn = t.empty((self.H, self.W), dtype=t.float64, device=self.dev)
+        check(self.lib.nf_sn_cached(prec_of(data), ptr(data), ptr(rms32), ptr(sn), self.npix, stream_ptr()), "nf_sn_cached")
+        return sn
+
     def undo_pixel_window(self, data):
         """filterMaps' last step (nemo/filters.py:98-101)."""
         out = self.apply_window(data, -1.0)

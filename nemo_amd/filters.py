@@ -344,6 +344,10 @@ class MatchedFilter(MapFilter):
                 shared['fMapsToFilter'] = fMapsToFilter
 
         haveFile = self.filterFileName is not None and os.path.exists(self.filterFileName)
+        if useCachedFilter == True and haveFile == False and self._dFilt is None and self._tileCache is not None:
+            cached = self._tileCache.get(('cachedFilter', self.label), None)
+            if cached is not None and tuple(cached.shape) == tuple(self.shape):
+                self._dFilt, self._signalNorm, self.fRelWeights = cached._dFilt, cached._signalNorm, dict(cached.fRelWeights)
         if haveFile == False and useCachedFilter == False:
             method = self.params['noiseParams']['method']
             if method not in ['dataMap', 'max(dataMap,CMB)']:

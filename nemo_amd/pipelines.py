@@ -18,7 +18,7 @@ import time
 
 import numpy as np
 
-from . import catalogs, filters, photometry, engine
+from . import catalogs, filters, photometry, engine, fitsio
 
 # columns exchanged between ranks (fixed-width float64 rows; strings are rebuilt from indices / coordinates)
 _GATHER_COLS = ['RADeg', 'decDeg', 'SNR', 'numSigPix', 'flags', 'ringFlag', 'galacticLatDeg', 'x', 'y']
@@ -99,6 +99,20 @@ def _gatherCatalogs(optimalCatalog, config):
     return tab
 
 
+def _loadCachedRMSMap(config, tileName, photFilter):
+    """RMS map of the reference filter for ``tileName`` as a float32 device tensor: from HBM if an earlier pass of this
+    process left it there, else from selFnDir/<tile>/RMSMap_<photFilter>#<tile>.fits."""
+    t = engine.torch()
+    if tileName in config.cachedRMSMapDict:
+        return engine.to_dev(config.cachedRMSMapDict[tileName], dtype=t.float32)
+    if config.selFnDir is not None:
+        fileName = config.selFnDir + os.path.sep + tileName + os.path.sep + "RMSMap_%s#%s.fits" % (photFilter, tileName)
+        if os.path.exists(fileName):
+            data, header = fitsio.readFITS(fileName)
+            return engine.to_dev(np.asarray(data, dtype=np.float32))
+    raise Exception("useCachedRMSMap: no RMS map of filter '%s' for tile '%s' (run the pipeline once without it)" % (photFilter, tileName))
+
+
 def _detectAndMeasure(config, job, stream, invertMap, measureFluxes, photFilter, verbose):
     """photometry.findObjects + measureFluxes for one (filter, tile) - nemo/pipelines.py:267-311.  With ``stream`` the
     work is enqueued on that HIP stream (called from the detection worker thread) after the filtered maps are complete."""
@@ -108,18 +122,22 @@ def _detectAndMeasure(config, job, stream, invertMap, measureFluxes, photFilter,
     with ctx:
         if stream is not None:
             stream.wait_event(ready)
-        catalog = photometry.findObjects(filteredMapDict, threshold=config.parDict['thresholdSigma'],
-                                         minObjPix=config.parDict['minObjPix'],
-                                         findCenterOfMass=config.parDict['findCenterOfMass'],
-                                         flagRings=config.parDict['flagRings'],
-                                         ringFlagDistArcmin=config.parDict['ringFlagDistArcmin'],
-                                         ringFlagMinRingerSNR=config.parDict['ringFlagMinRingerSNR'],
-                                         ringThresholdSigma=config.parDict['ringThresholdSigma'],
-                                         rejectBorder=config.parDict['rejectBorder'],
-                                         objIdent=config.parDict['objIdent'], longNames=config.parDict['longNames'],
-                                         useInterpolator=config.parDict['useInterpolator'],
-                                         measureShapes=config.parDict['measureShapes'], invertMap=invertMap,
-                                         verbose=verbose)
+        if config.parDict.get('forcedPhotometryCatalog', None) is not None:       # nemo/pipelines.py:267-274
+            catalog = photometry.makeForcedPhotometryCatalog(filteredMapDict, config.parDict['forcedPhotometryCatalog'],
+                                                             useInterpolator=config.parDict['useInterpolator'])
+        else:
+            catalog = photometry.findObjects(filteredMapDict, threshold=config.parDict['thresholdSigma'],
+                                             minObjPix=config.parDict['minObjPix'],
+                                             findCenterOfMass=config.parDict['findCenterOfMass'],
+                                             flagRings=config.parDict['flagRings'],
+                                             ringFlagDistArcmin=config.parDict['ringFlagDistArcmin'],
+                                             ringFlagMinRingerSNR=config.parDict['ringFlagMinRingerSNR'],
+                                             ringThresholdSigma=config.parDict['ringThresholdSigma'],
+                                             rejectBorder=config.parDict['rejectBorder'],
+                                             objIdent=config.parDict['objIdent'], longNames=config.parDict['longNames'],
+                                             useInterpolator=config.parDict['useInterpolator'],
+                                             measureShapes=config.parDict['measureShapes'], invertMap=invertMap,
+                                             verbose=verbose)
         if measureFluxes == True:
             photometry.measureFluxes(catalog, filteredMapDict, config.diagnosticsDir, photFilteredMapDict=photFilteredMapDict,
                                      useInterpolator=config.parDict['useInterpolator'])
@@ -171,11 +189,13 @@ def _filterMapsAndMakeCatalogs(config, rootOutDir=None, useCachedFilters=False, 
                                useCachedFilteredMaps=False, measureFluxes=True, invertMap=False, verbose=True,
                                writeAreaMask=False, writeFlagMask=False):
     """nemo/pipelines.py:118-398."""
-    if useCachedFilteredMaps or useCachedRMSMap:
-        raise NotImplementedError("useCachedFilteredMaps / useCachedRMSMap read products written by completeness / selFn code "
-                                  "(nemo/pipelines.py:204-218,234-250): 'next' row of the scope table")
-    if config.parDict['forcedPhotometryCatalog'] is not None:
-        raise NotImplementedError("forced photometry (nemo/photometry.py:380-444) is a 'next' row of the scope table")
+    if useCachedFilteredMaps:
+        raise NotImplementedError("useCachedFilteredMaps reads FITS products written by an earlier run (nemo/pipelines.py:204-218): "
+                                  "on-disk formats are a 'next' row of the scope table")
+    # nemo/pipelines.py:177-179: with a cached RMS map the pixel window is undone after the new S/N map is made
+    undoPixelWindow = config.parDict['undoPixelWindow']
+    if useCachedRMSMap == True:
+        undoPixelWindow = False
     if rootOutDir is not None:
         diagnosticsDir = rootOutDir + os.path.sep + "diagnostics"
         for d in [rootOutDir, rootOutDir + os.path.sep + "filteredMaps", diagnosticsDir]:
@@ -212,19 +232,37 @@ def _filterMapsAndMakeCatalogs(config, rootOutDir=None, useCachedFilters=False, 
             if verbose == True:
                 print(">>> [rank = %d] Making filtered maps - tileName = %s " % (config.rank, tileName))
             tileCache = {}      # what all filter scales of this tile share (data FFTs, noise covariance, masks): HBM-resident
+            if useCachedFilters == True and tileName in config.cachedFilters:
+                # the reference filter object of an earlier pass, still holding its cube in HBM (the reference rereads
+                # diagnostics/<tile>/filter_<label>#<tile>.fits; that file is used when present)
+                tileCache[('cachedFilter', config.cachedFilters[tileName].label)] = config.cachedFilters[tileName]
             for f in filtersList:
                 label = f['label'] + "#" + tileName
                 catalogDict[label] = {}
                 returnFilter = f['label'] == photFilter
                 filterResults = filters.filterMaps(config.unfilteredMapsDictList, f, tileName, diagnosticsDir=diagnosticsDir,
                                                    selFnDir=config.selFnDir, verbose=verbose,
-                                                   undoPixelWindow=config.parDict['undoPixelWindow'],
+                                                   undoPixelWindow=undoPixelWindow,
                                                    useCachedFilter=useCachedFilters, returnFilter=returnFilter,
                                                    tileCache=tileCache)
                 if returnFilter == False:
                     filteredMapDict = filterResults
                 else:
                     filteredMapDict, config.cachedFilters[tileName] = filterResults[0], filterResults[1]
+                if f['label'] == photFilter and useCachedRMSMap == False:
+                    # kept in HBM for later passes with useCachedRMSMap (the reference reloads selFn/RMSMap_<photFilter>.fits,
+                    # nemo/completeness.py:1070-1088); also written there when saveRMSMap is set and there is a selFnDir
+                    config.cachedRMSMapDict[tileName] = filteredMapDict['RMSMap']
+                    if f['params'].get('saveRMSMap', False) == True and config.selFnDir is not None:
+                        rmsDir = config.selFnDir + os.path.sep + tileName
+                        os.makedirs(rmsDir, exist_ok=True)
+                        fitsio.writeFITS(rmsDir + os.path.sep + "RMSMap_%s#%s.fits" % (photFilter, tileName),
+                                         filteredMapDict['RMSMap'].cpu().numpy(), {})
+                if useCachedRMSMap == True and photFilter is not None:            # nemo/pipelines.py:234-250
+                    RMSMap = _loadCachedRMSMap(config, tileName, photFilter)
+                    eng = engine.TileEngine.get(tuple(filteredMapDict['data'].shape))
+                    filteredMapDict['SNMap'] = eng.sn_cached(filteredMapDict['data'], RMSMap)
+                    filteredMapDict['data'] = eng.undo_pixel_window(filteredMapDict['data'])
                 if 'saveFilteredMaps' in f['params'] and f['params']['saveFilteredMaps'] == True:
                     t = engine.torch()
                     config.stitchedFilteredMapDict[tileName] = filteredMapDict['data'].to(t.float32)

@@ -187,6 +187,7 @@ class NemoConfig(object):
         self._identifyFilterSets()
         self.currentFilterSet = None
         self.cachedFilters = {}
+        self.cachedRMSMapDict = {}      # tile -> float32 RMS map of the reference filter (HBM), for useCachedRMSMap passes
 
     @staticmethod
     def _copyParDict(parDict):

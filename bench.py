@@ -90,8 +90,14 @@ def make_config(mapsList, numScales):
 def run_step(config):
     """One pass of the hot path over this rank's tile(s): pipelines.filterMapsAndMakeCatalogs = for every filter scale
     filters.filterMaps (+ pixel-window undo), photometry.findObjects, photometry.measureFluxes, then the optimal catalogue."""
-    from nemo_amd import pipelines
+    from nemo_amd import pipelines, catalogs
     cat = pipelines.filterMapsAndMakeCatalogs(config, verbose=False)
+    if config.size > 1:
+        # the one exchange of the path (nemo/pipelines.py:322): every rank ends with the catalogue of all tiles - an RCCL
+        # all-gather of fixed-width rows over xGMI, then the duplicate removal of tile overlaps (:335)
+        cat = pipelines._gatherCatalogs(cat, config)
+        if len(cat) > 0:
+            cat, numDup, names = catalogs.removeDuplicates(cat)
     if len(cat) > 0:
         cat['name']          # names are formatted lazily: make them part of the timed work
     return cat
@@ -152,6 +158,7 @@ def main():
     shape = (args.size, args.size)
     mapsList, wcs, truth = make_workload(shape, 1234 + rank, args.dtype)
     config = make_config(mapsList, args.scales)
+    config.rank, config.size = rank, world      # tiles are already one per rank (weak scaling): only the gather uses these
     N, S = 1, len(config.parDict['mapFilters'])
 
     def barrier():
@@ -170,7 +177,7 @@ def main():
         cat = run_step(config)
     barrier()
     elapsed = time.perf_counter() - t0
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device='cuda' if (world == 1 or dist.get_backend() == 'nccl') else 'cpu')
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())

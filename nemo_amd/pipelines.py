@@ -37,9 +37,13 @@ def initDistributed():
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if torch.cuda.is_available():
+    backend = os.environ.get('NEMO_AMD_DIST_BACKEND', 'nccl')      # 'gloo' to rehearse several ranks on one GPU
+    if torch.cuda.is_available() and backend == 'nccl':
         torch.cuda.set_device(local % torch.cuda.device_count())
         dist.init_process_group('nccl', device_id=torch.device('cuda', torch.cuda.current_device()))
+    elif torch.cuda.is_available():
+        torch.cuda.set_device(local % torch.cuda.device_count())
+        dist.init_process_group('gloo')
     else:
         dist.init_process_group('gloo')
     return dist.get_rank(), dist.get_world_size()

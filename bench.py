@@ -124,6 +124,19 @@ def cpu_baseline(procs, size):
             'launch_wall_s': round(time.time() - t0, 2)}
 
 
+def pmc_traffic(tag, shape, numScales, dtype):
+    """HBM bytes per launch (GB) of the kernel behind `tag` from the committed rocprofv3 PMC passes over this same command
+    (profiles/r01_pmc_traffic.json: FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE).
+    Counters cannot be read from inside a run, so this is the profiled figure for the headline workload only - None for
+    any other size / scale count / dtype, or when the file is absent."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if tuple(shape) != (4096, 4096) or numScales != 15 or dtype != "f64" or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        tab = json.load(f).get("kernels", {})
+    return tab[tag]["traffic_GB"] if tag in tab else None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -212,7 +225,9 @@ def main():
             devMs = sum(k['ms_total'] for k in kernels.values())
             algGB = sum(k['alg_GB_per_call'] * k['calls'] for k in kernels.values())
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]['GBps'], "peak": HBM_PEAK_GBS,
-                               "unit": "GB/s", "frac": round(kernels[dom]['GBps'] / HBM_PEAK_GBS, 4), "traffic": None,
+                               "unit": "GB/s", "frac": round(kernels[dom]['GBps'] / HBM_PEAK_GBS, 4),
+                               "traffic": pmc_traffic(dom, shape, S, args.dtype),
+                               "traffic_unit": "GB per launch (rocprofv3 PMC, profiles/r01_pmc_traffic.json)",
                                "avg_us": kernels[dom]['avg_us'], "alg_GB_per_launch": kernels[dom]['alg_GB_per_call'],
                                "share_of_device_time": round(kernels[dom]['ms_total'] / devMs, 3)}
             out["pipeline"] = {"device_ms_per_step": round(devMs / args.steps, 2),

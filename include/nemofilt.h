@@ -181,9 +181,13 @@ int nf_ring_flags(const int* ringLabels_d, const double* ringStats_d, int numRin
                   unsigned char* isRing_d, void* stream);
 
 /* RectBivariateSpline(kx=3, ky=3)(y, x) (nemo/photometry.py:82-84,128; nemo/filters.py:654-657) at nPts points;
- * yx_d: nPts pairs (y, x), out_d: nPts doubles; halfWin <= 34 (32 reproduces the whole-map fit to 1e-16). */
+ * yx_d: nPts pairs (y, x), out_d: nPts doubles; halfWin <= 34 (32 reproduces the whole-map fit to 1e-16).
+ * Points further than halfWin + 2 pixels from every edge are evaluated as one weighted sum over the window (Green's
+ * function of the spline's tridiagonal system), the others by a windowed not-a-knot solve that honours the map border.
+ * pointsClass: 0 = unknown (both kernels are launched, each skips the other's points), 1 = the caller guarantees that
+ * all points are interior, 2 = that none is - saves the launch that would do nothing. */
 int nf_spline_eval(int vtype, const void* map_d, int negate, int H, int W, const double* yx_d, int nPts, int halfWin,
-                   double* out_d, void* stream);
+                   int pointsClass, double* out_d, void* stream);
 
 /* Instrumentation (no counterpart in the reference; used by bench.py): when enabled, every entry point above brackets
  * the work it enqueues with a HIP event pair on the caller's stream.  nf_profile_enable(on) switches recording and

@@ -521,6 +521,17 @@ __device__ double nak_spline_eval(const double* y, int st, int n, double u, doub
     return M[i] * t1 * t1 * t1 / 6.0 + M[i + 1] * t * t * t / 6.0 + (y0 - M[i] / 6.0) * t1 + (y1 - M[i + 1] / 6.0) * t;
 }
 
+// interior points: small static LDS, so many workgroups share a CU (the windowed-solve kernel below needs 85 KB each)
+template <typename VT>
+__global__ void __launch_bounds__(128) k_spline_eval_interior(const VT* __restrict__ map, int negate, int H, int W,
+                                                              const double* __restrict__ yx, int halfWin, double* __restrict__ out) {
+    __shared__ double lds[3 * NF_SPL_MAXN + 2];
+    const double py = yx[2 * blockIdx.x], px = yx[2 * blockIdx.x + 1];
+    if (!(py >= 0.0 && py <= (double)(H - 1) && px >= 0.0 && px <= (double)(W - 1))) return;
+    const int iy = (int)floor(py), ix = (int)floor(px);
+    if (!spline_interior(iy, ix, H, W, halfWin)) return;
+    spline_eval_interior<VT>(map, negate, W, py, px, iy, ix, halfWin, lds, out + blockIdx.x);
+}
 
 template <typename VT>
 __global__ void k_spline_eval(const VT* __restrict__ map, int negate, int H, int W, const double* __restrict__ yx, int halfWin,
@@ -540,10 +551,7 @@ __global__ void k_spline_eval(const VT* __restrict__ map, int negate, int H, int
         if (threadIdx.x == 0) out[blockIdx.x] = nan("");
         return;
     }
-    if (spline_interior(iy, ix, H, W, halfWin)) {            // uniform over the workgroup
-        spline_eval_interior<VT>(map, negate, W, py, px, iy, ix, halfWin, win, out + blockIdx.x);
-        return;
-    }
+    if (spline_interior(iy, ix, H, W, halfWin)) return;      // k_spline_eval_interior wrote this point
     for (int i = threadIdx.x; i < ny * nx; i += blockDim.x) {
         int r = i / nx, c = i % nx;
         double v = (double)map[(long long)(y0 + r) * W + x0 + c];
@@ -564,8 +572,8 @@ __global__ void k_spline_eval(const VT* __restrict__ map, int negate, int H, int
     if (threadIdx.x == 0) out[blockIdx.x] = nak_spline_eval(colv, 1, ny, py - (double)y0, mwork, cp);
 }
 
-int spline_eval(int vtype, const void* map, int negate, int H, int W, const double* yx, int nPts, int halfWin, double* out,
-                hipStream_t s) {
+int spline_eval(int vtype, const void* map, int negate, int H, int W, const double* yx, int nPts, int halfWin, int pointsClass,
+                double* out, hipStream_t s) {
     if (nPts <= 0) return NF_OK;
     if (2 * halfWin + 2 > NF_SPL_MAXN) {
         nf_set_error("spline_eval: window too large");
@@ -578,13 +586,19 @@ int spline_eval(int vtype, const void* map, int negate, int H, int W, const doub
             NF_HIP(hipFuncSetAttribute((const void*)k_spline_eval<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             attr[1] = true;
         }
-        hipLaunchKernelGGL(k_spline_eval<double>, dim3(nPts), dim3(128), lds, s, (const double*)map, negate, H, W, yx, halfWin, out);
+        if (pointsClass != 2)
+            hipLaunchKernelGGL(k_spline_eval_interior<double>, dim3(nPts), dim3(128), 0, s, (const double*)map, negate, H, W, yx, halfWin, out);
+        if (pointsClass != 1)
+            hipLaunchKernelGGL(k_spline_eval<double>, dim3(nPts), dim3(128), lds, s, (const double*)map, negate, H, W, yx, halfWin, out);
     } else {
         if (!attr[0]) {
             NF_HIP(hipFuncSetAttribute((const void*)k_spline_eval<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             attr[0] = true;
         }
-        hipLaunchKernelGGL(k_spline_eval<float>, dim3(nPts), dim3(128), lds, s, (const float*)map, negate, H, W, yx, halfWin, out);
+        if (pointsClass != 2)
+            hipLaunchKernelGGL(k_spline_eval_interior<float>, dim3(nPts), dim3(128), 0, s, (const float*)map, negate, H, W, yx, halfWin, out);
+        if (pointsClass != 1)
+            hipLaunchKernelGGL(k_spline_eval<float>, dim3(nPts), dim3(128), lds, s, (const float*)map, negate, H, W, yx, halfWin, out);
     }
     NF_CHECK_LAUNCH("k_spline_eval");
     return NF_OK;

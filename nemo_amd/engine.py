@@ -462,10 +462,16 @@ class TileEngine(object):
         yx = np.ascontiguousarray(np.asarray(yx, dtype=np.float64).reshape(-1, 2))
         if len(yx) == 0:
             return np.zeros(0)
+        # which kernel serves which point is known here (the positions come from the host): tell the library, so that it
+        # does not launch a kernel in which every workgroup would only find out that it has nothing to do
+        iy, ix = np.floor(yx[:, 0]), np.floor(yx[:, 1])
+        interior = (iy - halfWin - 1 >= 0) & (iy + halfWin + 2 <= self.H - 1) & (ix - halfWin - 1 >= 0) & \
+            (ix + halfWin + 2 <= self.W - 1) & (yx[:, 0] >= 0) & (yx[:, 0] <= self.H - 1) & (yx[:, 1] >= 0) & (yx[:, 1] <= self.W - 1)
+        pointsClass = 1 if interior.all() else (2 if not interior.any() else 0)
         yx_d = to_dev(yx)
         out = t.empty(len(yx), dtype=t.float64, device=self.dev)
         check(self.lib.nf_spline_eval(prec_of(m), ptr(m), 1 if negate else 0, self.H, self.W, ptr(yx_d), len(yx), halfWin,
-                                      ptr(out), stream_ptr()), "nf_spline_eval")
+                                      pointsClass, ptr(out), stream_ptr()), "nf_spline_eval")
         if not to_host:
             return out
         return out.cpu().numpy()

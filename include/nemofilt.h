@@ -72,6 +72,27 @@ int nf_fft2_inverse_fused(nf_plan* plan, int prec, const void* in_d, const float
 /* nemo/filters.py:573: NP[i][j] = Re(F_i conj F_j) for all i, j;  F [N][npix] complex, NP [N][N][npix] real. */
 int nf_cross_power(int prec, const void* F_d, void* NP_d, int N, long long npix, void* stream);
 
+/* ---- half-stored spectra -------------------------------------------------------------------------------------
+ * Every transform on this path starts from or ends in a REAL map (nemo/filters.py:525,615,646,847), whose spectrum obeys
+ * F[-y][-x] = conj F[y][x].  The *_half entry points keep the [H][W] plane layout of the full-spectrum calls but store
+ * and read only the columns x <= W/2; the rest of each plane is never written nor read (its content is undefined).  The
+ * column pass of each transform then moves half of the bytes.  Values are those of the full-spectrum calls: the missing
+ * modes are used through the symmetry, in the same arithmetic.
+ *   nf_fft2_forward_half  = nf_fft2_forward of real input (NF_IN_REAL64 / NF_IN_REAL32), columns x <= W/2 only
+ *   nf_fft2_inverse_half  = nf_fft2_inverse_fused with real output of half-stored input planes; the float32 filter and the
+ *                           window tables stay full planes / full tables (the smoothed noise power of nemo/filters.py:580
+ *                           is not exactly symmetric under (y,x) -> (-y,-x), so both filter values enter)
+ *   nf_cross_power_half, nf_build_filter_half = nf_cross_power / nf_build_filter reading half-stored F_d / S_d and writing
+ *                           full planes */
+int nf_fft2_forward_half(nf_plan* plan, int prec, const void* in_d, int inType, void* out_d, int batch,
+                         const double* apodY_d, const double* apodX_d, int unitary, void* stream);
+int nf_fft2_inverse_half(nf_plan* plan, int prec, const void* in_d, const float* filt_d, int nSum, int filtPerBatch,
+                         const double* wy_d, const double* wx_d, void* work_d, void* out_d, int outType, int batch,
+                         int unitary, void* stream);
+int nf_cross_power_half(int prec, const void* F_d, void* NP_d, int N, int H, int W, void* stream);
+int nf_build_filter_half(int covType, int sigType, const void* cov_d, const void* S_d, const double* w, float* filt_d,
+                         int N, int H, int W, void* stream);
+
 /* scipy.ndimage.gaussian_filter with mode='reflect' (nemo/filters.py:580 with sigma (3,3); nemo/maps.py:1380).
  * wY_d / wX_d: normalised 1-D kernels of length 2*rad+1 (device, float64) for axis 0 / axis 1, as
  * scipy builds them; tmp_d holds the axis-0 result in the map dtype. */

@@ -38,6 +38,12 @@ SIGNATURES = {
     'nf_fft2_inverse_fused': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_int, c_int, c_int, c_void_p]),
     'nf_cross_power': (c_int, [c_int, c_void_p, c_void_p, c_int, c_ll, c_void_p]),
+    'nf_fft2_forward_half': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    'nf_fft2_inverse_half': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_int, c_int, c_int, c_void_p]),
+    'nf_cross_power_half': (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    'nf_build_filter_half': (c_int, [c_int, c_int, c_void_p, c_void_p, ctypes.POINTER(c_double), c_void_p, c_int, c_int, c_int,
+                                     c_void_p]),
     'nf_gaussian_filter': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p,
                                    c_int, c_void_p]),
     'nf_build_filter': (c_int, [c_int, c_int, c_void_p, c_void_p, ctypes.POINTER(c_double), c_void_p, c_int, c_ll, c_void_p]),

@@ -188,6 +188,23 @@ int nf_fft2_forward(nf_plan* p, int prec, const void* in, int inType, void* out,
     return p->pd.forward(in, inType, out, batch, apodY, apodX, unitary ? 1 : 0, scale, S(stream));
 }
 
+int nf_fft2_forward_half(nf_plan* p, int prec, const void* in, int inType, void* out, int batch, const double* apodY,
+                         const double* apodX, int unitary, void* stream) {
+    if (!p || !in || !out || batch < 1 || (inType != NF_IN_REAL64 && inType != NF_IN_REAL32)) {
+        nf_set_error("nf_fft2_forward_half: bad arguments (the input must be real)");
+        return NF_ERR_ARG;
+    }
+    if ((apodY == nullptr) != (apodX == nullptr)) {
+        nf_set_error("nf_fft2_forward_half: give both apodisation tables or neither");
+        return NF_ERR_ARG;
+    }
+    int rc = ensure_prec(p, prec);
+    if (rc) return rc;
+    double scale = std::sqrt((double)p->H * (double)p->W);
+    if (prec == NF_F32) return p->pf.forward(in, inType, out, batch, apodY, apodX, unitary ? 1 : 0, scale, S(stream), 1);
+    return p->pd.forward(in, inType, out, batch, apodY, apodX, unitary ? 1 : 0, scale, S(stream), 1);
+}
+
 int nf_fft2_inverse(nf_plan* p, int prec, const void* in, void* work, void* out, int outType, int batch, int unitary,
                     void* stream) {
     if (!p || !in || !work || !out || batch < 1 || outType < 0 || outType > 2) {
@@ -217,6 +234,23 @@ int nf_fft2_inverse_fused(nf_plan* p, int prec, const void* in, const float* fil
     return p->pd.inverse(in, work, out, outType, batch, unitary ? 1 : 0, scale, S(stream), filt, nSum, fbs, wy, wx);
 }
 
+int nf_fft2_inverse_half(nf_plan* p, int prec, const void* in, const float* filt, int nSum, int filtPerBatch,
+                         const double* wy, const double* wx, void* work, void* out, int outType, int batch, int unitary,
+                         void* stream) {
+    if (!p || !in || !work || !out || batch < 1 || (outType != NF_IN_REAL64 && outType != NF_IN_REAL32) || nSum < 1 ||
+        (nSum > 1 && (!filt || batch != 1)) || ((wy == nullptr) != (wx == nullptr))) {
+        nf_set_error("nf_fft2_inverse_half: bad arguments (the output must be real)");
+        return NF_ERR_ARG;
+    }
+    int rc = ensure_prec(p, prec);
+    if (rc) return rc;
+    double scale = std::sqrt((double)p->H * (double)p->W);
+    const long long fbs = (filt && filtPerBatch) ? (long long)p->H * p->W : 0;
+    if (prec == NF_F32)
+        return p->pf.inverse(in, work, out, outType, batch, unitary ? 1 : 0, scale, S(stream), filt, nSum, fbs, wy, wx, 1);
+    return p->pd.inverse(in, work, out, outType, batch, unitary ? 1 : 0, scale, S(stream), filt, nSum, fbs, wy, wx, 1);
+}
+
 int nf_cross_power(int prec, const void* F, void* NP, int N, long long npix, void* stream) {
     if (!F || !NP || N < 1 || npix < 1) {
         nf_set_error("nf_cross_power: bad arguments");
@@ -226,6 +260,19 @@ int nf_cross_power(int prec, const void* F, void* NP, int N, long long npix, voi
     nf::ProfScope ps(nf::PT_CROSS_POWER, S(stream), (double)npix * (N * 2 * es + (double)N * N * es));
     if (prec == NF_F32) return nf::cross_power<float>(F, NP, N, npix, S(stream));
     return nf::cross_power<double>(F, NP, N, npix, S(stream));
+}
+
+int nf_cross_power_half(int prec, const void* F, void* NP, int N, int H, int W, void* stream) {
+    if (!F || !NP || N < 1 || H < 1 || W < 1) {
+        nf_set_error("nf_cross_power_half: bad arguments");
+        return NF_ERR_ARG;
+    }
+    const long long npix = (long long)H * W;
+    const double es = prec == NF_F32 ? 4.0 : 8.0;
+    // each stored mode is read once from HBM (its second use comes out of the cache)
+    nf::ProfScope ps(nf::PT_CROSS_POWER, S(stream), (double)npix * (N * es + (double)N * N * es));
+    if (prec == NF_F32) return nf::cross_power<float>(F, NP, N, npix, S(stream), H, W);
+    return nf::cross_power<double>(F, NP, N, npix, S(stream), H, W);
 }
 
 int nf_gaussian_filter(int rtype, const void* in, void* tmp, void* out, int H, int W, int batch, const double* wY, int radY,
@@ -250,6 +297,21 @@ int nf_build_filter(int covType, int sigType, const void* cov, const void* Sg, c
     nf::ProfScope ps(nf::PT_BUILD_FILTER, S(stream),
                      (double)npix * ((double)N * N * (covType == NF_F32 ? 4.0 : 8.0) + N * (sigType == NF_F32 ? 8.0 : 16.0) + N * 4.0));
     return nf::build_filter(covType, sigType, cov, Sg, wv, filt, N, npix, S(stream));
+}
+
+int nf_build_filter_half(int covType, int sigType, const void* cov, const void* Sg, const double* w, float* filt, int N,
+                         int H, int W, void* stream) {
+    if (!cov || !Sg || !w || !filt || N < 1 || N > 6 || H < 1 || W < 1) {
+        nf_set_error("nf_build_filter_half: bad arguments (1 <= N <= 6)");
+        return NF_ERR_ARG;
+    }
+    const long long npix = (long long)H * W;
+    nf::WeightVec wv;
+    memset(&wv, 0, sizeof(wv));
+    for (int i = 0; i < N; ++i) wv.v[i] = w[i];
+    nf::ProfScope ps(nf::PT_BUILD_FILTER, S(stream),
+                     (double)npix * ((double)N * N * (covType == NF_F32 ? 4.0 : 8.0) + N * (sigType == NF_F32 ? 4.0 : 8.0) + N * 4.0));
+    return nf::build_filter(covType, sigType, cov, Sg, wv, filt, N, npix, S(stream), H, W);
 }
 
 int nf_apply_filter(int prec, const void* F, const float* filt, void* G, int N, int sum, long long npix, void* stream) {

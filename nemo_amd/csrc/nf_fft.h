@@ -52,6 +52,16 @@ struct LineArgs {
     long long sumStride;     // plane pitch of in / mul for the sum (elements)
     const double* winLine;   // pixel-window table along the line index (columns kernel: wx[col]) and
     const double* winElem;   //   along the element index (wy[row]); both NULL = no window
+    // real-data transforms (half the work of a complex transform; see "Real input / real output" in nf_fft.hip)
+    int pairMode;            // rows kernel: 0 = one line per row; 1 = forward, a line is the complex pair (row 2p) + i (row 2p+1)
+                             //   of REAL input rows, unpacked to two half-rows; 2 = inverse, two Hermitian half-rows are packed
+                             //   into one complex line whose real / imaginary parts are the two REAL output rows
+    int mirror;              // columns kernel, forward: column c of the half plane is also stored, conjugated and reversed, as
+                             //   column W - c (the other half of the spectrum of a real map)
+    int herm;                // columns kernel, inverse: load 0.5 * (G[y][c] + conj G[-y][-c]) (real part of the output only)
+    int halfIn;              //   ... of a spectrum of a real map that is stored for c <= W/2 only (the mirror mode is the
+                             //   conjugate of the stored one; only its filter value and window factor are fetched)
+    int realH, realW;        // shape of the real map (H rows, W columns)
     const double* apodLine;  // optional per-line apodisation factors (length nLines); rows kernel, real input only
     const double* apodElem;  // optional per-element apodisation factors (length n)
 };
@@ -61,13 +71,14 @@ struct Plan2D {
     int H, W;
     LinePlan<T> row, col;
     int rowsPerWG, colsPerWG, threadsRow, tbRow, threadsCol;
+    int useReal;    // real-data fast paths enabled (NF_FFT_REAL=0 switches them off)
     int init(int H, int W);
     void destroy();
     int forward(const void* in, int inType, void* out, int batch, const double* apodY, const double* apodX,
-                int scaleDiv, double scale, hipStream_t stream);
+                int scaleDiv, double scale, hipStream_t stream, int half = 0);
     int inverse(const void* in, void* work, void* out, int outType, int batch, int scaleDiv, double scale,
                 hipStream_t stream, const float* filt = nullptr, int nSum = 1, long long filtBatchStride = 0,
-                const double* winY = nullptr, const double* winX = nullptr);
+                const double* winY = nullptr, const double* winX = nullptr, int halfIn = 0);
 };
 
 }  // namespace nf

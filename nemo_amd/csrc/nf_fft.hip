@@ -190,7 +190,7 @@ __device__ __forceinline__ void store_elem(const nf::LineArgs<T>& a, void* outP,
     // multiplication by the rounded reciprocal of sqrt(H*W): within 1 ulp of the reference's division, exact when
     // H*W is a power of four; 1 when the transform is not scaled
     const T r = (T)a.scale;
-    if (OT == 0) {
+    if (OT == 0 || OT == 3) {
         v.x *= r;
         v.y *= r * (T)a.conjOutSign;
         ((cpx<T>*)outP)[off] = v;
@@ -204,9 +204,12 @@ __device__ __forceinline__ void store_elem(const nf::LineArgs<T>& a, void* outP,
 // Pointwise work fused into the column kernel's global load (the pass that would otherwise read and write the whole
 // plane once more): pixel-window factor (enmap.apply_window, nemo/filters.py:100,644: product of the two 1-D tables
 // formed first, applied in float64, rounded to T) and / or the float32 filter with the frequency sum
-// (nemo/filters.py:847, sum moved in front of the inverse transform).  `line` = column, `row` = element index.
+// (nemo/filters.py:847, sum moved in front of the inverse transform).  `line` = column, `row` = element index of the
+// mode the factors belong to; `off` = where the further planes of the sum are read (imaginary parts times imSign),
+// `offMul` = where the filter is read (differs from `off` only for the mirror mode of a half-stored spectrum).
 template <typename T>
-__device__ __forceinline__ cpx<T> fused_ops(const nf::LineArgs<T>& a, const Geo& G, cpx<T> v, unsigned off, int line, int row) {
+__device__ __forceinline__ cpx<T> fused_ops(const nf::LineArgs<T>& a, const Geo& G, cpx<T> v, unsigned off, T imSign,
+                                             unsigned offMul, int line, int row) {
     double win = 1.0;
     if (a.winElem != nullptr) {
         win = a.winElem[row] * a.winLine[line];
@@ -215,16 +218,16 @@ __device__ __forceinline__ cpx<T> fused_ops(const nf::LineArgs<T>& a, const Geo&
     }
     if (a.mulF32 != nullptr) {
         const float* mul = a.mulF32 + (size_t)blockIdx.y * (size_t)a.mulBatchStride;
-        T h = (T)mul[off];
+        T h = (T)mul[offMul];
         T re = v.x * h, im = v.y * h;
         for (int pl = 1; pl < a.nSum; ++pl) {
             cpx<T> f = ((const cpx<T>*)G.inP)[(size_t)pl * (size_t)a.sumStride + off];
-            f.y *= (T)a.conjInSign;
+            f.y *= (T)a.conjInSign * imSign;
             if (a.winElem != nullptr) {
                 f.x = (T)((double)f.x * win);
                 f.y = (T)((double)f.y * win);
             }
-            h = (T)mul[(size_t)pl * (size_t)a.sumStride + off];
+            h = (T)mul[(size_t)pl * (size_t)a.sumStride + offMul];
             re += f.x * h;
             im += f.y * h;
         }
@@ -234,10 +237,41 @@ __device__ __forceinline__ cpx<T> fused_ops(const nf::LineArgs<T>& a, const Geo&
     return v;
 }
 
+// Inverse transform of which only the real part is wanted: real(ifft2(G)) = ifft2(0.5 * (G[k] + conj G[-k])), and the
+// symmetrised spectrum needs only its columns c <= W/2 transformed (the rows pass rebuilds the rest by conjugation).
+// `v` is the (conjugated-for-the-inverse) element at (row, col) after load_elem; the mirror element goes through the same
+// load and the same pointwise factors, then u = 0.5 * (u1 + conj u2).
+template <typename T>
+__device__ __forceinline__ cpx<T> fused_ops_herm(const nf::LineArgs<T>& a, const Geo& G, cpx<T> v, unsigned off, int col, int row) {
+    cpx<T> u1 = fused_ops<T>(a, G, v, off, (T)1, off, col, row);
+    if (!a.herm) return u1;
+    const int rowM = row == 0 ? 0 : a.realH - row;
+    const int colM = col == 0 ? 0 : a.realW - col;
+    const unsigned offM = (unsigned)colM * (unsigned)a.inLineStride + (unsigned)rowM * (unsigned)a.inElemStride;
+    cpx<T> u2;
+    if (a.halfIn) {
+        // spectrum of a real map of which only the columns c <= W/2 are stored: the mirror mode is the conjugate of this
+        // one, only its filter value and window factor sit elsewhere
+        cpx<T> vm;
+        vm.x = v.x;
+        vm.y = -v.y;
+        u2 = fused_ops<T>(a, G, vm, off, (T)-1, offM, colM, rowM);
+    } else {
+        u2 = fused_ops<T>(a, G, load_elem<T, 0>(a, G.inP, offM, 1.0, rowM), offM, (T)1, offM, colM, rowM);
+    }
+    cpx<T> h;
+    h.x = (T)0.5 * (u1.x + u2.x);
+    h.y = (T)0.5 * (u1.y - u2.y);
+    return h;
+}
+
 // One in-place stage.  DIT (dif == false): twiddle the inputs, then the butterfly; DIF: butterfly, then twiddle the
 // outputs.  srcG: operands come from global memory (columns kernel, first DIT stage: row src[e]); dstG: results go
 // to global memory (last DIT stage: natural index e).
-template <typename T, int R, bool COLS, bool BLUE>
+// SPEC (compile time, so that the common kernels do not carry the registers of the special paths): columns kernel
+// 1 = mirrored second store (forward transform of a real map), 2 = pointwise / symmetrised load (fused inverse);
+// rows kernel 2 = two real output rows per line (inverse, real output).
+template <typename T, int R, bool COLS, bool BLUE, int SPEC>
 __device__ __forceinline__ void fft_stage(cpx<T>* __restrict__ buf, const nf::LineArgs<T>& a, const nf::StageInfo st,
                                           const bool dif, const bool srcG, const bool dstG, const Geo& G) {
     const nf::LinePlan<T>& p = a.plan;
@@ -277,10 +311,10 @@ __device__ __forceinline__ void fft_stage(cpx<T>* __restrict__ buf, const nf::Li
 #pragma unroll
                 for (int k = 0; k < R; ++k)
                     x[k] = load_elem<T, 0>(a, G.inP, lo + idx[k] * (unsigned)a.inElemStride, 1.0, (int)idx[k]);
-                if (a.fused) {      // uniform: after the plain loads, so that those stay batched
+                if (COLS && SPEC == 2) {      // after the plain loads, so that those stay batched
 #pragma unroll
                     for (int k = 0; k < R; ++k)
-                        x[k] = fused_ops<T>(a, G, x[k], lo + idx[k] * (unsigned)a.inElemStride, G.line0 + line, (int)idx[k]);
+                        x[k] = fused_ops_herm<T>(a, G, x[k], lo + idx[k] * (unsigned)a.inElemStride, G.line0 + line, (int)idx[k]);
                 }
             } else {
 #pragma unroll
@@ -302,7 +336,47 @@ __device__ __forceinline__ void fft_stage(cpx<T>* __restrict__ buf, const nf::Li
         const unsigned e = base + (unsigned)k * L;                                                                \
         if (!BLUE || e < (unsigned)p.n) store_elem<T, OT, BLUE>(a, G.outP, lo + e * (unsigned)a.outElemStride, (int)e, x[k]); \
     }
-                if (a.outType == 0) {
+                if (COLS && SPEC == 1) {
+                    // spectrum of a real map: F[-y][-c] = conj F[y][c]; this tile holds columns c <= W/2 and writes both
+                    NF_STORE_ALL(0)
+                    const unsigned col = (unsigned)(G.line0 + line);
+                    if (col > 0u && 2u * col < (unsigned)a.realW) {
+                        const T r = (T)a.scale;
+#pragma unroll
+                        for (int k = 0; k < R; ++k) {
+                            const unsigned e = base + (unsigned)k * L;
+                            if (!BLUE || e < (unsigned)p.n) {
+                                cpx<T> v = x[k];
+                                if (BLUE) v = cmul(cconj(v), p.chirp[e]);
+                                v.x *= r;
+                                v.y *= -(r * (T)a.conjOutSign);
+                                const unsigned rowM = e == 0u ? 0u : (unsigned)a.realH - e;
+                                ((cpx<T>*)G.outP)[rowM * (unsigned)a.outElemStride + ((unsigned)a.realW - col)] = v;
+                            }
+                        }
+                    }
+                } else if (!COLS && SPEC == 2) {
+                    // two real output rows from one complex line: row 2p = Re, row 2p+1 = Im (of the conjugated transform)
+                    const unsigned rowA = 2u * (unsigned)(G.line0 + line);
+                    const bool haveB = rowA + 1u < (unsigned)a.realH;
+                    const T r = (T)a.scale, rb = r * (T)a.conjOutSign;
+#pragma unroll
+                    for (int k = 0; k < R; ++k) {
+                        const unsigned e = base + (unsigned)k * L;
+                        if (!BLUE || e < (unsigned)p.n) {
+                            cpx<T> v = x[k];
+                            if (BLUE) v = cmul(cconj(v), p.chirp[e]);
+                            const unsigned oa = rowA * (unsigned)a.realW + e;
+                            if (a.outType == 1) {
+                                ((double*)G.outP)[oa] = (double)(v.x * r);
+                                if (haveB) ((double*)G.outP)[oa + (unsigned)a.realW] = (double)(v.y * rb);
+                            } else {
+                                ((float*)G.outP)[oa] = (float)(v.x * r);
+                                if (haveB) ((float*)G.outP)[oa + (unsigned)a.realW] = (float)(v.y * rb);
+                            }
+                        }
+                    }
+                } else if (a.outType == 0) {
                     NF_STORE_ALL(0)
                 } else if (a.outType == 1) {
                     NF_STORE_ALL(1)
@@ -324,21 +398,21 @@ __device__ __forceinline__ void fft_stage(cpx<T>* __restrict__ buf, const nf::Li
 
 // BIG == false: instantiates only the radices up to 8 (fewer registers: every nemo tile length without a factor 11 or
 // 13 runs this variant)
-template <typename T, bool COLS, int MODE>
+template <typename T, bool COLS, int MODE, int SPEC>
 __device__ __forceinline__ void fft_stage_dispatch(cpx<T>* buf, const nf::LineArgs<T>& a, int s, bool dif, bool srcG,
                                                    bool dstG, const Geo& G) {
     const nf::StageInfo st = a.plan.st[s];
     constexpr bool BIG = MODE == 1;
     if (!BIG && st.R > 8) return;
     switch (st.R) {
-        case 2: fft_stage<T, 2, COLS, MODE == 2>(buf, a, st, dif, srcG, dstG, G); break;
-        case 3: fft_stage<T, 3, COLS, MODE == 2>(buf, a, st, dif, srcG, dstG, G); break;
-        case 4: fft_stage<T, 4, COLS, MODE == 2>(buf, a, st, dif, srcG, dstG, G); break;
-        case 5: fft_stage<T, 5, COLS, MODE == 2>(buf, a, st, dif, srcG, dstG, G); break;
-        case 7: fft_stage<T, 7, COLS, MODE == 2>(buf, a, st, dif, srcG, dstG, G); break;
-        case 8: fft_stage<T, 8, COLS, MODE == 2>(buf, a, st, dif, srcG, dstG, G); break;
-        case 11: if (BIG) fft_stage<T, 11, COLS, MODE == 2>(buf, a, st, dif, srcG, dstG, G); break;
-        case 13: if (BIG) fft_stage<T, 13, COLS, MODE == 2>(buf, a, st, dif, srcG, dstG, G); break;
+        case 2: fft_stage<T, 2, COLS, MODE == 2, SPEC>(buf, a, st, dif, srcG, dstG, G); break;
+        case 3: fft_stage<T, 3, COLS, MODE == 2, SPEC>(buf, a, st, dif, srcG, dstG, G); break;
+        case 4: fft_stage<T, 4, COLS, MODE == 2, SPEC>(buf, a, st, dif, srcG, dstG, G); break;
+        case 5: fft_stage<T, 5, COLS, MODE == 2, SPEC>(buf, a, st, dif, srcG, dstG, G); break;
+        case 7: fft_stage<T, 7, COLS, MODE == 2, SPEC>(buf, a, st, dif, srcG, dstG, G); break;
+        case 8: fft_stage<T, 8, COLS, MODE == 2, SPEC>(buf, a, st, dif, srcG, dstG, G); break;
+        case 11: if (BIG) fft_stage<T, 11, COLS, MODE == 2, SPEC>(buf, a, st, dif, srcG, dstG, G); break;
+        case 13: if (BIG) fft_stage<T, 13, COLS, MODE == 2, SPEC>(buf, a, st, dif, srcG, dstG, G); break;
         default: break;
     }
 }
@@ -348,7 +422,7 @@ __device__ __forceinline__ void fft_stage_dispatch(cpx<T>* buf, const nf::LineAr
 template <typename T, bool COLS, int MODE>
 __device__ __forceinline__ void bluestein_middle(cpx<T>* buf, const nf::LineArgs<T>& a, const Geo& G) {
     const nf::LinePlan<T>& p = a.plan;
-    for (int s = p.nst - 1; s >= 0; --s) fft_stage_dispatch<T, COLS, MODE>(buf, a, s, true, false, false, G);
+    for (int s = p.nst - 1; s >= 0; --s) fft_stage_dispatch<T, COLS, MODE, 0>(buf, a, s, true, false, false, G);
     for (int e = G.tb; e < p.m; e += G.TB) {
         const cpx<T> cf = p.chirpFp[e];
         for (int line = G.tl; line < G.nl; line += (COLS ? G.nl : G.TL)) {
@@ -401,9 +475,152 @@ __device__ __forceinline__ void stage_in_rows(cpx<T>* __restrict__ buf, const nf
     }
 }
 
+// Real input / real output (rows kernel, pairMode).
+//  forward (pairMode 1): line p = (row 2p) + i (row 2p+1) of the REAL map; after the transform Z,
+//      F_a[k] = 0.5 (Z[k] + conj Z[W-k]),  F_b[k] = -0.5 i (Z[k] - conj Z[W-k]),   k = 0 .. W/2,
+//      are the half-rows of the two spectra (the columns pass completes the plane by conjugate symmetry).
+//  inverse (pairMode 2): the two Hermitian half-rows A, B (k <= W/2; the rest is conj of the mirror; the imaginary parts
+//      of k = 0 and k = W/2 are rounding noise and are dropped) are packed as Z = A + i B; the inverse transform of Z
+//      has the two real output rows as its real and imaginary parts.
+template <typename T, int IT, bool BLUE>
+__device__ __forceinline__ void stage_in_pairs_fwd(cpx<T>* __restrict__ buf, const nf::LineArgs<T>& a, const Geo& G) {
+    const nf::LinePlan<T>& p = a.plan;
+    const int nIn = BLUE ? p.m : p.n;
+    for (int line = G.tl; line < G.nl; line += G.TL) {
+        const int rowA = 2 * (G.line0 + line);
+        const bool haveB = rowA + 1 < a.realH;
+        const int rowB = haveB ? rowA + 1 : rowA;
+        const unsigned offA = (unsigned)rowA * (unsigned)a.realW, offB = (unsigned)rowB * (unsigned)a.realW;
+        cpx<T>* __restrict__ lb = buf + line * p.mPad;
+        const double flA = IT >= 3 ? a.apodLine[rowA] : 1.0, flB = IT >= 3 ? a.apodLine[rowB] : 1.0;
+        for (int i0 = G.tb; i0 < nIn; i0 += NF_STAGE_IN * G.TB) {
+            cpx<T> v[NF_STAGE_IN], ch[BLUE ? NF_STAGE_IN : 1];
+            int pos[NF_STAGE_IN];
+#pragma unroll
+            for (int j = 0; j < NF_STAGE_IN; ++j) {
+                const int i = min(i0 + j * G.TB, p.n - 1);
+                v[j].x = load_elem<T, IT>(a, G.inP, offA + (unsigned)i, flA, i).x;
+                v[j].y = load_elem<T, IT>(a, G.inP, offB + (unsigned)i, flB, i).x;
+                if (BLUE)
+                    ch[j] = p.chirp[i];
+                else
+                    pos[j] = p.rev[i];
+            }
+#pragma unroll
+            for (int j = 0; j < NF_STAGE_IN; ++j) {
+                const int i = i0 + j * G.TB;
+                if (i < nIn) {
+                    cpx<T> t = v[j];
+                    if (!haveB) t.y = 0;
+                    if (BLUE) {
+                        t = cmul(t, ch[j]);
+                        if (i >= p.n) {
+                            t.x = 0;
+                            t.y = 0;
+                        }
+                        lb[swz(i)] = t;
+                    } else {
+                        lb[swz(pos[j])] = t;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <typename T, bool BLUE>
+__device__ __forceinline__ void unpack_pairs_fwd(cpx<T>* __restrict__ buf, const nf::LineArgs<T>& a, const Geo& G) {
+    const nf::LinePlan<T>& p = a.plan;
+    const int n = p.n, nh = n / 2 + 1;
+    const T r = (T)a.scale * (T)0.5;
+    for (int line = G.tl; line < G.nl; line += G.TL) {
+        const int rowA = 2 * (G.line0 + line);
+        const bool haveB = rowA + 1 < a.realH;
+        const cpx<T>* __restrict__ lb = buf + line * p.mPad;
+        cpx<T>* outA = (cpx<T>*)G.outP + (unsigned)rowA * (unsigned)a.realW;
+        for (int k = G.tb; k < nh; k += G.TB) {
+            const int km = k == 0 ? 0 : n - k;
+            cpx<T> zk = lb[swz(k)], zm = lb[swz(km)];
+            if (BLUE) {
+                zk = cmul(cconj(zk), p.chirp[k]);
+                zm = cmul(cconj(zm), p.chirp[km]);
+            }
+            cpx<T> fa, fb;
+            fa.x = r * (zk.x + zm.x);
+            fa.y = r * (zk.y - zm.y);
+            fb.x = r * (zk.y + zm.y);
+            fb.y = -r * (zk.x - zm.x);
+            outA[k] = fa;
+            if (haveB) outA[(unsigned)a.realW + k] = fb;
+        }
+    }
+}
+
+template <typename T, bool BLUE>
+__device__ __forceinline__ void stage_in_pairs_inv(cpx<T>* __restrict__ buf, const nf::LineArgs<T>& a, const Geo& G) {
+    const nf::LinePlan<T>& p = a.plan;
+    const int n = p.n, nIn = BLUE ? p.m : p.n;
+    const T sgn = (T)a.conjInSign;
+    for (int line = G.tl; line < G.nl; line += G.TL) {
+        const int rowA = 2 * (G.line0 + line);
+        const bool haveB = rowA + 1 < a.realH;
+        const cpx<T>* inA = (const cpx<T>*)G.inP + (unsigned)rowA * (unsigned)a.realW;
+        const cpx<T>* inB = inA + (haveB ? (unsigned)a.realW : 0u);
+        cpx<T>* __restrict__ lb = buf + line * p.mPad;
+        for (int i0 = G.tb; i0 < nIn; i0 += NF_STAGE_IN * G.TB) {
+            cpx<T> va[NF_STAGE_IN], vb[NF_STAGE_IN], ch[BLUE ? NF_STAGE_IN : 1];
+            int pos[NF_STAGE_IN];
+#pragma unroll
+            for (int j = 0; j < NF_STAGE_IN; ++j) {
+                const int i = min(i0 + j * G.TB, n - 1);
+                const int k = 2 * i <= n ? i : n - i;
+                va[j] = inA[k];
+                vb[j] = inB[k];
+                if (BLUE)
+                    ch[j] = p.chirp[i];
+                else
+                    pos[j] = p.rev[i];
+            }
+#pragma unroll
+            for (int j = 0; j < NF_STAGE_IN; ++j) {
+                const int i = i0 + j * G.TB;
+                if (i < nIn) {
+                    const int ic = min(i, n - 1);
+                    cpx<T> A = va[j], B = vb[j];
+                    if (2 * ic > n) {              // mirrored half: conjugate
+                        A.y = -A.y;
+                        B.y = -B.y;
+                    }
+                    if (ic == 0 || 2 * ic == n) {  // self-conjugate modes are real
+                        A.y = 0;
+                        B.y = 0;
+                    }
+                    if (!haveB) {
+                        B.x = 0;
+                        B.y = 0;
+                    }
+                    cpx<T> t;
+                    t.x = A.x - B.y;
+                    t.y = (A.y + B.x) * sgn;
+                    if (BLUE) {
+                        t = cmul(t, ch[j]);
+                        if (i >= n) {
+                            t.x = 0;
+                            t.y = 0;
+                        }
+                        lb[swz(i)] = t;
+                    } else {
+                        lb[swz(pos[j])] = t;
+                    }
+                }
+            }
+        }
+    }
+}
+
 // Rows: lines are contiguous in memory (elemStride 1).  LDS layout [line][swz(e)].
-template <typename T, int MODE>
-__global__ void __launch_bounds__(NF_FFT_MAXTHREADS) k_fft_rows(nf::LineArgs<T> a) {
+template <typename T, int MODE, int PAIR>
+__global__ void __launch_bounds__(512) k_fft_rows(nf::LineArgs<T> a) {
     extern __shared__ __align__(16) unsigned char nf_smem[];
     cpx<T>* buf = (cpx<T>*)nf_smem;
     const nf::LinePlan<T>& p = a.plan;
@@ -424,20 +641,37 @@ __global__ void __launch_bounds__(NF_FFT_MAXTHREADS) k_fft_rows(nf::LineArgs<T> 
     // global -> LDS in batches of NF_STAGE_IN loads per thread, all issued before the first LDS store: the copy is
     // latency-bound otherwise (one HBM round trip per element and thread)
     const int it = a.inType == 0 ? 0 : a.inType + (a.apodLine != nullptr ? 2 : 0);
-    switch (it) {
-        case 0: stage_in_rows<T, 0, MODE == 2>(buf, a, G); break;
-        case 1: stage_in_rows<T, 1, MODE == 2>(buf, a, G); break;
-        case 2: stage_in_rows<T, 2, MODE == 2>(buf, a, G); break;
-        case 3: stage_in_rows<T, 3, MODE == 2>(buf, a, G); break;
-        default: stage_in_rows<T, 4, MODE == 2>(buf, a, G); break;
+    if (PAIR == 1) {
+        switch (it) {
+            case 1: stage_in_pairs_fwd<T, 1, MODE == 2>(buf, a, G); break;
+            case 2: stage_in_pairs_fwd<T, 2, MODE == 2>(buf, a, G); break;
+            case 3: stage_in_pairs_fwd<T, 3, MODE == 2>(buf, a, G); break;
+            default: stage_in_pairs_fwd<T, 4, MODE == 2>(buf, a, G); break;
+        }
+    } else if (PAIR == 2) {
+        stage_in_pairs_inv<T, MODE == 2>(buf, a, G);
+    } else {
+        switch (it) {
+            case 0: stage_in_rows<T, 0, MODE == 2>(buf, a, G); break;
+            case 1: stage_in_rows<T, 1, MODE == 2>(buf, a, G); break;
+            case 2: stage_in_rows<T, 2, MODE == 2>(buf, a, G); break;
+            case 3: stage_in_rows<T, 3, MODE == 2>(buf, a, G); break;
+            default: stage_in_rows<T, 4, MODE == 2>(buf, a, G); break;
+        }
     }
     __syncthreads();
     if (MODE == 2) bluestein_middle<T, false, MODE>(buf, a, G);
-    for (int s = 0; s < p.nst; ++s) fft_stage_dispatch<T, false, MODE>(buf, a, s, false, false, s == p.nst - 1, G);
+    if (PAIR == 1) {
+        // the unpacking needs Z[k] and Z[W-k] together: the last stage stays in LDS
+        for (int s = 0; s < p.nst; ++s) fft_stage_dispatch<T, false, MODE, 0>(buf, a, s, false, false, false, G);
+        unpack_pairs_fwd<T, MODE == 2>(buf, a, G);
+        return;
+    }
+    for (int s = 0; s < p.nst; ++s) fft_stage_dispatch<T, false, MODE, PAIR == 2 ? 2 : 0>(buf, a, s, false, false, s == p.nst - 1, G);
 }
 
 // Columns: a tile of TL = linesPerWG adjacent lines (elemStride = row pitch, lineStride 1).  LDS layout [swz(e)][line].
-template <typename T, int MODE>
+template <typename T, int MODE, int SPEC>
 __global__ void __launch_bounds__(NF_FFT_MAXTHREADS) k_fft_cols(nf::LineArgs<T> a) {
     extern __shared__ __align__(16) unsigned char nf_smem[];
     cpx<T>* buf = (cpx<T>*)nf_smem;
@@ -469,7 +703,7 @@ __global__ void __launch_bounds__(NF_FFT_MAXTHREADS) k_fft_cols(nf::LineArgs<T> 
                 if (i < p.n) {
                     const unsigned off = (unsigned)(G.line0 + G.tl) * (unsigned)a.inLineStride + (unsigned)i * (unsigned)a.inElemStride;
                     v = load_elem<T, 0>(a, G.inP, off, 1.0, i);
-                    if (a.fused) v = fused_ops<T>(a, G, v, off, G.line0 + G.tl, i);
+                    if (SPEC == 2) v = fused_ops_herm<T>(a, G, v, off, G.line0 + G.tl, i);
                     v = cmul(v, p.chirp[i]);
                 } else {
                     v.x = 0;
@@ -480,9 +714,9 @@ __global__ void __launch_bounds__(NF_FFT_MAXTHREADS) k_fft_cols(nf::LineArgs<T> 
         }
         __syncthreads();
         bluestein_middle<T, true, MODE>(buf, a, G);
-        for (int s = 0; s < p.nst; ++s) fft_stage_dispatch<T, true, MODE>(buf, a, s, false, false, s == p.nst - 1, G);
+        for (int s = 0; s < p.nst; ++s) fft_stage_dispatch<T, true, MODE, SPEC>(buf, a, s, false, false, s == p.nst - 1, G);
     } else {
-        for (int s = 0; s < p.nst; ++s) fft_stage_dispatch<T, true, MODE>(buf, a, s, false, s == 0, s == p.nst - 1, G);
+        for (int s = 0; s < p.nst; ++s) fft_stage_dispatch<T, true, MODE, SPEC>(buf, a, s, false, s == 0, s == p.nst - 1, G);
     }
 }
 
@@ -710,20 +944,34 @@ int launch_lines(const LineArgs<T>& a, bool cols, int batch, int threads, hipStr
     static bool attrSet[2] = {false, false};
     int which = sizeof(T) == 8 ? 1 : 0;
     if (!attrSet[which]) {
-        NF_HIP(hipFuncSetAttribute((const void*)k_fft_rows<T, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
-        NF_HIP(hipFuncSetAttribute((const void*)k_fft_cols<T, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
-        NF_HIP(hipFuncSetAttribute((const void*)k_fft_rows<T, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
-        NF_HIP(hipFuncSetAttribute((const void*)k_fft_cols<T, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
-        NF_HIP(hipFuncSetAttribute((const void*)k_fft_rows<T, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
-        NF_HIP(hipFuncSetAttribute((const void*)k_fft_cols<T, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds));
+#define NF_ATTR(K) NF_HIP(hipFuncSetAttribute((const void*)K, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds))
+#define NF_ATTR3(KK, M) \
+    NF_ATTR((KK<T, M, 0>)); \
+    NF_ATTR((KK<T, M, 1>)); \
+    NF_ATTR((KK<T, M, 2>))
+        NF_ATTR3(k_fft_rows, 0);
+        NF_ATTR3(k_fft_rows, 1);
+        NF_ATTR3(k_fft_rows, 2);
+        NF_ATTR3(k_fft_cols, 0);
+        NF_ATTR3(k_fft_cols, 1);
+        NF_ATTR3(k_fft_cols, 2);
+#undef NF_ATTR3
+#undef NF_ATTR
         attrSet[which] = true;
     }
     const double npixTotal = (double)a.nLines * a.plan.n * batch;
     const double inB = a.inType == 0 ? sizeof(cpx<T>) : (a.inType == 1 ? 8.0 : 4.0);
     const double outB = a.outType == 0 ? sizeof(cpx<T>) : (a.outType == 1 ? 8.0 : 4.0);
     const int tag = sizeof(T) == 8 ? (cols ? PT_FFT_COLS_F64 : PT_FFT_ROWS_F64) : (cols ? PT_FFT_COLS_F32 : PT_FFT_ROWS_F32);
-    const double fusedIn = cols ? ((a.nSum > 1 ? a.nSum : 1) * (inB + (a.mulF32 ? 4.0 : 0.0))) : inB;
-    ProfScope ps(tag, stream, npixTotal * (fusedIn + outB));
+    // algorithmic bytes per line element: pair lines carry two real rows (or two half-rows); the mirrored store writes the
+    // element twice; the symmetrised load reads it (and its filter value) twice
+    double lineIn = cols ? ((a.nSum > 1 ? a.nSum : 1) * (inB + (a.mulF32 ? 4.0 : 0.0))) : inB, lineOut = outB;
+    if (!cols && a.pairMode == 1) lineIn *= 2.0;
+    if (!cols && a.pairMode == 2) lineOut *= 2.0;
+    if (cols && a.mirror) lineOut *= 2.0;
+    if (cols && a.herm && !a.halfIn) lineIn *= 2.0;
+    if (cols && a.herm && a.halfIn && a.mulF32) lineIn += (a.nSum > 1 ? a.nSum : 1) * 4.0;   // the mirror mode's filter value
+    ProfScope ps(tag, stream, npixTotal * (lineIn + lineOut));
     int mode = a.plan.bluestein ? 2 : 0;
     for (int s = 0; s < a.plan.nst; ++s)
         if (a.plan.st[s].R > 8) mode = 1;
@@ -732,7 +980,14 @@ int launch_lines(const LineArgs<T>& a, bool cols, int batch, int threads, hipStr
         return NF_ERR_SIZE;
     }
     dim3 grid = cols ? dim3(((a.nTiles + 7) / 8) * 8, batch) : dim3(nf_div_up(a.nLines, a.linesPerWG), batch);
-#define NF_LAUNCH(K, M) hipLaunchKernelGGL((K<T, M>), grid, dim3(threads), lds, stream, a)
+    const int spec = cols ? (a.mirror ? 1 : (a.fused ? 2 : 0)) : a.pairMode;
+#define NF_LAUNCH2(K, M, SP) hipLaunchKernelGGL((K<T, M, SP>), grid, dim3(threads), lds, stream, a)
+#define NF_LAUNCH(K, M)                          \
+    do {                                         \
+        if (spec == 0) NF_LAUNCH2(K, M, 0);      \
+        else if (spec == 1) NF_LAUNCH2(K, M, 1); \
+        else NF_LAUNCH2(K, M, 2);                \
+    } while (0)
     if (cols) {
         if (mode == 0) NF_LAUNCH(k_fft_cols, 0);
         else if (mode == 1) NF_LAUNCH(k_fft_cols, 1);
@@ -742,6 +997,7 @@ int launch_lines(const LineArgs<T>& a, bool cols, int batch, int threads, hipStr
         else if (mode == 1) NF_LAUNCH(k_fft_rows, 1);
         else NF_LAUNCH(k_fft_rows, 2);
     }
+#undef NF_LAUNCH2
 #undef NF_LAUNCH
     NF_CHECK_LAUNCH("k_fft_lines");
     return NF_OK;
@@ -792,6 +1048,7 @@ int Plan2D<T>::init(int H_, int W_) {
     if ((size_t)c * colBytes > 80 * 1024) threadsCol = 1024;      // one workgroup per CU: fill it
     if (env_int("NF_FFT_COL_THREADS", 0) > 0) threadsCol = env_int("NF_FFT_COL_THREADS", 0);
     threadsCol = std::max(threadsCol, colsPerWG);
+    useReal = env_int("NF_FFT_REAL", 1);
     return NF_OK;
 }
 
@@ -817,6 +1074,8 @@ static LineArgs<T> row_args(const Plan2D<T>& P, const void* in, void* out, int i
     a.outLineStride = P.W;
     a.outBatchStride = (long long)P.H * P.W;
     a.conjInSign = a.conjOutSign = a.scale = 1.0;
+    a.realH = P.H;
+    a.realW = P.W;
     a.nLines = P.H;
     a.linesPerWG = P.rowsPerWG;
     a.tb = P.tbRow;
@@ -839,6 +1098,8 @@ static LineArgs<T> col_args(const Plan2D<T>& P, const void* in, void* out) {
     c.outLineStride = 1;
     c.outBatchStride = (long long)P.H * P.W;
     c.conjInSign = c.conjOutSign = c.scale = 1.0;
+    c.realH = P.H;
+    c.realW = P.W;
     c.nLines = P.W;
     c.linesPerWG = P.colsPerWG;
     c.nTiles = nf_div_up(P.W, P.colsPerWG);
@@ -849,14 +1110,27 @@ static LineArgs<T> col_args(const Plan2D<T>& P, const void* in, void* out) {
 // result divided by `scale` if scaleDiv (enmap.fft: sqrt(H*W)).
 template <typename T>
 int Plan2D<T>::forward(const void* in, int inType, void* out, int batch, const double* apodY, const double* apodX,
-                       int scaleDiv, double scale, hipStream_t stream) {
+                       int scaleDiv, double scale, hipStream_t stream, int half) {
     LineArgs<T> a = row_args<T>(*this, in, out, inType, 0);
     a.apodLine = apodY;
     a.apodElem = apodX;
-    int rc = launch_lines<T>(a, false, batch, threadsRow, stream);
-    if (rc) return rc;
     LineArgs<T> c = col_args<T>(*this, out, out);
     if (scaleDiv) c.scale = 1.0 / scale;
+    if (half && inType == 0) {
+        nf_set_error("half-stored spectra are spectra of real maps: the input must be real");
+        return NF_ERR_ARG;
+    }
+    if (inType != 0 && (useReal || half)) {
+        // real map: two rows per complex line, half of the columns; the other half by conjugate symmetry, or (half) left
+        // unwritten for consumers that know F[-y][-c] = conj F[y][c]
+        a.pairMode = 1;
+        a.nLines = (H + 1) / 2;
+        c.mirror = half ? 0 : 1;
+        c.nLines = W / 2 + 1;
+        c.nTiles = nf_div_up(c.nLines, colsPerWG);
+    }
+    int rc = launch_lines<T>(a, false, batch, threadsRow, stream);
+    if (rc) return rc;
     return launch_lines<T>(c, true, batch, threadsCol, stream);
 }
 
@@ -865,7 +1139,7 @@ int Plan2D<T>::forward(const void* in, int inType, void* out, int batch, const d
 template <typename T>
 int Plan2D<T>::inverse(const void* in, void* work, void* out, int outType, int batch, int scaleDiv, double scale,
                        hipStream_t stream, const float* filt, int nSum, long long filtBatchStride, const double* winY,
-                       const double* winX) {
+                       const double* winX, int halfIn) {
     LineArgs<T> c = col_args<T>(*this, in, work);
     c.conjInSign = -1.0;  // conj(FFT(conj x)): the conj between the two passes cancels, so only the ends matter
     c.mulF32 = filt;
@@ -875,11 +1149,28 @@ int Plan2D<T>::inverse(const void* in, void* work, void* out, int outType, int b
     c.winLine = winX;
     c.winElem = winY;
     c.fused = (filt != nullptr || winY != nullptr) ? 1 : 0;
-    int rc = launch_lines<T>(c, true, batch, threadsCol, stream);
-    if (rc) return rc;
     LineArgs<T> a = row_args<T>(*this, work, out, 0, outType);
     a.conjOutSign = -1.0;
     if (scaleDiv) a.scale = 1.0 / scale;
+    if (halfIn && outType == 0) {
+        nf_set_error("a half-stored spectrum has a real inverse transform: ask for real output");
+        return NF_ERR_ARG;
+    }
+    if (outType != 0 && (useReal || halfIn)) {
+        // only the real part is wanted: transform the symmetrised spectrum - half of the columns, two rows per line.
+        // The half plane left in `work` is conj(column-inverse), which is Hermitian along x like the column-inverse
+        // itself; packed as Z = V1 + i V2 its forward row transform is x1 + i x2 with no conjugation at either end.
+        c.herm = 1;
+        c.halfIn = halfIn ? 1 : 0;
+        c.fused = 1;
+        c.nLines = W / 2 + 1;
+        c.nTiles = nf_div_up(c.nLines, colsPerWG);
+        a.pairMode = 2;
+        a.nLines = (H + 1) / 2;
+        a.conjOutSign = 1.0;
+    }
+    int rc = launch_lines<T>(c, true, batch, threadsCol, stream);
+    if (rc) return rc;
     return launch_lines<T>(a, false, batch, threadsRow, stream);
 }
 

@@ -10,9 +10,9 @@ struct WeightVec {
 
 // nf_pointwise.hip
 template <typename T>
-int cross_power(const void* F, void* NP, int N, long long npix, hipStream_t s);
+int cross_power(const void* F, void* NP, int N, long long npix, hipStream_t s, int halfH = 0, int halfW = 0);
 int build_filter(int covType, int sigType, const void* cov, const void* S, const WeightVec& w, float* filt, int N,
-                 long long npix, hipStream_t s);
+                 long long npix, hipStream_t s, int halfH = 0, int halfW = 0);
 template <typename T>
 int apply_filter(const void* F, const float* filt, void* G, int N, int sum, long long npix, hipStream_t s);
 template <typename T>

@@ -21,14 +21,25 @@ static inline int grid_for(long long n, int threads) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ void k_cross_power(const cpx<T>* __restrict__ F, T* __restrict__ NP, int N, long long npix) {
+// Half-stored spectra (nf_fft2_forward_half): the plane has the full pitch W but only the columns c <= W/2 hold values;
+// mode (y, c) with c > W/2 is the conjugate of the stored mode (-y, -c).  The consumers here need |F| or Re(F_i conj F_j),
+// which do not change under a common conjugation, so they only redirect the read.
+__device__ __forceinline__ long long half_src(long long p, int H, int W) {
+    const unsigned y = (unsigned)(p / W), x = (unsigned)(p - (long long)y * W);
+    if (2u * x <= (unsigned)W) return p;
+    const unsigned ym = y == 0u ? 0u : (unsigned)H - y;
+    return (long long)ym * W + ((unsigned)W - x);
+}
+
+template <typename T, bool HALF>
+__global__ void k_cross_power(const cpx<T>* __restrict__ F, T* __restrict__ NP, int N, long long npix, int H, int W) {
     // NP layout [N][N][npix]; only j >= i computed, mirrored (the product is commutative bit for bit)
     for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < npix; p += (long long)gridDim.x * blockDim.x) {
+        const long long ps = HALF ? half_src(p, H, W) : p;
         for (int i = 0; i < N; ++i) {
-            cpx<T> a = F[(long long)i * npix + p];
+            cpx<T> a = F[(long long)i * npix + ps];
             for (int j = i; j < N; ++j) {
-                cpx<T> b = F[(long long)j * npix + p];
+                cpx<T> b = F[(long long)j * npix + ps];
                 // np.real(a * conj(b)) = a.x*b.x + a.y*b.y, evaluated as numpy does: two products, one add
                 T v = a.x * b.x + a.y * b.y;
                 NP[((long long)i * N + j) * npix + p] = v;
@@ -39,26 +50,32 @@ __global__ void k_cross_power(const cpx<T>* __restrict__ F, T* __restrict__ NP, 
 }
 
 template <typename T>
-int cross_power(const void* F, void* NP, int N, long long npix, hipStream_t s) {
-    hipLaunchKernelGGL(k_cross_power<T>, dim3(grid_for(npix, 256)), dim3(256), 0, s, (const cpx<T>*)F, (T*)NP, N, npix);
+int cross_power(const void* F, void* NP, int N, long long npix, hipStream_t s, int halfH, int halfW) {
+    if (halfH > 0)
+        hipLaunchKernelGGL((k_cross_power<T, true>), dim3(grid_for(npix, 256)), dim3(256), 0, s, (const cpx<T>*)F, (T*)NP, N,
+                           npix, halfH, halfW);
+    else
+        hipLaunchKernelGGL((k_cross_power<T, false>), dim3(grid_for(npix, 256)), dim3(256), 0, s, (const cpx<T>*)F, (T*)NP, N,
+                           npix, 0, 0);
     NF_CHECK_LAUNCH("k_cross_power");
     return NF_OK;
 }
-template int cross_power<float>(const void*, void*, int, long long, hipStream_t);
-template int cross_power<double>(const void*, void*, int, long long, hipStream_t);
+template int cross_power<float>(const void*, void*, int, long long, hipStream_t, int, int);
+template int cross_power<double>(const void*, void*, int, long long, hipStream_t, int, int);
 
 // ---------------------------------------------------------------------------------------------------
 // N x N inverse by LU with partial pivoting in the covariance precision T (np.linalg.inv -> LAPACK gesv),
 // then a float64 matrix-vector product with w*|S| (numpy promotes the f32 inverse to f64 in np.dot),
 // stored as float32.  A singular pivot leaves the mode at zero, like the reference's try/except.
-template <typename T, typename TS, int N>
+template <typename T, typename TS, int N, bool HALF>
 __global__ void k_build_filter(const T* __restrict__ cov, const cpx<TS>* __restrict__ S, nf::WeightVec w,
-                               float* __restrict__ filt, long long npix) {
+                               float* __restrict__ filt, long long npix, int H, int W) {
     for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < npix; p += (long long)gridDim.x * blockDim.x) {
         double rhs[N];
+        const long long ps = HALF ? half_src(p, H, W) : p;
 #pragma unroll
         for (int i = 0; i < N; ++i) {
-            cpx<TS> s = S[(long long)i * npix + p];
+            cpx<TS> s = S[(long long)i * npix + ps];
             // np.abs(complex) = hypot; computed in the template precision TS, then promoted
             TS mag = (sizeof(TS) == 4) ? (TS)hypotf((float)s.x, (float)s.y) : (TS)hypot((double)s.x, (double)s.y);
             rhs[i] = w.v[i] * (double)mag;
@@ -145,11 +162,17 @@ __global__ void k_build_filter(const T* __restrict__ cov, const cpx<TS>* __restr
 }
 
 template <typename T, typename TS>
-static int build_filter_n(const void* cov, const void* S, const WeightVec& w, float* filt, int N, long long npix, hipStream_t s) {
+static int build_filter_n(const void* cov, const void* S, const WeightVec& w, float* filt, int N, long long npix, hipStream_t s,
+                          int halfH, int halfW) {
     dim3 g(grid_for(npix, 256)), b(256);
-#define NF_BF(NN)                                                                                                   \
-    case NN:                                                                                                        \
-        hipLaunchKernelGGL((k_build_filter<T, TS, NN>), g, b, 0, s, (const T*)cov, (const cpx<TS>*)S, w, filt, npix); \
+#define NF_BF(NN)                                                                                                       \
+    case NN:                                                                                                            \
+        if (halfH > 0)                                                                                                  \
+            hipLaunchKernelGGL((k_build_filter<T, TS, NN, true>), g, b, 0, s, (const T*)cov, (const cpx<TS>*)S, w, filt, npix, \
+                               halfH, halfW);                                                                           \
+        else                                                                                                            \
+            hipLaunchKernelGGL((k_build_filter<T, TS, NN, false>), g, b, 0, s, (const T*)cov, (const cpx<TS>*)S, w, filt, npix, \
+                               0, 0);                                                                                   \
         break;
     switch (N) {
         NF_BF(1)
@@ -168,11 +191,11 @@ static int build_filter_n(const void* cov, const void* S, const WeightVec& w, fl
 }
 
 int build_filter(int covType, int sigType, const void* cov, const void* S, const WeightVec& w, float* filt, int N,
-                 long long npix, hipStream_t s) {
-    if (covType == NF_F64 && sigType == NF_F32) return build_filter_n<double, float>(cov, S, w, filt, N, npix, s);
-    if (covType == NF_F64 && sigType == NF_F64) return build_filter_n<double, double>(cov, S, w, filt, N, npix, s);
-    if (covType == NF_F32 && sigType == NF_F32) return build_filter_n<float, float>(cov, S, w, filt, N, npix, s);
-    if (covType == NF_F32 && sigType == NF_F64) return build_filter_n<float, double>(cov, S, w, filt, N, npix, s);
+                 long long npix, hipStream_t s, int halfH, int halfW) {
+    if (covType == NF_F64 && sigType == NF_F32) return build_filter_n<double, float>(cov, S, w, filt, N, npix, s, halfH, halfW);
+    if (covType == NF_F64 && sigType == NF_F64) return build_filter_n<double, double>(cov, S, w, filt, N, npix, s, halfH, halfW);
+    if (covType == NF_F32 && sigType == NF_F32) return build_filter_n<float, float>(cov, S, w, filt, N, npix, s, halfH, halfW);
+    if (covType == NF_F32 && sigType == NF_F64) return build_filter_n<float, double>(cov, S, w, filt, N, npix, s, halfH, halfW);
     nf_set_error("build_filter: bad dtype");
     return NF_ERR_ARG;
 }

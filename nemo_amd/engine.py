@@ -152,8 +152,12 @@ class TileEngine(object):
         return self._gauss[key]
 
     # ---- FFTs ----------------------------------------------------------------------------------------------
-    def fft(self, x, prec=None, apod=False, unitary=True):
-        """enmap.fft of [B,H,W] or [H,W]; real input is promoted to the complex type of ``prec``."""
+    def fft(self, x, prec=None, apod=False, unitary=True, half=False):
+        """enmap.fft of [B,H,W] or [H,W]; real input is promoted to the complex type of ``prec``.
+
+        ``half`` (real input only): a half-stored spectrum comes back - same [.., H, W] shape, but only the columns
+        x <= W/2 hold values (include/nemofilt.h, "half-stored spectra").  Hand it only to ifft(half=True),
+        cross_power(half=True) and build_filter(half=True)."""
         t = self.t
         x3 = x.reshape(-1, self.H, self.W)
         if x3.is_complex():
@@ -164,22 +168,27 @@ class TileEngine(object):
             if prec is None:
                 prec = NF_F64 if x3.dtype == t.float64 else NF_F32
         out = t.empty(x3.shape, dtype=t.complex128 if prec == NF_F64 else t.complex64, device=self.dev)
-        check(self.lib.nf_fft2_forward(self.plan, prec, ptr(x3), inType, ptr(out), x3.shape[0],
-                                       ptr(self.apodY) if apod else None, ptr(self.apodX) if apod else None,
-                                       1 if unitary else 0, stream_ptr()), "nf_fft2_forward")
+        if half and inType == IN_COMPLEX:
+            raise NemoFiltError("half-stored spectra are spectra of real maps")
+        fwd = self.lib.nf_fft2_forward_half if half else self.lib.nf_fft2_forward
+        check(fwd(self.plan, prec, ptr(x3), inType, ptr(out), x3.shape[0],
+                  ptr(self.apodY) if apod else None, ptr(self.apodX) if apod else None,
+                  1 if unitary else 0, stream_ptr()), "nf_fft2_forward")
         return out.reshape(x.shape)
 
-    def ifft(self, X, out='complex', unitary=False, clobber=False, filt=None, sum=False, window=None):
+    def ifft(self, X, out='complex', unitary=False, clobber=False, filt=None, sum=False, window=None, half=False):
         """enmap.ifft; ``out`` in {'complex', 'f64', 'f32'} (the latter two keep the real part only).
 
         ``filt`` (float32 [N,H,W] or [H,W]) and ``window`` (power of the pixel window) are multiplied in while the
         transform loads its input (nemo/filters.py:847 and enmap.apply_window); with ``sum`` the N planes of X are summed
-        after the product and one map comes out."""
+        after the product and one map comes out.  ``half``: X holds half-stored spectra (fft(half=True)); real output only."""
         t = self.t
         X3 = X.reshape(-1, self.H, self.W)
         prec = prec_of(X3)
-        if filt is not None or window is not None:
-            return self._ifft_fused(X3, X.shape, out, unitary, clobber, filt, sum, window)
+        if half and out == 'complex':
+            raise NemoFiltError("the inverse transform of a half-stored spectrum is real")
+        if filt is not None or window is not None or half:
+            return self._ifft_fused(X3, X.shape, out, unitary, clobber, filt, sum, window, half)
         work = X3 if clobber else t.empty_like(X3)
         if out == 'complex':
             res = t.empty_like(X3)
@@ -194,7 +203,7 @@ class TileEngine(object):
                                        1 if unitary else 0, stream_ptr()), "nf_fft2_inverse")
         return res.reshape(X.shape)
 
-    def _ifft_fused(self, X3, shape, out, unitary, clobber, filt, sum, window):
+    def _ifft_fused(self, X3, shape, out, unitary, clobber, filt, sum, window, half=False):
         t = self.t
         prec = prec_of(X3)
         N = X3.shape[0]
@@ -221,20 +230,23 @@ class TileEngine(object):
             res, outType = t.empty(outShape, dtype=t.float64, device=self.dev), IN_REAL64
         else:
             res, outType = t.empty(outShape, dtype=t.float32, device=self.dev), IN_REAL32
-        check(self.lib.nf_fft2_inverse_fused(self.plan, prec, ptr(X3), ptr(f3), nSum, perBatch, ptr(wy), ptr(wx), ptr(work),
-                                             ptr(res), outType, batch, 1 if unitary else 0, stream_ptr()),
-              "nf_fft2_inverse_fused")
+        inv = self.lib.nf_fft2_inverse_half if half else self.lib.nf_fft2_inverse_fused
+        check(inv(self.plan, prec, ptr(X3), ptr(f3), nSum, perBatch, ptr(wy), ptr(wx), ptr(work),
+                  ptr(res), outType, batch, 1 if unitary else 0, stream_ptr()), "nf_fft2_inverse_fused")
         if sum:
             return res.reshape(self.H, self.W)
         return res.reshape(shape)
 
     # ---- Fourier-domain pointwise --------------------------------------------------------------------------
-    def cross_power(self, F):
+    def cross_power(self, F, half=False):
         t = self.t
         N = F.shape[0]
         prec = prec_of(F)
         NP = t.empty((N, N, self.H, self.W), dtype=t.float64 if prec == NF_F64 else t.float32, device=self.dev)
-        check(self.lib.nf_cross_power(prec, ptr(F), ptr(NP), N, self.npix, stream_ptr()), "nf_cross_power")
+        if half:
+            check(self.lib.nf_cross_power_half(prec, ptr(F), ptr(NP), N, self.H, self.W, stream_ptr()), "nf_cross_power_half")
+        else:
+            check(self.lib.nf_cross_power(prec, ptr(F), ptr(NP), N, self.npix, stream_ptr()), "nf_cross_power")
         return NP
 
     def gaussian_filter(self, x, sigmaYX):
@@ -249,13 +261,17 @@ class TileEngine(object):
                                           ptr(wY), rY, ptr(wX), rX, stream_ptr()), "nf_gaussian_filter")
         return out.reshape(x.shape)
 
-    def build_filter(self, noiseCov, fSignals, w):
+    def build_filter(self, noiseCov, fSignals, w, half=False):
         t = self.t
         N = fSignals.shape[0]
         filt = t.empty((N, self.H, self.W), dtype=t.float32, device=self.dev)
         warr = (ctypes.c_double * N)(*[float(v) for v in w])
-        check(self.lib.nf_build_filter(prec_of(noiseCov), prec_of(fSignals), ptr(noiseCov), ptr(fSignals), warr,
-                                       ptr(filt), N, self.npix, stream_ptr()), "nf_build_filter")
+        if half:
+            check(self.lib.nf_build_filter_half(prec_of(noiseCov), prec_of(fSignals), ptr(noiseCov), ptr(fSignals), warr,
+                                                ptr(filt), N, self.H, self.W, stream_ptr()), "nf_build_filter_half")
+        else:
+            check(self.lib.nf_build_filter(prec_of(noiseCov), prec_of(fSignals), ptr(noiseCov), ptr(fSignals), warr,
+                                           ptr(filt), N, self.npix, stream_ptr()), "nf_build_filter")
         return filt
 
     def apply_filter(self, F, filt, sum=True):
@@ -275,8 +291,8 @@ class TileEngine(object):
 
     def apply_window(self, m, pow):
         """enmap.apply_window(m, pow): real [H,W] map in, real map of the same dtype out."""
-        F = self.fft(m, unitary=True)
-        return self.ifft(F, out='f64' if m.dtype == self.t.float64 else 'f32', unitary=True, clobber=True, window=pow)
+        F = self.fft(m, unitary=True, half=True)
+        return self.ifft(F, out='f64' if m.dtype == self.t.float64 else 'f32', unitary=True, clobber=True, window=pow, half=True)
 
     # ---- templates -----------------------------------------------------------------------------------------
     def paint(self, geom, table):

@@ -338,7 +338,7 @@ class MatchedFilter(MapFilter):
             fMapsToFilter = shared['fMapsToFilter']
         else:
             dCube = t.stack(self._dData).contiguous() if N > 1 else self._dData[0].reshape(1, *self.shape)
-            fMapsToFilter = eng.fft(dCube, apod=True)                             # :523-526  K1+K2
+            fMapsToFilter = eng.fft(dCube, apod=True, half=True)                          # :523-526  K1+K2
             del dCube
             if shared is not None:
                 shared['fMapsToFilter'] = fMapsToFilter
@@ -360,7 +360,7 @@ class MatchedFilter(MapFilter):
                 noiseCov = shared[('noiseCov', method)]
             else:
                 fMapsForNoise = fMapsToFilter                                     # identical to :548 without a catalog
-                NP = eng.cross_power(fMapsForNoise)                               # :573  K4
+                NP = eng.cross_power(fMapsForNoise, half=True)                            # :573  K4
                 if method == 'max(dataMap,CMB)':
                     NPCMB = engine.to_dev(self.makeForegroundsPower().astype(_asnumpy(NP[0, 0, :1, :1]).dtype))
                     NP = t.maximum(NP, NPCMB)
@@ -370,9 +370,9 @@ class MatchedFilter(MapFilter):
                     shared[('noiseCov', method)] = noiseCov
 
             w = self._frequencyWeights()                                          # :587-608
-            fSignals = [eng.fft(self._paintTemplate(m['beamFileName'])) for m in self.unfilteredMapsDictList]   # :611-618
+            fSignals = [eng.fft(self._paintTemplate(m['beamFileName']), half=True) for m in self.unfilteredMapsDictList]   # :611-618
             fSignals = t.stack(fSignals) if N > 1 else fSignals[0].reshape(1, *self.shape)
-            self._dFilt = eng.build_filter(noiseCov, fSignals, w)                 # :621-627  K6
+            self._dFilt = eng.build_filter(noiseCov, fSignals, w, half=True)              # :621-627  K6
             del noiseCov
 
             if self.params['outputUnits'] == 'yc':                                # :632-668
@@ -388,9 +388,9 @@ class MatchedFilter(MapFilter):
                     else:
                         deltaT0 = maps.convertToDeltaT(y0, mapDict['obsFreqGHz'])
                         signalMap = self._paintTemplate(mapDict['beamFileName'], amplitude=deltaT0)
-                    fSignalMaps.append(eng.fft(signalMap))                         # :644-646  K8
+                    fSignalMaps.append(eng.fft(signalMap, half=True))                      # :644-646  K8
                 fSignalMaps = t.stack(fSignalMaps) if N > 1 else fSignalMaps[0].reshape(1, *self.shape)
-                filteredSignal = self._applyFilterDevice(fSignalMaps, window=1.0)
+                filteredSignal = self._applyFilterDevice(fSignalMaps, window=1.0, half=True)
                 cRADeg, cDecDeg = self.wcs.getCentreWCSCoords()
                 cx, cy = self.wcs.wcs2pix(cRADeg, cDecDeg)
                 # signalNorm = y0 / peak stays on the device (float64 division there): the host goes on enqueueing
@@ -405,14 +405,14 @@ class MatchedFilter(MapFilter):
                 else:
                     maxValue, maxIndex = eng.map_max(filteredSignal)              # :661
                     totalSignal = np.float32(maxValue)
-                    planes = eng.ifft(fSignalMaps, out='f32', filt=self._dFilt, window=1.0)       # :662-667
+                    planes = eng.ifft(fSignalMaps, out='f32', filt=self._dFilt, window=1.0, half=True)       # :662-667
                     vals = planes.reshape(N, -1)[:, maxIndex].cpu().numpy()
                     for i, mapDict in enumerate(self.unfilteredMapsDictList):
                         self.fRelWeights[mapDict['obsFreqGHz']] = np.float32(vals[i]) / totalSignal
                 del fSignalMaps
             elif self.params['outputUnits'] == 'uK':                              # :669-685
                 # the reference paints and transforms the unit templates a second time (:672-679): same values as fSignals
-                filteredSignal = self._applyFilterDevice(fSignals)
+                filteredSignal = self._applyFilterDevice(fSignals, half=True)
                 mm = eng.map_max(filteredSignal, to_host=False)                   # :684, float32 arithmetic, on the device
                 self._signalNorm = engine.DeviceScalar((1.0 / mm[:1].to(t.float32)).to(t.float64), wide=False)
             else:
@@ -427,7 +427,7 @@ class MatchedFilter(MapFilter):
             self.params['savePlots'] = False
 
         # Apply filter (:696), point-source mask (:714)
-        filtered32 = self._applyFilterDevice(fMapsToFilter, scale=False)
+        filtered32 = self._applyFilterDevice(fMapsToFilter, scale=False, half=True)
         del fMapsToFilter
         mapUnits, combinedObsFreqGHz, beamSolidAngle_nsr = self._unitsInfo()
         dFiltered = eng.scale_mask(filtered32, self._signalNorm, self._dPSMask)
@@ -495,8 +495,9 @@ class MatchedFilter(MapFilter):
         raise NotImplementedError("reshapeFilter (nemo/filters.py:793-817) is only reached when map and filter shapes "
                                   "differ; not part of this build yet")
 
-    def _applyFilterDevice(self, cube, scale=True, window=None):
-        """Device form of applyFilter: complex (Fourier) or real [N,H,W] tensor in, float32 [H,W] map out; with
+    def _applyFilterDevice(self, cube, scale=True, window=None, half=False):
+        """Device form of applyFilter: complex (Fourier) or real [N,H,W] tensor in, float32 [H,W] map out (``half``: the
+        complex cube holds half-stored spectra of real maps, as eng.fft(half=True) returns them); with
         ``scale`` the map is multiplied by signalNorm exactly as nemo/filters.py:853 does (numpy promotion).  The
         product with the filter, the frequency sum (moved in front of the inverse transform, which is linear) and an
         optional pixel-window factor are applied while the inverse transform loads the Fourier planes."""
@@ -507,9 +508,10 @@ class MatchedFilter(MapFilter):
         if cube.is_complex():
             fMaps = cube
         else:
-            fMaps = eng.fft(cube, apod=True)                                      # :845
+            fMaps = eng.fft(cube, apod=True, half=True)                           # :845
+            half = True
         out = eng.ifft(fMaps.reshape(-1, *self.shape), out='f32', unitary=False, filt=self._dFilt, sum=True,
-                       window=window)                                            # :847  K7 + K3
+                       window=window, half=half)                                 # :847  K7 + K3
         if 'bckSub' in self.params.keys() and 'bckSubScaleArcmin' in self.params.keys() and self.params['bckSub'] == True:
             out = maps.subtractBackground(out, self.wcs, smoothScaleDeg=self.params['bckSubScaleArcmin'] / 60.)   # :850-851
         if scale:

@@ -141,6 +141,57 @@ def test_fused_inverse(shape, dtype, N):
     assert np.array_equal(_np(dF), F)
 
 
+@pytest.mark.parametrize("shape", [(96, 120), (129, 86), (64, 1031), (1031, 48), (840, 1440)])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("N", [1, 2])
+def test_half_stored_spectra(shape, dtype, N):
+    """The *_half entry points (include/nemofilt.h): spectra of real maps stored for the columns x <= W/2 only.  Forward
+    against enmap.fft of the same maps on those columns; cross power, filter build and the filtered inverse against the
+    numpy statements on the full spectra (a filter that is NOT symmetric under k -> -k, like the smoothed noise power)."""
+    rng = np.random.default_rng(31)
+    eng = _eng(shape)
+    H, W = shape
+    hw = W // 2 + 1
+    x = rng.standard_normal((N,) + shape).astype(dtype)
+    tol = 1e-12 if dtype == np.float64 else 3e-5
+    dx = engine.to_dev(x)
+    for apod in (False, True):
+        Fh = eng.fft(dx, apod=apod, half=True)
+        ref = enmap.fft((enmap.apod(x, 20) if apod else x).astype(np.float64))
+        assert np.abs(_np(Fh)[..., :hw] - ref[..., :hw]).max() <= tol * np.abs(ref).max()
+    # the stored half is what the full-spectrum call writes there, bit for bit (same kernels, same order)
+    Ffull = _np(eng.fft(dx, apod=True))
+    assert np.array_equal(_np(Fh)[..., :hw], Ffull[..., :hw])
+    # poison the columns that carry no values: nothing may read them
+    Fh[..., hw:] = float('nan')
+    NP = _np(eng.cross_power(Fh, half=True))
+    refNP = _np(eng.cross_power(engine.to_dev(Ffull)))
+    assert np.array_equal(NP, refNP)
+    cov = np.abs(refNP) + np.eye(N)[:, :, None, None] * np.abs(refNP).max()
+    w = rng.uniform(0.5, 2, N)
+    filtH = _np(eng.build_filter(engine.to_dev(cov), Fh, w, half=True))
+    filtF = _np(eng.build_filter(engine.to_dev(cov), engine.to_dev(Ffull), w))
+    assert np.array_equal(filtH, filtF)
+    # filtered inverse: asymmetric float32 filter, window, frequency sum
+    filt = rng.standard_normal((N,) + shape).astype(np.float32)
+    dfilt = engine.to_dev(filt)
+    win = np.sinc(np.fft.fftfreq(H))[:, None] * np.sinc(np.fft.fftfreq(W))[None, :]
+    out = 'f64' if dtype == np.float64 else 'f32'
+    Fd = Ffull.astype(np.complex128)
+    ref = np.real(enmap.ifft(Fd * filt, normalize=False)).sum(axis=0)
+    got = _np(eng.ifft(Fh, out=out, filt=dfilt, sum=True, half=True))
+    assert got.shape == shape
+    assert np.abs(got - ref).max() <= tol * np.abs(ref).max()
+    ref = np.real(enmap.ifft(Fd * win * filt, normalize=False))
+    got = _np(eng.ifft(Fh, out=out, filt=dfilt, window=1.0, half=True))
+    assert np.abs(got - ref).max() <= tol * np.abs(ref).max()
+    # plain round trip
+    got = _np(eng.ifft(Fh, out=out, unitary=True, half=True))
+    assert np.abs(got - enmap.apod(x, 20)).max() <= (1e-12 if dtype == np.float64 else 2e-5)
+    with pytest.raises(Exception):
+        eng.ifft(Fh, out='complex', half=True)
+
+
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_gaussian_filter_and_background(dtype):
     shape = (211, 256)

@@ -1,6 +1,6 @@
 // Micro-benchmark of the 2-D FFT entry points through the C ABI (include/nemofilt.h): per-pass device time from the
 // library's own HIP-event profiler, algorithmic GB/s (each pass reads and writes the plane once).
-//   fftbench H W prec(0=f32,1=f64) batch reps
+//   fftbench H W prec(0=f32,1=f64) batch reps mode(0 = complex, 1 = real map <-> full spectrum, 2 = real map <-> half-stored spectrum)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -14,6 +14,7 @@
 int main(int argc, char** argv) {
     int H = argc > 1 ? atoi(argv[1]) : 4096, W = argc > 2 ? atoi(argv[2]) : 4096;
     int prec = argc > 3 ? atoi(argv[3]) : 1, batch = argc > 4 ? atoi(argv[4]) : 1, reps = argc > 5 ? atoi(argv[5]) : 10;
+    int mode = argc > 6 ? atoi(argv[6]) : 0;
     size_t es = prec ? 16 : 8;
     size_t n = (size_t)H * W * batch;
     void *a, *b, *c;
@@ -27,6 +28,35 @@ int main(int argc, char** argv) {
     HK(hipMemcpy(a, h.data(), n * es, hipMemcpyHostToDevice));
     nf_plan* plan;
     CK(nf_plan_create(H, W, &plan));
+    if (mode != 0) {
+        // real maps of the precision's own real type: a [batch][H][W] real array at the start of `a`, real output into `c`
+        const int rt = prec ? NF_IN_REAL64 : NF_IN_REAL32;
+        nf_profile_enable(1);
+        for (int i = 0; i < reps + 2; ++i) {
+            if (i == 2) { HK(hipDeviceSynchronize()); nf_profile_enable(0); nf_profile_enable(1); }
+            if (mode == 1) {
+                CK(nf_fft2_forward(plan, prec, a, rt, b, batch, nullptr, nullptr, 1, nullptr));
+                CK(nf_fft2_inverse(plan, prec, b, b, c, rt, batch, 1, nullptr));
+            } else {
+                CK(nf_fft2_forward_half(plan, prec, a, rt, b, batch, nullptr, nullptr, 1, nullptr));
+                CK(nf_fft2_inverse_half(plan, prec, b, nullptr, 1, 0, nullptr, nullptr, b, c, rt, batch, 1, nullptr));
+            }
+        }
+        HK(hipDeviceSynchronize());
+        std::vector<float> r(n * es / 8);
+        HK(hipMemcpy(r.data(), c, n * es / 2, hipMemcpyDeviceToHost));
+        double maxerr = 0;
+        if (prec) { double *x = (double*)h.data(), *y = (double*)r.data(); for (size_t i = 0; i < n; ++i) { double e = x[i] - y[i]; if (e < 0) e = -e; if (e > maxerr) maxerr = e; } }
+        else for (size_t i = 0; i < n; ++i) { double e = h[i] - r[i]; if (e < 0) e = -e; if (e > maxerr) maxerr = e; }
+        printf("H=%d W=%d prec=%s batch=%d mode=%s roundtrip_maxerr=%.3g\n", H, W, prec ? "f64" : "f32", batch, mode == 1 ? "real/full" : "real/half", maxerr);
+        for (int t = 0; t < nf_profile_num_tags(); ++t) {
+            long long cnt; double ms, by;
+            CK(nf_profile_read(t, &cnt, &ms, &by));
+            if (cnt > 0) printf("  %-14s calls=%lld avg_us=%.1f GB/s=%.0f\n", nf_profile_tag_name(t), cnt, 1e3 * ms / cnt, by / 1e9 / (ms / 1e3));
+        }
+        nf_plan_destroy(plan);
+        return 0;
+    }
     for (int i = 0; i < 2; ++i) {
         CK(nf_fft2_forward(plan, prec, a, NF_IN_COMPLEX, b, batch, nullptr, nullptr, 1, nullptr));
         CK(nf_fft2_inverse(plan, prec, b, c, c, NF_IN_COMPLEX, batch, 1, nullptr));

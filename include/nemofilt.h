@@ -135,10 +135,12 @@ int nf_scale_mask_dev(int vtype, const float* in_d, void* out_d, const double* s
 /* MapFilter.makeNoiseMap, grid mode (nemo/filters.py:407-478): local clipped RMS in ny x nx cells (edges as
  * np.linspace(..., dtype=int), device int arrays of ny+1 / nx+1 entries), each widened by `overlap` pixels,
  * with `numBins` weight-percentile bins per cell (quantiles: numBins host doubles = percentiles/100).
- * weights_d: the median weight map (float32/float64).  work_d: nf_noise_workspace_bytes() bytes of device scratch.
+ * weights_d: the median weight map (float32/float64).  work_d: nf_noise_workspace_bytes() bytes of device scratch (for the
+ * default estimator with one bin this includes the per-block sums and tail lists of the single-read evaluation, about
+ * 2 bytes per pixel).
  * estimator: 0 = 3-sigma clipped standard deviation (10 iterations, the default), 1 = RMSEstimator 'percentile'
  * (np.percentile(abs(values), 68.3), nemo/filters.py:459-460).  'biweight' needs astropy.stats and is not provided. */
-size_t nf_noise_workspace_bytes(int ny, int nx, int numBins);
+size_t nf_noise_workspace_bytes(int H, int W, int ny, int nx, int numBins);
 int nf_noise_map(int vtype, const void* filtered_d, const void* weights_d, int wtype, float* rms_d, int H, int W,
                  int ny, int nx, const int* yEdges_d, const int* xEdges_d, int overlap, int numBins,
                  const double* quantiles, int estimator, void* work_d, size_t workBytes, void* stream);

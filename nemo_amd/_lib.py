@@ -53,7 +53,7 @@ SIGNATURES = {
                                 c_double, c_double, c_double, c_void_p]),
     'nf_scale_mask': (c_int, [c_int, c_void_p, c_void_p, c_double, c_void_p, c_ll, c_void_p]),
     'nf_scale_mask_dev': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_ll, c_void_p]),
-    'nf_noise_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
+    'nf_noise_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     'nf_noise_map': (c_int, [c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                              c_int, c_int, ctypes.POINTER(c_double), c_int, c_void_p, c_size_t, c_void_p]),
     'nf_noise_smart_workspace_bytes': (c_size_t, []),

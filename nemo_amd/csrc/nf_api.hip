@@ -365,13 +365,13 @@ int nf_scale_mask_dev(int vtype, const float* in, void* out, const double* norm_
     return nf::scale_mask(vtype, in, out, 1.0, norm_d, psMask, n, S(stream));
 }
 
-size_t nf_noise_workspace_bytes(int ny, int nx, int numBins) {
+size_t nf_noise_workspace_bytes(int H, int W, int ny, int nx, int numBins) {
     nf::NoiseGrid g;
     memset(&g, 0, sizeof(g));
     g.ny = ny;
     g.nx = nx;
     g.numBins = numBins;
-    return nf::noise_workspace_bytes(g);
+    return nf::noise_workspace_bytes(g, H, W);
 }
 
 int nf_noise_map(int vtype, const void* filtered, const void* weights, int wtype, float* rms, int H, int W, int ny, int nx,

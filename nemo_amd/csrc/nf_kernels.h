@@ -49,7 +49,7 @@ struct NoiseGrid {
 };
 int noise_map(int vtype, const void* filtered, const void* weights, int wtype, float* rms, int H, int W, const NoiseGrid& g,
               void* cellStats, size_t cellStatsBytes, hipStream_t s);
-size_t noise_workspace_bytes(const NoiseGrid& g);
+size_t noise_workspace_bytes(const NoiseGrid& g, int H, int W);
 size_t noise_smart_workspace_bytes();
 int noise_map_smart(int vtype, const void* filtered, const void* weights, int wtype, float* rms, long long n, int numBins,
                     void* work, size_t workBytes, hipStream_t s);

@@ -16,6 +16,11 @@
 
 namespace nf {
 
+static bool env_flag_default_on(const char* name) {
+    const char* e = getenv(name);
+    return !(e && e[0] == '0');
+}
+
 #define NF_NOISE_THREADS 256
 #define NF_MAXBINS 16
 
@@ -592,6 +597,609 @@ k_noise_cells_reg(const VT* __restrict__ v, const WT* __restrict__ wts, int H, i
     if (tid == 0) rec[0] = 1.0;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// One-bin grid mode without re-reading the map ("block" path).
+//
+// The widened windows of neighbouring cells overlap (overlap = half a cell: every pixel lies in four windows), and the
+// clipping loop visits every pixel of a window up to 11 times.  Here the map is read once:
+//  k_noise_breaks   the window boundaries of all cells cut each axis into intervals (cut again where longer than
+//                   NF_BLK); their products are the elementary blocks, and every window is a whole number of blocks.
+//  k_noise_blocks   one workgroup per block, block held in registers: count of valid pixels, weight range, and with
+//                   T = 2 * sqrt(mean v^2) of the block the CORE pixels |v| < T as three sums (n, sum (v - mu),
+//                   sum (v - mu)^2, mu = block mean) and the TAIL pixels |v| >= T as a list of values (at most a quarter
+//                   of the block by Chebyshev's inequality, which sizes the list; in Gaussian noise ~5 %).
+//  k_noise_windows  one workgroup per cell: the clipping iterations of nemo/filters.py:417-433 over its blocks.  An
+//                   iteration with threshold thr >= T of a block takes all of the block's core pixels (|v| < T <= thr)
+//                   from the three sums, shifted to the current centre, and tests only the tail list; a block with
+//                   thr < T (a bright object inflated T, or much noisier than its window) is scanned pixel by pixel
+//                   from the map for that iteration.  Same sums as the direct evaluation, regrouped (float64).
+#define NF_BLK 64
+#define NF_BLK_THREADS 256
+#define NF_BLK_VPT (NF_BLK * NF_BLK / NF_BLK_THREADS)
+#define NF_BREC 10   // per block: n valid, wmin, wmax, T, n core, mu, S1, S2, tail count, tail offset
+
+struct BlockWs {
+    int* hdr;                      // [0] breakpoints along y, [1] along x
+    int *breakY, *breakX;          // ascending pixel coordinates
+    int *wY0, *wY1, *wX0, *wX1;    // per cell row / column: first block and one past the last block of its window
+    double* rec;                   // [maxBy][maxBx][NF_BREC]
+    double* tails;
+    int maxBy, maxBx;
+};
+
+static inline int blocks_max_breaks(int ncell, int len) { return 2 * ncell + len / NF_BLK + 5; }
+
+__device__ void axis_breaks(const int* __restrict__ E, int n, int ov, int L, int* __restrict__ out, int maxOut, int* nOut) {
+    // windows [a_i, b_i), a_i = max(E[i] - ov, 0), b_i = min(E[i+1] + ov, L): both sequences ascend; merge, drop repeats
+    int ia = 0, ib = 0, cnt = 0, last = -1;
+    if (max(E[0] - ov, 0) > 0) {
+        out[cnt++] = 0;
+        last = 0;
+    }
+    bool tail = false;
+    while (ia < n || ib < n || !tail) {
+        const int va = ia < n ? max(E[ia] - ov, 0) : 0x7fffffff;
+        const int vb = ib < n ? min(E[ib + 1] + ov, L) : 0x7fffffff;
+        int v = min(va, vb);
+        if (ia >= n && ib >= n) {
+            v = L;          // pixels after the last window: blocks that belong to no cell
+            tail = true;
+        } else if (va <= vb) ++ia; else ++ib;
+        if (v == last) continue;
+        if (last >= 0 && v - last > NF_BLK) {
+            const int len = v - last, pieces = (len + NF_BLK - 1) / NF_BLK, step = (len + pieces - 1) / pieces;
+            for (int j = 1; j < pieces; ++j)
+                if (cnt < maxOut) out[cnt++] = last + j * step;
+        }
+        if (cnt < maxOut) out[cnt++] = v;
+        last = v;
+    }
+    *nOut = cnt;
+}
+
+__device__ __forceinline__ int find_break(const int* __restrict__ b, int n, int v) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (b[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+#define NF_BRK_MAXCELLS 1023
+#define NF_BRK_MAXOUT 4096
+
+// LDS form of axis_breaks for one axis: parallel merge of the two ascending sequences (ties: starts first), then one thread
+// walks the merged list (repeats dropped, long intervals cut) - no dependent global loads anywhere.
+__device__ void axis_merge_lds(const int* __restrict__ Eg, int n, int ov, int L, int* __restrict__ E, int* __restrict__ merged) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int i = tid; i <= n; i += nt) E[i] = Eg[i];
+    __syncthreads();
+    for (int i = tid; i < 2 * n; i += nt) {
+        int v, pos;
+        if (i < n) {            // a_i: after the b_j that are strictly smaller
+            v = max(E[i] - ov, 0);
+            int lo = 0, hi = n;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (min(E[mid + 1] + ov, L) < v) lo = mid + 1; else hi = mid;
+            }
+            pos = i + lo;
+        } else {                // b_j: after the a_i that are smaller or equal
+            const int j = i - n;
+            v = min(E[j + 1] + ov, L);
+            int lo = 0, hi = n;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (max(E[mid] - ov, 0) <= v) lo = mid + 1; else hi = mid;
+            }
+            pos = j + lo;
+        }
+        merged[pos] = v;
+    }
+}
+
+__device__ void axis_walk_lds(const int* __restrict__ merged, int n, int L, int* __restrict__ out, int maxOut, int* __restrict__ nOutLds) {
+    {
+        int cnt = 0, last = -1;
+        if (merged[0] > 0) {      // pixels before the first window belong to no cell: give them blocks all the same
+            out[cnt++] = 0;
+            last = 0;
+        }
+        for (int i = 0; i <= 2 * n; ++i) {
+            const int v = i < 2 * n ? merged[i] : L;    // likewise after the last window
+            if (v == last) continue;
+            if (last >= 0 && v - last > NF_BLK) {
+                const int len = v - last, pieces = (len + NF_BLK - 1) / NF_BLK, step = (len + pieces - 1) / pieces;
+                for (int j = 1; j < pieces; ++j)
+                    if (cnt < maxOut) out[cnt++] = last + j * step;
+            }
+            if (cnt < maxOut) out[cnt++] = v;
+            last = v;
+        }
+        *nOutLds = cnt;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_noise_breaks(NoiseGrid g, int H, int W, BlockWs ws) {
+    __shared__ int E[2][NF_BRK_MAXCELLS + 1];
+    __shared__ int merged[2][2 * NF_BRK_MAXCELLS];
+    __shared__ int outL[2][NF_BRK_MAXOUT];
+    __shared__ int nOut[2];
+    const bool lds = g.ny <= NF_BRK_MAXCELLS && g.nx <= NF_BRK_MAXCELLS && ws.maxBy <= NF_BRK_MAXOUT && ws.maxBx <= NF_BRK_MAXOUT;
+    const int* bY = ws.breakY;
+    const int* bX = ws.breakX;
+    if (lds) {
+        axis_merge_lds(g.yEdges, g.ny, g.overlap, H, E[0], merged[0]);
+        axis_merge_lds(g.xEdges, g.nx, g.overlap, W, E[1], merged[1]);
+        __syncthreads();
+        if (threadIdx.x == 0) axis_walk_lds(merged[0], g.ny, H, outL[0], ws.maxBy, &nOut[0]);
+        if (threadIdx.x == 64) axis_walk_lds(merged[1], g.nx, W, outL[1], ws.maxBx, &nOut[1]);
+        __syncthreads();
+        for (int i = threadIdx.x; i < nOut[0]; i += blockDim.x) ws.breakY[i] = outL[0][i];
+        for (int i = threadIdx.x; i < nOut[1]; i += blockDim.x) ws.breakX[i] = outL[1][i];
+        if (threadIdx.x == 0) {
+            ws.hdr[0] = nOut[0];
+            ws.hdr[1] = nOut[1];
+        }
+        bY = outL[0];
+        bX = outL[1];
+    } else {
+        if (threadIdx.x == 0) axis_breaks(g.yEdges, g.ny, g.overlap, H, ws.breakY, ws.maxBy, &nOut[0]);
+        if (threadIdx.x == 64) axis_breaks(g.xEdges, g.nx, g.overlap, W, ws.breakX, ws.maxBx, &nOut[1]);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            ws.hdr[0] = nOut[0];
+            ws.hdr[1] = nOut[1];
+        }
+    }
+    const int nBy = nOut[0], nBx = nOut[1];
+    for (int i = threadIdx.x; i < g.ny; i += blockDim.x) {
+        ws.wY0[i] = find_break(bY, nBy, max(g.yEdges[i] - g.overlap, 0));
+        ws.wY1[i] = find_break(bY, nBy, min(g.yEdges[i + 1] + g.overlap, H));
+    }
+    for (int k = threadIdx.x; k < g.nx; k += blockDim.x) {
+        ws.wX0[k] = find_break(bX, nBx, max(g.xEdges[k] - g.overlap, 0));
+        ws.wX1[k] = find_break(bX, nBx, min(g.xEdges[k + 1] + g.overlap, W));
+    }
+}
+
+template <typename VT, typename WT>
+__global__ void __launch_bounds__(NF_BLK_THREADS)
+k_noise_blocks(const VT* __restrict__ v, const WT* __restrict__ wts, int W, BlockWs ws) {
+    __shared__ double red[48];
+    __shared__ int waveTails[NF_BLK_THREADS / 64];
+    const int nBy = ws.hdr[0], nBx = ws.hdr[1];
+    const int by = blockIdx.y, bx = blockIdx.x;
+    if (by >= nBy - 1 || bx >= nBx - 1) return;
+    const int y0 = ws.breakY[by], y1 = ws.breakY[by + 1], x0 = ws.breakX[bx], x1 = ws.breakX[bx + 1];
+    const int bw = x1 - x0, bh = y1 - y0, npx = bw * bh;
+    const int tid = threadIdx.x;
+    double* __restrict__ rec = ws.rec + ((long long)by * ws.maxBx + bx) * NF_BREC;
+
+    // element j of thread tid is block pixel j * 256 + tid (consecutive lanes -> consecutive x); out-of-block slots read
+    // the block's first pixel and are discarded, so that all loads issue back to back
+    double val[NF_BLK_VPT];
+    double sv = 0.0, sv2 = 0.0, n = 0.0, wmin = INFINITY, wmax = -INFINITY;
+    {
+        int rr = tid / bw, xx = tid - rr * bw;
+        const int dr = NF_BLK_THREADS / bw, dx = NF_BLK_THREADS - dr * bw;
+        const long long qSafe = (long long)y0 * W + x0;
+        VT tv[NF_BLK_VPT];
+        WT tw[NF_BLK_VPT];
+#pragma unroll
+        for (int j = 0; j < NF_BLK_VPT; ++j) {
+            const bool in = j * NF_BLK_THREADS + tid < npx;
+            const long long q = in ? (long long)(y0 + rr) * W + x0 + xx : qSafe;
+            tv[j] = v[q];
+            tw[j] = wts[q];
+            rr += dr;
+            xx += dx;
+            if (xx >= bw) {
+                xx -= bw;
+                rr += 1;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NF_BLK_VPT; ++j) {
+            const bool in = j * NF_BLK_THREADS + tid < npx;
+            const double t = in ? (double)tv[j] : 0.0;
+            if (t != 0.0) {
+                n += 1.0;
+                sv += t;
+                sv2 += t * t;
+                const double wv = (double)tw[j];
+                wmin = fmin(wmin, wv);
+                wmax = fmax(wmax, wv);
+            }
+            val[j] = t;
+        }
+    }
+    block_sum3(sv, sv2, n, red);
+    if (n == 0.0) {
+        if (tid == 0) {
+            rec[0] = 0.0;
+            rec[8] = 0.0;
+        }
+        return;
+    }
+    wmin = block_min(wmin, red);
+    wmax = block_max(wmax, red);
+    const double mu = sv / n;
+    double T = 2.0000001 * sqrt(sv2 / n);   // a hair above 2 rms: strictly fewer than n / 4 pixels can reach it
+    double s1 = 0.0, s2 = 0.0, nc = 0.0;
+    int tc = 0;
+#pragma unroll
+    for (int j = 0; j < NF_BLK_VPT; ++j) {
+        const double t = val[j];
+        if (t != 0.0) {
+            if (fabs(t) < T) {
+                const double d = t - mu;
+                s1 += d;
+                s2 += d * d;
+                nc += 1.0;
+            } else {
+                ++tc;
+            }
+        }
+    }
+    block_sum3(s1, s2, nc, red);
+    // exclusive prefix of the tail counts in thread order: the list order (hence every later sum) is fixed
+    const int lane = tid & 63, wave = tid >> 6;
+    int incl = tc;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int up = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += up;
+    }
+    if (lane == 63) waveTails[wave] = incl;
+    __syncthreads();
+    int before = incl - tc, total = 0;
+    for (int w = 0; w < NF_BLK_THREADS / 64; ++w) {
+        if (w < wave) before += waveTails[w];
+        total += waveTails[w];
+    }
+    const long long Wtot = ws.breakX[nBx - 1] - ws.breakX[0];
+    const long long rank = (long long)(y0 - ws.breakY[0]) * Wtot + (long long)(x0 - ws.breakX[0]) * bh;
+    const long long tailOff = rank / 4 + (long long)by * (nBx - 1) + bx;
+    const int cap = npx / 4 + 1;
+    if (total > cap) {
+        // cannot happen (Chebyshev); if it did, the block would be scanned directly in every iteration (thr >= NaN is false)
+        T = __longlong_as_double(0x7ff8000000000000LL);
+        total = 0;
+    } else {
+        double* __restrict__ tp = ws.tails + tailOff + before;
+        int k = 0;
+#pragma unroll
+        for (int j = 0; j < NF_BLK_VPT; ++j) {
+            const double t = val[j];
+            if (t != 0.0 && !(fabs(t) < T)) tp[k++] = t;
+        }
+    }
+    if (tid == 0) {
+        rec[0] = n;
+        rec[1] = wmin;
+        rec[2] = wmax;
+        rec[3] = T;
+        rec[4] = nc;
+        rec[5] = mu;
+        rec[6] = s1;
+        rec[7] = s2;
+        rec[8] = (double)total;
+        rec[9] = (double)tailOff;
+    }
+}
+
+__device__ __forceinline__ void cell_range(const int* __restrict__ e, int ncell, int overlap, int t, int* lo, int* hi);
+
+// ---- k_noise_windows: ONE WAVEFRONT per cell (no barriers; reductions on the vector ALU) ----
+#define NF_WIN_MAXBLK 64      // blocks of a window whose records are staged in LDS (more: everything from global memory)
+#define NF_WIN_MAXTAIL 2048   // tail values of a window staged in LDS
+
+__device__ __forceinline__ double wave_total(double v) {
+    v = wave_sum_lane63(v);
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+
+// one block scanned pixel by pixel (its T exceeds the threshold of this iteration)
+template <typename VT>
+__device__ __forceinline__ void scan_block(const VT* __restrict__ v, int W, const BlockWs& ws, int by, int bx, double c0, double thr,
+                                           double& s, double& ss, double& nn) {
+    const int lane = threadIdx.x & 63;
+    const int y0 = ws.breakY[by], y1 = ws.breakY[by + 1], x0 = ws.breakX[bx], x1 = ws.breakX[bx + 1];
+    for (int y = y0; y < y1; ++y) {
+        const VT* __restrict__ row = v + (long long)y * W;
+        for (int x = x0 + lane; x < x1; x += 64) {
+            const double t = (double)row[x];
+            if (t != 0.0 && fabs(t) < thr) {
+                const double d = t - c0;
+                s += d;
+                ss += d * d;
+                nn += 1.0;
+            }
+        }
+    }
+}
+
+struct WinLds {
+    double T[NF_WIN_MAXBLK], nc[NF_WIN_MAXBLK], mu[NF_WIN_MAXBLK], S1[NF_WIN_MAXBLK], S2[NF_WIN_MAXBLK];
+    int tailBase[NF_WIN_MAXBLK + 1];
+    double tail[NF_WIN_MAXTAIL];
+    unsigned char tailBlk[NF_WIN_MAXTAIL];
+};
+
+// sum d, sum d^2, count over the valid pixels of the window with |v| < thr, d = v - c0 (every lane gets the totals)
+template <typename VT, bool LDS>
+__device__ __forceinline__ void window_sums(const VT* __restrict__ v, int W, const BlockWs& ws, const WinLds& L, int BY0, int BX0,
+                                            int nbx, int nblk, int ntail, double c0, double thr, double& s, double& ss, double& nn) {
+    const int lane = threadIdx.x & 63;
+    s = 0.0;
+    ss = 0.0;
+    nn = 0.0;
+    if (LDS) {
+        // lane = block: core sums, or (rarely) a direct scan, which the whole wavefront does block after block
+        bool scan = false;
+        if (lane < nblk && L.nc[lane] >= 0.0) {
+            if (thr >= L.T[lane]) {
+                const double nc = L.nc[lane], dmu = L.mu[lane] - c0, S1 = L.S1[lane], S2 = L.S2[lane];
+                s = S1 + nc * dmu;
+                ss = S2 + 2.0 * dmu * S1 + nc * dmu * dmu;
+                nn = nc;
+            } else {
+                scan = true;
+            }
+        }
+        for (int e = lane; e < ntail; e += 64) {
+            const double t = L.tail[e];
+            if (thr >= L.T[L.tailBlk[e]] && fabs(t) < thr) {
+                const double d = t - c0;
+                s += d;
+                ss += d * d;
+                nn += 1.0;
+            }
+        }
+        unsigned long long todo = __ballot(scan);
+        while (todo) {
+            const int bi = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const int byo = bi / nbx;
+            scan_block<VT>(v, W, ws, BY0 + byo, BX0 + (bi - byo * nbx), c0, thr, s, ss, nn);
+        }
+    } else {
+        // window too large for the LDS tables (a single cell over a whole map, say): lane = block, records and tail
+        // lists straight from global memory
+        for (int b0 = 0; b0 < nblk; b0 += 64) {
+            const int bi = b0 + lane;
+            bool scan = false;
+            if (bi < nblk) {
+                const int byo = bi / nbx;
+                const double* __restrict__ rb = ws.rec + ((long long)(BY0 + byo) * ws.maxBx + BX0 + (bi - byo * nbx)) * NF_BREC;
+                if (rb[0] > 0.0) {
+                    if (thr >= rb[3]) {
+                        const double nc = rb[4], dmu = rb[5] - c0, S1 = rb[6], S2 = rb[7];
+                        s += S1 + nc * dmu;
+                        ss += S2 + 2.0 * dmu * S1 + nc * dmu * dmu;
+                        nn += nc;
+                        const int tc = (int)rb[8];
+                        const double* __restrict__ tp = ws.tails + (long long)rb[9];
+                        for (int e = 0; e < tc; ++e) {
+                            const double t = tp[e];
+                            if (fabs(t) < thr) {
+                                const double d = t - c0;
+                                s += d;
+                                ss += d * d;
+                                nn += 1.0;
+                            }
+                        }
+                    } else {
+                        scan = true;
+                    }
+                }
+            }
+            unsigned long long todo = __ballot(scan);
+            while (todo) {
+                const int bj = b0 + __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                const int byo = bj / nbx;
+                scan_block<VT>(v, W, ws, BY0 + byo, BX0 + (bj - byo * nbx), c0, thr, s, ss, nn);
+            }
+        }
+    }
+    s = wave_total(s);
+    ss = wave_total(ss);
+    nn = wave_total(nn);
+}
+
+// 3-sigma clipping exactly as k_noise_cells_reg runs it (nemo/filters.py:417-433)
+template <typename VT, bool LDS>
+__device__ __forceinline__ double window_clip(const VT* __restrict__ v, int W, const BlockWs& ws, const WinLds& L, int BY0, int BX0,
+                                              int nbx, int nblk, int ntail) {
+    double thr = INFINITY, mean = 0.0, rms = 0.0;
+    bool have = false;
+    for (int it = 0; it <= 10; ++it) {
+        double m, r, s, ss, n;
+        if (it == 0) {
+            window_sums<VT, LDS>(v, W, ws, L, BY0, BX0, nbx, nblk, ntail, 0.0, INFINITY, s, ss, n);
+            if (n == 0.0) break;
+            m = s / n;
+            window_sums<VT, LDS>(v, W, ws, L, BY0, BX0, nbx, nblk, ntail, m, INFINITY, s, ss, n);
+            r = sqrt(ss / n);
+        } else {
+            const double c0 = mean;
+            window_sums<VT, LDS>(v, W, ws, L, BY0, BX0, nbx, nblk, ntail, c0, thr, s, ss, n);
+            if (n == 0.0) continue;
+            const double dm = s / n;
+            m = c0 + dm;
+            const double var = ss / n - dm * dm;
+            r = sqrt(var > 0.0 ? var : 0.0);
+        }
+        const bool same = have && (m == mean) && (r == rms);
+        mean = m;
+        rms = r;
+        have = true;
+        thr = fabs(mean + 3.0 * rms);
+        if (same) break;
+    }
+    return have ? rms : 0.0;
+}
+
+template <typename VT>
+__global__ void __launch_bounds__(64) k_noise_windows(const VT* __restrict__ v, int W, NoiseGrid g, BlockWs ws, double* __restrict__ stats) {
+    __shared__ WinLds L;
+    const int cell = blockIdx.x, i = cell / g.nx, k = cell - i * g.nx;
+    const int BY0 = ws.wY0[i], BX0 = ws.wX0[k], nbx = ws.wX1[k] - BX0, nblk = (ws.wY1[i] - BY0) * nbx;
+    const int lane = threadIdx.x;
+    double* __restrict__ rec = stats + (long long)cell * cell_stride(1);
+    double cnt = 0.0, wmin = INFINITY, wmax = -INFINITY;
+    int tcSum = 0;
+    for (int bi = lane; bi < nblk; bi += 64) {
+        const int byo = bi / nbx;
+        const double* __restrict__ rb = ws.rec + ((long long)(BY0 + byo) * ws.maxBx + BX0 + (bi - byo * nbx)) * NF_BREC;
+        const double nv = rb[0];
+        if (nv > 0.0) {
+            cnt += nv;
+            wmin = fmin(wmin, rb[1]);
+            wmax = fmax(wmax, rb[2]);
+            tcSum += (int)rb[8];
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        cnt += __shfl_xor(cnt, off, 64);
+        wmin = fmin(wmin, __shfl_xor(wmin, off, 64));
+        wmax = fmax(wmax, __shfl_xor(wmax, off, 64));
+        tcSum += __shfl_xor(tcSum, off, 64);
+    }
+    if (cnt == 0.0) {
+        if (lane == 0) rec[0] = 0.0;
+        return;
+    }
+    double rms;
+    if (nblk <= NF_WIN_MAXBLK && tcSum <= NF_WIN_MAXTAIL) {
+        // stage the block records (lane = block) and, through a prefix of the tail counts, all tail values
+        int tc = 0;
+        long long toff = 0;
+        if (lane < nblk) {
+            const int byo = lane / nbx;
+            const double* __restrict__ rb = ws.rec + ((long long)(BY0 + byo) * ws.maxBx + BX0 + (lane - byo * nbx)) * NF_BREC;
+            const bool live = rb[0] > 0.0;
+            L.T[lane] = rb[3];
+            L.nc[lane] = live ? rb[4] : -1.0;     // -1: block without valid pixels
+            L.mu[lane] = rb[5];
+            L.S1[lane] = rb[6];
+            L.S2[lane] = rb[7];
+            tc = live ? (int)rb[8] : 0;
+            toff = (long long)rb[9];
+        }
+        int incl = tc;
+        for (int off = 1; off < 64; off <<= 1) {
+            const int up = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += up;
+        }
+        if (lane < nblk) L.tailBase[lane] = incl - tc;
+        if (lane == 63) L.tailBase[NF_WIN_MAXBLK] = incl;
+        __syncthreads();
+        // lane-parallel copy: the block of flat tail index e by binary search in the prefix
+        for (int e = lane; e < tcSum; e += 64) {
+            int lo = 0, hi = nblk - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (L.tailBase[mid] <= e) lo = mid; else hi = mid - 1;
+            }
+            const int byo = lo / nbx;
+            const double* __restrict__ rb = ws.rec + ((long long)(BY0 + byo) * ws.maxBx + BX0 + (lo - byo * nbx)) * NF_BREC;
+            L.tail[e] = ws.tails[(long long)rb[9] + (e - L.tailBase[lo])];
+            L.tailBlk[e] = (unsigned char)lo;
+        }
+        (void)toff;
+        __syncthreads();
+        rms = window_clip<VT, true>(v, W, ws, L, BY0, BX0, nbx, nblk, tcSum);
+    } else {
+        rms = window_clip<VT, false>(v, W, ws, L, BY0, BX0, nbx, nblk, 0);
+    }
+    if (lane == 0) {
+        rec[0] = 1.0;
+        rec[1] = wmin;
+        rec[2] = wmax + 1e-6;
+        rec[3] = rms;
+    }
+}
+
+// Paint for the block path: all pixels of a block lie in the same windows, so the candidate cells (in the reference's
+// overwrite order, last writer first; only active cells with rms > 0) are found once per block.
+#define NF_PAINT_MAXCAND 32
+template <typename WT>
+__global__ void __launch_bounds__(NF_BLK_THREADS)
+k_noise_paint_blocks(const WT* __restrict__ wts, float* __restrict__ rmsMap, int W, NoiseGrid g, BlockWs ws,
+                     const double* __restrict__ stats) {
+    __shared__ double cLo[NF_PAINT_MAXCAND], cHi[NF_PAINT_MAXCAND];
+    __shared__ float cR[NF_PAINT_MAXCAND];
+    __shared__ int nCand, range[4];
+    const int nBy = ws.hdr[0], nBx = ws.hdr[1];
+    const int by = blockIdx.y, bx = blockIdx.x;
+    if (by >= nBy - 1 || bx >= nBx - 1) return;
+    const int y0 = ws.breakY[by], y1 = ws.breakY[by + 1], x0 = ws.breakX[bx], x1 = ws.breakX[bx + 1];
+    const int bw = x1 - x0, bh = y1 - y0, npx = bw * bh;
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        int iLo, iHi, kLo, kHi;
+        cell_range(g.yEdges, g.ny, g.overlap, y0, &iLo, &iHi);
+        cell_range(g.xEdges, g.nx, g.overlap, x0, &kLo, &kHi);
+        int n = 0;
+        bool overflow = false;
+        for (int i = iHi; i >= iLo; --i)
+            for (int k = kHi; k >= kLo; --k) {
+                const double* rec = stats + (long long)(i * g.nx + k) * cell_stride(1);
+                if (rec[0] == 0.0 || !(rec[3] > 0.0)) continue;
+                if (n < NF_PAINT_MAXCAND) {
+                    cLo[n] = rec[1];
+                    cHi[n] = rec[2];
+                    cR[n] = (float)rec[3];
+                    ++n;
+                } else {
+                    overflow = true;
+                }
+            }
+        nCand = overflow ? -1 : n;
+        range[0] = iLo;
+        range[1] = iHi;
+        range[2] = kLo;
+        range[3] = kHi;
+    }
+    __syncthreads();
+    const int nc = nCand;
+    int rr = tid / bw, xx = tid - rr * bw;
+    const int dr = NF_BLK_THREADS / bw, dx = NF_BLK_THREADS - dr * bw;
+    for (int p = tid; p < npx; p += NF_BLK_THREADS) {
+        const long long q = (long long)(y0 + rr) * W + x0 + xx;
+        const double wv = (double)wts[q];
+        float outv = 0.0f;
+        if (nc >= 0) {
+            for (int c = 0; c < nc; ++c)
+                if (wv >= cLo[c] && wv < cHi[c]) {
+                    outv = cR[c];
+                    break;
+                }
+        } else {
+            bool done = false;
+            for (int i = range[1]; i >= range[0] && !done; --i)
+                for (int k = range[3]; k >= range[2] && !done; --k) {
+                    const double* rec = stats + (long long)(i * g.nx + k) * cell_stride(1);
+                    if (rec[0] == 0.0) continue;
+                    if (wv >= rec[1] && wv < rec[2] && rec[3] > 0.0) {
+                        outv = (float)rec[3];
+                        done = true;
+                    }
+                }
+        }
+        rmsMap[q] = outv;
+        rr += dr;
+        xx += dx;
+        if (xx >= bw) {
+            xx -= bw;
+            rr += 1;
+        }
+    }
+}
+
 // index range [lo, hi] of the cells whose widened window contains coordinate t along one axis (edges ascending)
 __device__ __forceinline__ void cell_range(const int* __restrict__ e, int ncell, int overlap, int t, int* lo, int* hi) {
     // hi: last cell with e[i] - overlap <= t
@@ -699,8 +1307,17 @@ int median_stack(int rtype, const void* in, void* out, int N, long long n, hipSt
     return NF_OK;
 }
 
-size_t noise_workspace_bytes(const NoiseGrid& g) {
-    return (size_t)g.ny * g.nx * cell_stride(g.numBins) * sizeof(double);
+static size_t align8(size_t b) { return (b + 7) & ~(size_t)7; }
+
+// cell records, then (one-bin clipped-RMS mode) the block tables: see BlockWs
+size_t noise_workspace_bytes(const NoiseGrid& g, int H, int W) {
+    size_t cells = (size_t)g.ny * g.nx * cell_stride(g.numBins) * sizeof(double);
+    if (g.numBins != 1) return cells;
+    const size_t maxBy = blocks_max_breaks(g.ny, H), maxBx = blocks_max_breaks(g.nx, W);
+    size_t ints = align8((4 + maxBy + maxBx + 2 * (size_t)g.ny + 2 * (size_t)g.nx) * sizeof(int));
+    size_t recs = maxBy * maxBx * NF_BREC * sizeof(double);
+    size_t tails = ((size_t)H * W / 4 + maxBy * maxBx + 8) * sizeof(double);
+    return cells + ints + recs + tails;
 }
 
 int noise_map(int vtype, const void* filtered, const void* weights, int wtype, float* rms, int H, int W, const NoiseGrid& g,
@@ -713,11 +1330,52 @@ int noise_map(int vtype, const void* filtered, const void* weights, int wtype, f
         nf_set_error("noise_map: estimator must be 0 (3-sigma clipped standard deviation) or 1 (68.3 percentile of |v|)");
         return NF_ERR_ARG;
     }
-    if (cellStatsBytes < noise_workspace_bytes(g)) {
+    if (cellStatsBytes < noise_workspace_bytes(g, H, W)) {
         nf_set_error("noise_map: workspace too small");
         return NF_ERR_SIZE;
     }
     double* stats = (double*)cellStats;
+    static const bool blockPath = env_flag_default_on("NF_NOISE_BLOCKS");
+    if (g.estimator == 0 && g.numBins == 1 && blockPath) {
+        BlockWs ws;
+        ws.maxBy = blocks_max_breaks(g.ny, H);
+        ws.maxBx = blocks_max_breaks(g.nx, W);
+        char* p = (char*)cellStats + (size_t)g.ny * g.nx * cell_stride(1) * sizeof(double);
+        ws.hdr = (int*)p;
+        ws.breakY = ws.hdr + 4;
+        ws.breakX = ws.breakY + ws.maxBy;
+        ws.wY0 = ws.breakX + ws.maxBx;
+        ws.wY1 = ws.wY0 + g.ny;
+        ws.wX0 = ws.wY1 + g.ny;
+        ws.wX1 = ws.wX0 + g.nx;
+        p += align8((4 + (size_t)ws.maxBy + ws.maxBx + 2 * (size_t)g.ny + 2 * (size_t)g.nx) * sizeof(int));
+        ws.rec = (double*)p;
+        ws.tails = ws.rec + (size_t)ws.maxBy * ws.maxBx * NF_BREC;
+        if (ws.maxBy > 65535) {
+            nf_set_error("noise_map: too many block rows");
+            return NF_ERR_SIZE;
+        }
+        hipLaunchKernelGGL(k_noise_breaks, dim3(1), dim3(256), 0, s, g, H, W, ws);
+        NF_CHECK_LAUNCH("k_noise_breaks");
+        dim3 gb(ws.maxBx - 1, ws.maxBy - 1), gw(g.ny * g.nx);
+#define NF_NB(VT, WT)                                                                                                      \
+    do {                                                                                                                   \
+        hipLaunchKernelGGL((k_noise_blocks<VT, WT>), gb, dim3(NF_BLK_THREADS), 0, s, (const VT*)filtered, (const WT*)weights, W, ws); \
+        hipLaunchKernelGGL((k_noise_windows<VT>), gw, dim3(64), 0, s, (const VT*)filtered, W, g, ws, stats);               \
+    } while (0)
+        if (vtype == NF_F64 && wtype == NF_F64) NF_NB(double, double);
+        else if (vtype == NF_F64 && wtype == NF_F32) NF_NB(double, float);
+        else if (vtype == NF_F32 && wtype == NF_F64) NF_NB(float, double);
+        else NF_NB(float, float);
+#undef NF_NB
+        NF_CHECK_LAUNCH("k_noise_blocks / k_noise_windows");
+        if (wtype == NF_F64)
+            hipLaunchKernelGGL(k_noise_paint_blocks<double>, gb, dim3(NF_BLK_THREADS), 0, s, (const double*)weights, rms, W, g, ws, stats);
+        else
+            hipLaunchKernelGGL(k_noise_paint_blocks<float>, gb, dim3(NF_BLK_THREADS), 0, s, (const float*)weights, rms, W, g, ws, stats);
+        NF_CHECK_LAUNCH("k_noise_paint_blocks");
+        return NF_OK;
+    }
     dim3 gc(g.ny * g.nx), bc(NF_NOISE_THREADS);
     // widest possible window: (largest cell + 2 * overlap)^2; cells differ by at most one pixel (np.linspace(dtype=int))
     const long long maxH = (long long)(H / g.ny + 1) + 2LL * g.overlap, maxW = (long long)(W / g.nx + 1) + 2LL * g.overlap;

@@ -379,7 +379,7 @@ class TileEngine(object):
         if ncy < 1 or ncx < 1:
             rms.zero_()
             return rms
-        wbytes = self.lib.nf_noise_workspace_bytes(ncy, ncx, nb)
+        wbytes = self.lib.nf_noise_workspace_bytes(self.H, self.W, ncy, ncx, nb)
         work = t.empty(wbytes // 8 + 1, dtype=t.float64, device=self.dev)
         key = ('noiseEdges', yEdges.tobytes(), xEdges.tobytes())
         if key not in self._geom2:

@@ -605,18 +605,18 @@ k_noise_cells_reg(const VT* __restrict__ v, const WT* __restrict__ wts, int H, i
 //  k_noise_breaks   the window boundaries of all cells cut each axis into intervals (cut again where longer than
 //                   NF_BLK); their products are the elementary blocks, and every window is a whole number of blocks.
 //  k_noise_blocks   one workgroup per block, block held in registers: count of valid pixels, weight range, and with
-//                   T = 2 * sqrt(mean v^2) of the block the CORE pixels |v| < T as three sums (n, sum (v - mu),
-//                   sum (v - mu)^2, mu = block mean) and the TAIL pixels |v| >= T as a list of values (at most a quarter
-//                   of the block by Chebyshev's inequality, which sizes the list; in Gaussian noise ~5 %).
+//                   T = 2.5 * sqrt(mean v^2) of the block the CORE pixels |v| < T as three sums (n, sum (v - mu),
+//                   sum (v - mu)^2, mu = block mean) and the TAIL pixels |v| >= T as a list of values (in Gaussian noise
+//                   1 - 2 % of the pixels; list capacities from Chebyshev's inequality, offsets by k_noise_breaks).
 //  k_noise_windows  one workgroup per cell: the clipping iterations of nemo/filters.py:417-433 over its blocks.  An
 //                   iteration with threshold thr >= T of a block takes all of the block's core pixels (|v| < T <= thr)
 //                   from the three sums, shifted to the current centre, and tests only the tail list; a block with
 //                   thr < T (a bright object inflated T, or much noisier than its window) is scanned pixel by pixel
 //                   from the map for that iteration.  Same sums as the direct evaluation, regrouped (float64).
-#define NF_BLK 64
+#define NF_BLK 48
 #define NF_BLK_THREADS 256
 #define NF_BLK_VPT (NF_BLK * NF_BLK / NF_BLK_THREADS)
-#define NF_BREC 10   // per block: n valid, wmin, wmax, T, n core, mu, S1, S2, tail count, tail offset
+#define NF_BREC 12   // per block: n valid, wmin, wmax, T, n core, mu, S1, S2, tail count, tail offset, wmin / wmax of all pixels
 
 struct BlockWs {
     int* hdr;                      // [0] breakpoints along y, [1] along x
@@ -624,6 +624,9 @@ struct BlockWs {
     int *wY0, *wY1, *wX0, *wX1;    // per cell row / column: first block and one past the last block of its window
     double* rec;                   // [maxBy][maxBx][NF_BREC]
     double* tails;
+    long long tailCap;             // room in `tails`
+    int* tailCol;                  // [maxBx] and
+    long long* tailRow;            // [maxBy]: tail list offset tables (see tail_cap)
     int maxBy, maxBx;
 };
 
@@ -666,6 +669,8 @@ __device__ __forceinline__ int find_break(const int* __restrict__ b, int n, int 
     return lo;
 }
 
+__device__ __forceinline__ int tail_cap(int h, int w);
+
 #define NF_BRK_MAXCELLS 1023
 #define NF_BRK_MAXOUT 4096
 
@@ -699,42 +704,79 @@ __device__ void axis_merge_lds(const int* __restrict__ Eg, int n, int ov, int L,
     }
 }
 
-__device__ void axis_walk_lds(const int* __restrict__ merged, int n, int L, int* __restrict__ out, int maxOut, int* __restrict__ nOutLds) {
-    {
-        int cnt = 0, last = -1;
-        if (merged[0] > 0) {      // pixels before the first window belong to no cell: give them blocks all the same
-            out[cnt++] = 0;
-            last = 0;
-        }
-        for (int i = 0; i <= 2 * n; ++i) {
-            const int v = i < 2 * n ? merged[i] : L;    // likewise after the last window
-            if (v == last) continue;
-            if (last >= 0 && v - last > NF_BLK) {
-                const int len = v - last, pieces = (len + NF_BLK - 1) / NF_BLK, step = (len + pieces - 1) / pieces;
-                for (int j = 1; j < pieces; ++j)
-                    if (cnt < maxOut) out[cnt++] = last + j * step;
-            }
-            if (cnt < maxOut) out[cnt++] = v;
-            last = v;
-        }
-        *nOutLds = cnt;
+// exclusive prefix over the 256 threads of the workgroup (wsum: 4 LDS ints); *total = sum over all threads
+__device__ __forceinline__ int block_excl_scan256(int x, int* __restrict__ wsum, int* total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = x;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int up = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += up;
     }
+    __syncthreads();
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int before = incl - x, tot = 0;
+    for (int w = 0; w < 4; ++w) {
+        if (w < wave) before += wsum[w];
+        tot += wsum[w];
+    }
+    *total = tot;
+    return before;
+}
+
+// ext[0 .. m) = 0, the merged window boundaries, L (ascending).  Every distinct value is a breakpoint, and an interval
+// longer than NF_BLK is cut into ceil(len / NF_BLK) pieces: element i contributes that many breakpoints (0 if it repeats
+// its predecessor), written at the exclusive prefix of the counts.  Each thread takes a run of consecutive elements.
+__device__ void axis_walk_lds(const int* __restrict__ ext, int m, int* __restrict__ out, int maxOut, int* __restrict__ wsum,
+                              int* __restrict__ nOutLds) {
+    const int per = (m + 255) / 256, i0 = threadIdx.x * per, i1 = min(i0 + per, m);
+    int mine = 0;
+    for (int i = i0; i < i1; ++i) {
+        if (i == 0) mine += 1;
+        else {
+            const int len = ext[i] - ext[i - 1];
+            mine += (len + NF_BLK - 1) / NF_BLK;      // 0 for a repeat
+        }
+    }
+    int total;
+    int pos = block_excl_scan256(mine, wsum, &total);
+    for (int i = i0; i < i1; ++i) {
+        if (i == 0) {
+            if (pos < maxOut) out[pos] = ext[0];
+            ++pos;
+            continue;
+        }
+        const int prev = ext[i - 1], len = ext[i] - prev;
+        if (len <= 0) continue;
+        const int pieces = (len + NF_BLK - 1) / NF_BLK, step = (len + pieces - 1) / pieces;
+        for (int j = 1; j < pieces; ++j, ++pos)
+            if (pos < maxOut) out[pos] = prev + j * step;
+        if (pos < maxOut) out[pos] = ext[i];
+        ++pos;
+    }
+    if (threadIdx.x == 0) *nOutLds = min(total, maxOut);
 }
 
 __global__ void __launch_bounds__(256) k_noise_breaks(NoiseGrid g, int H, int W, BlockWs ws) {
     __shared__ int E[2][NF_BRK_MAXCELLS + 1];
-    __shared__ int merged[2][2 * NF_BRK_MAXCELLS];
+    __shared__ int merged[2][2 * NF_BRK_MAXCELLS + 2];   // 0, the merged boundaries, the axis length
     __shared__ int outL[2][NF_BRK_MAXOUT];
-    __shared__ int nOut[2];
+    __shared__ int nOut[2], wsum[4];
     const bool lds = g.ny <= NF_BRK_MAXCELLS && g.nx <= NF_BRK_MAXCELLS && ws.maxBy <= NF_BRK_MAXOUT && ws.maxBx <= NF_BRK_MAXOUT;
     const int* bY = ws.breakY;
     const int* bX = ws.breakX;
     if (lds) {
-        axis_merge_lds(g.yEdges, g.ny, g.overlap, H, E[0], merged[0]);
-        axis_merge_lds(g.xEdges, g.nx, g.overlap, W, E[1], merged[1]);
+        axis_merge_lds(g.yEdges, g.ny, g.overlap, H, E[0], merged[0] + 1);
+        axis_merge_lds(g.xEdges, g.nx, g.overlap, W, E[1], merged[1] + 1);
+        if (threadIdx.x == 0) {
+            merged[0][0] = 0;
+            merged[0][2 * g.ny + 1] = H;
+            merged[1][0] = 0;
+            merged[1][2 * g.nx + 1] = W;
+        }
         __syncthreads();
-        if (threadIdx.x == 0) axis_walk_lds(merged[0], g.ny, H, outL[0], ws.maxBy, &nOut[0]);
-        if (threadIdx.x == 64) axis_walk_lds(merged[1], g.nx, W, outL[1], ws.maxBx, &nOut[1]);
+        axis_walk_lds(merged[0], 2 * g.ny + 2, outL[0], ws.maxBy, wsum, &nOut[0]);
+        axis_walk_lds(merged[1], 2 * g.nx + 2, outL[1], ws.maxBx, wsum, &nOut[1]);
         __syncthreads();
         for (int i = threadIdx.x; i < nOut[0]; i += blockDim.x) ws.breakY[i] = outL[0][i];
         for (int i = threadIdx.x; i < nOut[1]; i += blockDim.x) ws.breakX[i] = outL[1][i];
@@ -762,120 +804,190 @@ __global__ void __launch_bounds__(256) k_noise_breaks(NoiseGrid g, int H, int W,
         ws.wX0[k] = find_break(bX, nBx, max(g.xEdges[k] - g.overlap, 0));
         ws.wX1[k] = find_break(bX, nBx, min(g.xEdges[k + 1] + g.overlap, W));
     }
-}
-
-template <typename VT, typename WT>
-__global__ void __launch_bounds__(NF_BLK_THREADS)
-k_noise_blocks(const VT* __restrict__ v, const WT* __restrict__ wts, int W, BlockWs ws) {
-    __shared__ double red[48];
-    __shared__ int waveTails[NF_BLK_THREADS / 64];
-    const int nBy = ws.hdr[0], nBx = ws.hdr[1];
-    const int by = blockIdx.y, bx = blockIdx.x;
-    if (by >= nBy - 1 || bx >= nBx - 1) return;
-    const int y0 = ws.breakY[by], y1 = ws.breakY[by + 1], x0 = ws.breakX[bx], x1 = ws.breakX[bx + 1];
-    const int bw = x1 - x0, bh = y1 - y0, npx = bw * bh;
-    const int tid = threadIdx.x;
-    double* __restrict__ rec = ws.rec + ((long long)by * ws.maxBx + bx) * NF_BREC;
-
-    // element j of thread tid is block pixel j * 256 + tid (consecutive lanes -> consecutive x); out-of-block slots read
-    // the block's first pixel and are discarded, so that all loads issue back to back
-    double val[NF_BLK_VPT];
-    double sv = 0.0, sv2 = 0.0, n = 0.0, wmin = INFINITY, wmax = -INFINITY;
+    // tail list offsets (see tail_cap): tailCol[c] = sum over c' < c of ceil(w_c' / 3); tailRow[r] = sum over r' < r of the
+    // rows' totals h_r' * tailCol[nbx] + 18 nbx
+    const int nby = nBy - 1, nbx = nBx - 1;
     {
-        int rr = tid / bw, xx = tid - rr * bw;
-        const int dr = NF_BLK_THREADS / bw, dx = NF_BLK_THREADS - dr * bw;
-        const long long qSafe = (long long)y0 * W + x0;
-        VT tv[NF_BLK_VPT];
-        WT tw[NF_BLK_VPT];
-#pragma unroll
-        for (int j = 0; j < NF_BLK_VPT; ++j) {
-            const bool in = j * NF_BLK_THREADS + tid < npx;
-            const long long q = in ? (long long)(y0 + rr) * W + x0 + xx : qSafe;
-            tv[j] = v[q];
-            tw[j] = wts[q];
-            rr += dr;
-            xx += dx;
-            if (xx >= bw) {
-                xx -= bw;
-                rr += 1;
-            }
+        const int per = (nbx + 255) / 256, c0 = threadIdx.x * per, c1 = min(c0 + per, nbx);
+        int mine = 0;
+        for (int c = c0; c < c1; ++c) mine += (bX[c + 1] - bX[c] + 2) / 3;
+        int total;
+        int pos = block_excl_scan256(mine, wsum, &total);
+        for (int c = c0; c < c1; ++c) {
+            ws.tailCol[c] = pos;
+            pos += (bX[c + 1] - bX[c] + 2) / 3;
         }
-#pragma unroll
-        for (int j = 0; j < NF_BLK_VPT; ++j) {
-            const bool in = j * NF_BLK_THREADS + tid < npx;
-            const double t = in ? (double)tv[j] : 0.0;
-            if (t != 0.0) {
-                n += 1.0;
-                sv += t;
-                sv2 += t * t;
-                const double wv = (double)tw[j];
-                wmin = fmin(wmin, wv);
-                wmax = fmax(wmax, wv);
-            }
-            val[j] = t;
+        const int rowUnit = total;      // per pixel row of a block row
+        const int perR = (nby + 255) / 256, r0 = threadIdx.x * perR, r1 = min(r0 + perR, nby);
+        int mineR = 0;
+        for (int r = r0; r < r1; ++r) mineR += (bY[r + 1] - bY[r]) * rowUnit + 18 * nbx;
+        int totalR;
+        long long posR = block_excl_scan256(mineR, wsum, &totalR);   // below H * W / 3 + ...: fits an int
+        for (int r = r0; r < r1; ++r) {
+            ws.tailRow[r] = posR;
+            posR += (bY[r + 1] - bY[r]) * rowUnit + 18 * nbx;
         }
     }
-    block_sum3(sv, sv2, n, red);
+}
+
+// Workgroup -> block: workgroups go to the 8 XCDs round robin, so XCD x takes the block rows x, x + 8, ... and walks each
+// from left to right: the 128-byte lines that two neighbouring blocks share meet in one L2.
+__device__ __forceinline__ bool block_of_workgroup(const BlockWs& ws, int* by, int* bx) {
+    const int nby = ws.hdr[0] - 1, nbx = ws.hdr[1] - 1;
+    const int xcd = (int)(blockIdx.x & 7u), idx = (int)(blockIdx.x >> 3);
+    if (nbx < 1) return false;
+    const int r = idx / nbx;
+    *by = r * 8 + xcd;
+    *bx = idx - r * nbx;
+    return *by < nby;
+}
+static inline int blocks_grid(const BlockWs& ws) { return ((ws.maxBy - 1 + 7) / 8) * (ws.maxBx - 1) * 8; }
+
+// Tail list room of block (r, c): h_r * ceil(w_c / 3) + 18 values (at least a third of the block, and 18 for the
+// smallest: the rule for T below lets fewer than n / (2.5 shrink)^2 <= max(18, n / 3 + 8) of n valid pixels reach T).
+// Separable, so the list offsets are two short prefix tables (k_noise_breaks): tailRow[r] + h_r * tailCol[c] + 18 c.
+__device__ __forceinline__ int tail_cap(int h, int w) { return h * ((w + 2) / 3) + 18; }
+
+__device__ __forceinline__ double wave_total(double v) {
+    v = wave_sum_lane63(v);
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+
+// One WAVEFRONT per block (no barriers).  Two sweeps over the block: sums and weight ranges, then - with T known - the
+// core sums and the tail list (the second sweep finds the block in the L2).  Lanes run along x, then down the rows.
+template <typename VT, typename WT>
+__global__ void __launch_bounds__(64) k_noise_blocks(const VT* __restrict__ v, const WT* __restrict__ wts, int W, BlockWs ws) {
+    int by, bx;
+    if (!block_of_workgroup(ws, &by, &bx)) return;
+    const int y0 = ws.breakY[by], y1 = ws.breakY[by + 1], x0 = ws.breakX[bx], x1 = ws.breakX[bx + 1];
+    const int bw = x1 - x0, bh = y1 - y0, npx = bw * bh;
+    const int lane = threadIdx.x;
+    double* __restrict__ rec = ws.rec + ((long long)by * ws.maxBx + bx) * NF_BREC;
+    const int r0 = lane / bw, c0 = lane - r0 * bw;
+    const int dr = 64 / bw, dx = 64 - dr * bw;           // bw <= NF_BLK < 64
+    const unsigned base = (unsigned)y0 * (unsigned)W + (unsigned)x0;   // 32-bit pixel offsets: H * W < 2^31 (host check)
+
+    double sv = 0.0, sv2 = 0.0, n = 0.0, wmin = INFINITY, wmax = -INFINITY;
+    double wminAll = INFINITY, wmaxAll = -INFINITY;     // over every pixel of the block, valid or not (for the paint step)
+    const int iters = (npx + 63) >> 6;
+    {
+        // loads in uniform groups of 4 per lane (slots past the block re-read its first pixel and are discarded)
+        int rr = r0, xx = c0;
+        for (int i0 = 0; i0 < iters; i0 += 4) {
+            VT tv[4];
+            WT tw[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool in = (i0 + u) * 64 + lane < npx;
+                const unsigned q = in ? base + (unsigned)rr * (unsigned)W + (unsigned)xx : base;
+                tv[u] = v[q];
+                tw[u] = wts[q];
+                rr += dr;
+                xx += dx;
+                if (xx >= bw) {
+                    xx -= bw;
+                    rr += 1;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool in = (i0 + u) * 64 + lane < npx;
+                const double t = in ? (double)tv[u] : 0.0;
+                const double wv = (double)tw[u];
+                if (in) {
+                    wminAll = fmin(wminAll, wv);
+                    wmaxAll = fmax(wmaxAll, wv);
+                }
+                if (t != 0.0) {
+                    n += 1.0;
+                    sv += t;
+                    sv2 += t * t;
+                    wmin = fmin(wmin, wv);
+                    wmax = fmax(wmax, wv);
+                }
+            }
+        }
+    }
+    sv = wave_total(sv);
+    sv2 = wave_total(sv2);
+    n = wave_total(n);
+    for (int off = 32; off > 0; off >>= 1) {
+        wmin = fmin(wmin, __shfl_xor(wmin, off, 64));
+        wmax = fmax(wmax, __shfl_xor(wmax, off, 64));
+        wminAll = fmin(wminAll, __shfl_xor(wminAll, off, 64));
+        wmaxAll = fmax(wmaxAll, __shfl_xor(wmaxAll, off, 64));
+    }
     if (n == 0.0) {
-        if (tid == 0) {
+        if (lane == 0) {
             rec[0] = 0.0;
             rec[8] = 0.0;
+            rec[10] = wminAll;
+            rec[11] = wmaxAll;
         }
         return;
     }
-    wmin = block_min(wmin, red);
-    wmax = block_max(wmax, red);
     const double mu = sv / n;
-    double T = 2.0000001 * sqrt(sv2 / n);   // a hair above 2 rms: strictly fewer than n / 4 pixels can reach it
+    // T = 2.5 rms of the block, lowered by 3.5 standard errors of that rms (1 / sqrt(2n) relative): thin blocks with a
+    // noisy rms must not end up above the windows' 3-sigma thresholds (they would be scanned directly every iteration);
+    // blocks of a few pixels get T = 0, i.e. all their pixels in the list
+    const double shrink = 1.0 - 3.5 / sqrt(2.0 * n);
+    double T = shrink > 0.0 ? 2.5 * shrink * sqrt(sv2 / n) : 0.0;
+    const int cap = tail_cap(bh, bw);
+    const long long tailOff = ws.tailRow[by] + (long long)bh * ws.tailCol[bx] + 18LL * bx;
+    const bool room = tailOff + cap <= ws.tailCap;
+    double* __restrict__ tp = ws.tails + tailOff;
     double s1 = 0.0, s2 = 0.0, nc = 0.0;
-    int tc = 0;
+    int total = 0;       // tails so far (uniform); list order = pixel order
+    {
+        int rr = r0, xx = c0;
+        for (int i0 = 0; i0 < iters; i0 += 4) {
+            VT tv[4];
 #pragma unroll
-    for (int j = 0; j < NF_BLK_VPT; ++j) {
-        const double t = val[j];
-        if (t != 0.0) {
-            if (fabs(t) < T) {
-                const double d = t - mu;
-                s1 += d;
-                s2 += d * d;
-                nc += 1.0;
-            } else {
-                ++tc;
+            for (int u = 0; u < 4; ++u) {
+                const bool in = (i0 + u) * 64 + lane < npx;
+                const unsigned q = in ? base + (unsigned)rr * (unsigned)W + (unsigned)xx : base;
+                tv[u] = v[q];
+                rr += dr;
+                xx += dx;
+                if (xx >= bw) {
+                    xx -= bw;
+                    rr += 1;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool in = (i0 + u) * 64 + lane < npx;
+                const double t = in ? (double)tv[u] : 0.0;
+                bool tail = false;
+                if (t != 0.0) {
+                    if (fabs(t) < T) {
+                        const double d = t - mu;
+                        s1 += d;
+                        s2 += d * d;
+                        nc += 1.0;
+                    } else {
+                        tail = true;
+                    }
+                }
+                const unsigned long long m = __ballot(tail);
+                if (tail) {
+                    const int pos = total + __popcll(m & ((1ULL << lane) - 1ULL));
+                    if (room && pos < cap) tp[pos] = t;
+                }
+                total += __popcll(m);
             }
         }
     }
-    block_sum3(s1, s2, nc, red);
-    // exclusive prefix of the tail counts in thread order: the list order (hence every later sum) is fixed
-    const int lane = tid & 63, wave = tid >> 6;
-    int incl = tc;
-    for (int off = 1; off < 64; off <<= 1) {
-        const int up = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += up;
-    }
-    if (lane == 63) waveTails[wave] = incl;
-    __syncthreads();
-    int before = incl - tc, total = 0;
-    for (int w = 0; w < NF_BLK_THREADS / 64; ++w) {
-        if (w < wave) before += waveTails[w];
-        total += waveTails[w];
-    }
-    const long long Wtot = ws.breakX[nBx - 1] - ws.breakX[0];
-    const long long rank = (long long)(y0 - ws.breakY[0]) * Wtot + (long long)(x0 - ws.breakX[0]) * bh;
-    const long long tailOff = rank / 4 + (long long)by * (nBx - 1) + bx;
-    const int cap = npx / 4 + 1;
-    if (total > cap) {
-        // cannot happen (Chebyshev); if it did, the block would be scanned directly in every iteration (thr >= NaN is false)
+    s1 = wave_total(s1);
+    s2 = wave_total(s2);
+    nc = wave_total(nc);
+    if (!room || total > cap) {
+        // no list space (or, against Chebyshev, too many tails): the block is scanned directly in every iteration
+        // (thr >= NaN is false)
         T = __longlong_as_double(0x7ff8000000000000LL);
         total = 0;
-    } else {
-        double* __restrict__ tp = ws.tails + tailOff + before;
-        int k = 0;
-#pragma unroll
-        for (int j = 0; j < NF_BLK_VPT; ++j) {
-            const double t = val[j];
-            if (t != 0.0 && !(fabs(t) < T)) tp[k++] = t;
-        }
     }
-    if (tid == 0) {
+    if (lane == 0) {
         rec[0] = n;
         rec[1] = wmin;
         rec[2] = wmax;
@@ -886,6 +998,8 @@ k_noise_blocks(const VT* __restrict__ v, const WT* __restrict__ wts, int W, Bloc
         rec[7] = s2;
         rec[8] = (double)total;
         rec[9] = (double)tailOff;
+        rec[10] = wminAll;
+        rec[11] = wmaxAll;
     }
 }
 
@@ -893,12 +1007,7 @@ __device__ __forceinline__ void cell_range(const int* __restrict__ e, int ncell,
 
 // ---- k_noise_windows: ONE WAVEFRONT per cell (no barriers; reductions on the vector ALU) ----
 #define NF_WIN_MAXBLK 64      // blocks of a window whose records are staged in LDS (more: everything from global memory)
-#define NF_WIN_MAXTAIL 2048   // tail values of a window staged in LDS
-
-__device__ __forceinline__ double wave_total(double v) {
-    v = wave_sum_lane63(v);
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
-}
+#define NF_WIN_MAXTAIL 1024   // tail values of a window staged in LDS
 
 // one block scanned pixel by pixel (its T exceeds the threshold of this iteration)
 template <typename VT>
@@ -922,7 +1031,8 @@ __device__ __forceinline__ void scan_block(const VT* __restrict__ v, int W, cons
 
 struct WinLds {
     double T[NF_WIN_MAXBLK], nc[NF_WIN_MAXBLK], mu[NF_WIN_MAXBLK], S1[NF_WIN_MAXBLK], S2[NF_WIN_MAXBLK];
-    int tailBase[NF_WIN_MAXBLK + 1];
+    int tailBase[NF_WIN_MAXBLK];
+    long long tailOff[NF_WIN_MAXBLK];
     double tail[NF_WIN_MAXTAIL];
     unsigned char tailBlk[NF_WIN_MAXTAIL];
 };
@@ -937,9 +1047,10 @@ __device__ __forceinline__ void window_sums(const VT* __restrict__ v, int W, con
     nn = 0.0;
     if (LDS) {
         // lane = block: core sums, or (rarely) a direct scan, which the whole wavefront does block after block
-        bool scan = false;
+        bool scan = false, core = false;
         if (lane < nblk && L.nc[lane] >= 0.0) {
-            if (thr >= L.T[lane]) {
+            core = thr >= L.T[lane];
+            if (core) {
                 const double nc = L.nc[lane], dmu = L.mu[lane] - c0, S1 = L.S1[lane], S2 = L.S2[lane];
                 s = S1 + nc * dmu;
                 ss = S2 + 2.0 * dmu * S1 + nc * dmu * dmu;
@@ -948,9 +1059,11 @@ __device__ __forceinline__ void window_sums(const VT* __restrict__ v, int W, con
                 scan = true;
             }
         }
+        const unsigned long long coreMask = __ballot(core);   // bit b: the tails of block b count (it is not scanned directly)
+#pragma unroll 4
         for (int e = lane; e < ntail; e += 64) {
             const double t = L.tail[e];
-            if (thr >= L.T[L.tailBlk[e]] && fabs(t) < thr) {
+            if (((coreMask >> L.tailBlk[e]) & 1ULL) && fabs(t) < thr) {
                 const double d = t - c0;
                 s += d;
                 ss += d * d;
@@ -1076,7 +1189,6 @@ __global__ void __launch_bounds__(64) k_noise_windows(const VT* __restrict__ v, 
     if (nblk <= NF_WIN_MAXBLK && tcSum <= NF_WIN_MAXTAIL) {
         // stage the block records (lane = block) and, through a prefix of the tail counts, all tail values
         int tc = 0;
-        long long toff = 0;
         if (lane < nblk) {
             const int byo = lane / nbx;
             const double* __restrict__ rb = ws.rec + ((long long)(BY0 + byo) * ws.maxBx + BX0 + (lane - byo * nbx)) * NF_BREC;
@@ -1087,7 +1199,7 @@ __global__ void __launch_bounds__(64) k_noise_windows(const VT* __restrict__ v, 
             L.S1[lane] = rb[6];
             L.S2[lane] = rb[7];
             tc = live ? (int)rb[8] : 0;
-            toff = (long long)rb[9];
+            L.tailOff[lane] = (long long)rb[9];
         }
         int incl = tc;
         for (int off = 1; off < 64; off <<= 1) {
@@ -1095,21 +1207,21 @@ __global__ void __launch_bounds__(64) k_noise_windows(const VT* __restrict__ v, 
             if (lane >= off) incl += up;
         }
         if (lane < nblk) L.tailBase[lane] = incl - tc;
-        if (lane == 63) L.tailBase[NF_WIN_MAXBLK] = incl;
         __syncthreads();
-        // lane-parallel copy: the block of flat tail index e by binary search in the prefix
+        // the block of flat tail index e by binary search in the prefix (LDS only), then the loads, all independent
         for (int e = lane; e < tcSum; e += 64) {
             int lo = 0, hi = nblk - 1;
             while (lo < hi) {
                 const int mid = (lo + hi + 1) >> 1;
                 if (L.tailBase[mid] <= e) lo = mid; else hi = mid - 1;
             }
-            const int byo = lo / nbx;
-            const double* __restrict__ rb = ws.rec + ((long long)(BY0 + byo) * ws.maxBx + BX0 + (lo - byo * nbx)) * NF_BREC;
-            L.tail[e] = ws.tails[(long long)rb[9] + (e - L.tailBase[lo])];
             L.tailBlk[e] = (unsigned char)lo;
         }
-        (void)toff;
+#pragma unroll 8
+        for (int e = lane; e < tcSum; e += 64) {
+            const int bl = L.tailBlk[e];
+            L.tail[e] = ws.tails[L.tailOff[bl] + (e - L.tailBase[bl])];
+        }
         __syncthreads();
         rms = window_clip<VT, true>(v, W, ws, L, BY0, BX0, nbx, nblk, tcSum);
     } else {
@@ -1132,10 +1244,9 @@ k_noise_paint_blocks(const WT* __restrict__ wts, float* __restrict__ rmsMap, int
                      const double* __restrict__ stats) {
     __shared__ double cLo[NF_PAINT_MAXCAND], cHi[NF_PAINT_MAXCAND];
     __shared__ float cR[NF_PAINT_MAXCAND];
-    __shared__ int nCand, range[4];
-    const int nBy = ws.hdr[0], nBx = ws.hdr[1];
-    const int by = blockIdx.y, bx = blockIdx.x;
-    if (by >= nBy - 1 || bx >= nBx - 1) return;
+    __shared__ int nCand, range[4], uniform;
+    int by, bx;
+    if (!block_of_workgroup(ws, &by, &bx)) return;
     const int y0 = ws.breakY[by], y1 = ws.breakY[by + 1], x0 = ws.breakX[bx], x1 = ws.breakX[bx + 1];
     const int bw = x1 - x0, bh = y1 - y0, npx = bw * bh;
     const int tid = threadIdx.x;
@@ -1159,6 +1270,9 @@ k_noise_paint_blocks(const WT* __restrict__ wts, float* __restrict__ rmsMap, int
                 }
             }
         nCand = overflow ? -1 : n;
+        // every weight of the block inside the first candidate's range: one value for the whole block, weights not read
+        const double* rb = ws.rec + ((long long)by * ws.maxBx + bx) * NF_BREC;
+        uniform = (!overflow && n >= 1 && rb[10] >= cLo[0] && rb[11] < cHi[0]) ? 1 : 0;
         range[0] = iLo;
         range[1] = iHi;
         range[2] = kLo;
@@ -1168,11 +1282,15 @@ k_noise_paint_blocks(const WT* __restrict__ wts, float* __restrict__ rmsMap, int
     const int nc = nCand;
     int rr = tid / bw, xx = tid - rr * bw;
     const int dr = NF_BLK_THREADS / bw, dx = NF_BLK_THREADS - dr * bw;
+    const bool uni = uniform != 0;
+    const float uniVal = uni ? cR[0] : 0.0f;
     for (int p = tid; p < npx; p += NF_BLK_THREADS) {
         const long long q = (long long)(y0 + rr) * W + x0 + xx;
-        const double wv = (double)wts[q];
         float outv = 0.0f;
-        if (nc >= 0) {
+        const double wv = uni ? 0.0 : (double)wts[q];
+        if (uni) {
+            outv = uniVal;
+        } else if (nc >= 0) {
             for (int c = 0; c < nc; ++c)
                 if (wv >= cLo[c] && wv < cHi[c]) {
                     outv = cR[c];
@@ -1308,15 +1426,19 @@ int median_stack(int rtype, const void* in, void* out, int N, long long n, hipSt
 }
 
 static size_t align8(size_t b) { return (b + 7) & ~(size_t)7; }
+// sum of tail_cap over any block decomposition of an H x W map with at most maxBy x maxBx blocks
+static size_t noise_tail_cap(int H, int W, int maxBy, int maxBx) {
+    return (size_t)H * ((size_t)W / 3 + maxBx) + 18 * (size_t)maxBy * maxBx + 8;
+}
 
 // cell records, then (one-bin clipped-RMS mode) the block tables: see BlockWs
 size_t noise_workspace_bytes(const NoiseGrid& g, int H, int W) {
     size_t cells = (size_t)g.ny * g.nx * cell_stride(g.numBins) * sizeof(double);
     if (g.numBins != 1) return cells;
     const size_t maxBy = blocks_max_breaks(g.ny, H), maxBx = blocks_max_breaks(g.nx, W);
-    size_t ints = align8((4 + maxBy + maxBx + 2 * (size_t)g.ny + 2 * (size_t)g.nx) * sizeof(int));
+    size_t ints = align8((8 + maxBy + 2 * maxBx + 2 * (size_t)g.ny + 2 * (size_t)g.nx) * sizeof(int)) + maxBy * sizeof(long long);
     size_t recs = maxBy * maxBx * NF_BREC * sizeof(double);
-    size_t tails = ((size_t)H * W / 4 + maxBy * maxBx + 8) * sizeof(double);
+    size_t tails = noise_tail_cap(H, W, (int)maxBy, (int)maxBx) * sizeof(double);
     return cells + ints + recs + tails;
 }
 
@@ -1342,25 +1464,29 @@ int noise_map(int vtype, const void* filtered, const void* weights, int wtype, f
         ws.maxBx = blocks_max_breaks(g.nx, W);
         char* p = (char*)cellStats + (size_t)g.ny * g.nx * cell_stride(1) * sizeof(double);
         ws.hdr = (int*)p;
-        ws.breakY = ws.hdr + 4;
+        ws.tailCap = (long long)noise_tail_cap(H, W, ws.maxBy, ws.maxBx);
+        ws.breakY = ws.hdr + 8;
         ws.breakX = ws.breakY + ws.maxBy;
         ws.wY0 = ws.breakX + ws.maxBx;
         ws.wY1 = ws.wY0 + g.ny;
         ws.wX0 = ws.wY1 + g.ny;
         ws.wX1 = ws.wX0 + g.nx;
-        p += align8((4 + (size_t)ws.maxBy + ws.maxBx + 2 * (size_t)g.ny + 2 * (size_t)g.nx) * sizeof(int));
+        ws.tailCol = ws.wX1 + g.nx;
+        p += align8((8 + (size_t)ws.maxBy + 2 * (size_t)ws.maxBx + 2 * (size_t)g.ny + 2 * (size_t)g.nx) * sizeof(int));
+        ws.tailRow = (long long*)p;
+        p += (size_t)ws.maxBy * sizeof(long long);
         ws.rec = (double*)p;
         ws.tails = ws.rec + (size_t)ws.maxBy * ws.maxBx * NF_BREC;
-        if (ws.maxBy > 65535) {
-            nf_set_error("noise_map: too many block rows");
+        if ((long long)H * W >= (1LL << 31)) {
+            nf_set_error("noise_map: map too large for the 32-bit pixel offsets of the block kernels");
             return NF_ERR_SIZE;
         }
         hipLaunchKernelGGL(k_noise_breaks, dim3(1), dim3(256), 0, s, g, H, W, ws);
         NF_CHECK_LAUNCH("k_noise_breaks");
-        dim3 gb(ws.maxBx - 1, ws.maxBy - 1), gw(g.ny * g.nx);
+        dim3 gb(blocks_grid(ws)), gw(g.ny * g.nx);
 #define NF_NB(VT, WT)                                                                                                      \
     do {                                                                                                                   \
-        hipLaunchKernelGGL((k_noise_blocks<VT, WT>), gb, dim3(NF_BLK_THREADS), 0, s, (const VT*)filtered, (const WT*)weights, W, ws); \
+        hipLaunchKernelGGL((k_noise_blocks<VT, WT>), gb, dim3(64), 0, s, (const VT*)filtered, (const WT*)weights, W, ws); \
         hipLaunchKernelGGL((k_noise_windows<VT>), gw, dim3(64), 0, s, (const VT*)filtered, W, g, ws, stats);               \
     } while (0)
         if (vtype == NF_F64 && wtype == NF_F64) NF_NB(double, double);

@@ -604,10 +604,11 @@ k_noise_cells_reg(const VT* __restrict__ v, const WT* __restrict__ wts, int H, i
 // clipping loop visits every pixel of a window up to 11 times.  Here the map is read once:
 //  k_noise_breaks   the window boundaries of all cells cut each axis into intervals (cut again where longer than
 //                   NF_BLK); their products are the elementary blocks, and every window is a whole number of blocks.
-//  k_noise_blocks   one workgroup per block, block held in registers: count of valid pixels, weight range, and with
-//                   T = 2.5 * sqrt(mean v^2) of the block the CORE pixels |v| < T as three sums (n, sum (v - mu),
-//                   sum (v - mu)^2, mu = block mean) and the TAIL pixels |v| >= T as a list of values (in Gaussian noise
-//                   1 - 2 % of the pixels; list capacities from Chebyshev's inequality, offsets by k_noise_breaks).
+//  k_noise_block_stats / k_noise_window_rms0 / k_noise_block_core
+//                   one wavefront per block: count of valid pixels, sums, weight ranges; from those the unclipped rms of
+//                   every window; then, with T = 2.25 x the smallest such rms among the block's windows, the CORE pixels
+//                   |v| < T as three sums (n, sum (v - mu), sum (v - mu)^2, mu = block mean) and the TAIL pixels |v| >= T
+//                   as a list of values (2 - 3 % of the pixels in Gaussian noise; the second sweep is served by the caches).
 //  k_noise_windows  one workgroup per cell: the clipping iterations of nemo/filters.py:417-433 over its blocks.  An
 //                   iteration with threshold thr >= T of a block takes all of the block's core pixels (|v| < T <= thr)
 //                   from the three sums, shifted to the current centre, and tests only the tail list; a block with
@@ -616,7 +617,8 @@ k_noise_cells_reg(const VT* __restrict__ v, const WT* __restrict__ wts, int H, i
 #define NF_BLK 48
 #define NF_BLK_THREADS 256
 #define NF_BLK_VPT (NF_BLK * NF_BLK / NF_BLK_THREADS)
-#define NF_BREC 12   // per block: n valid, wmin, wmax, T, n core, mu, S1, S2, tail count, tail offset, wmin / wmax of all pixels
+#define NF_BREC 14   // per block: n valid, wmin, wmax, T, n core, mu, S1, S2, tail count, tail offset, wmin / wmax of all pixels,
+                     // sum v, sum v^2
 
 struct BlockWs {
     int* hdr;                      // [0] breakpoints along y, [1] along x
@@ -783,6 +785,8 @@ __global__ void __launch_bounds__(256) k_noise_breaks(NoiseGrid g, int H, int W,
         if (threadIdx.x == 0) {
             ws.hdr[0] = nOut[0];
             ws.hdr[1] = nOut[1];
+            ws.hdr[2] = 0;
+            ws.hdr[3] = 0;
         }
         bY = outL[0];
         bX = outL[1];
@@ -793,6 +797,8 @@ __global__ void __launch_bounds__(256) k_noise_breaks(NoiseGrid g, int H, int W,
         if (threadIdx.x == 0) {
             ws.hdr[0] = nOut[0];
             ws.hdr[1] = nOut[1];
+            ws.hdr[2] = 0;
+            ws.hdr[3] = 0;
         }
     }
     const int nBy = nOut[0], nBx = nOut[1];
@@ -853,10 +859,13 @@ __device__ __forceinline__ double wave_total(double v) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
 
-// One WAVEFRONT per block (no barriers).  Two sweeps over the block: sums and weight ranges, then - with T known - the
-// core sums and the tail list (the second sweep finds the block in the L2).  Lanes run along x, then down the rows.
+__device__ __forceinline__ void cell_range(const int* __restrict__ e, int ncell, int overlap, int t, int* lo, int* hi);
+
+// One WAVEFRONT per block (no barriers), lanes along x, then down the rows; loads in uniform groups of 4 per lane (slots
+// past the block re-read its first pixel and are discarded).
+// First sweep (k_noise_block_stats): valid count, sum v, sum v^2, weight ranges.
 template <typename VT, typename WT>
-__global__ void __launch_bounds__(64) k_noise_blocks(const VT* __restrict__ v, const WT* __restrict__ wts, int W, BlockWs ws) {
+__global__ void __launch_bounds__(64) k_noise_block_stats(const VT* __restrict__ v, const WT* __restrict__ wts, int W, BlockWs ws) {
     int by, bx;
     if (!block_of_workgroup(ws, &by, &bx)) return;
     const int y0 = ws.breakY[by], y1 = ws.breakY[by + 1], x0 = ws.breakX[bx], x1 = ws.breakX[bx + 1];
@@ -866,45 +875,41 @@ __global__ void __launch_bounds__(64) k_noise_blocks(const VT* __restrict__ v, c
     const int r0 = lane / bw, c0 = lane - r0 * bw;
     const int dr = 64 / bw, dx = 64 - dr * bw;           // bw <= NF_BLK < 64
     const unsigned base = (unsigned)y0 * (unsigned)W + (unsigned)x0;   // 32-bit pixel offsets: H * W < 2^31 (host check)
-
     double sv = 0.0, sv2 = 0.0, n = 0.0, wmin = INFINITY, wmax = -INFINITY;
     double wminAll = INFINITY, wmaxAll = -INFINITY;     // over every pixel of the block, valid or not (for the paint step)
     const int iters = (npx + 63) >> 6;
-    {
-        // loads in uniform groups of 4 per lane (slots past the block re-read its first pixel and are discarded)
-        int rr = r0, xx = c0;
-        for (int i0 = 0; i0 < iters; i0 += 4) {
-            VT tv[4];
-            WT tw[4];
+    int rr = r0, xx = c0;
+    for (int i0 = 0; i0 < iters; i0 += 4) {
+        VT tv[4];
+        WT tw[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const bool in = (i0 + u) * 64 + lane < npx;
-                const unsigned q = in ? base + (unsigned)rr * (unsigned)W + (unsigned)xx : base;
-                tv[u] = v[q];
-                tw[u] = wts[q];
-                rr += dr;
-                xx += dx;
-                if (xx >= bw) {
-                    xx -= bw;
-                    rr += 1;
-                }
+        for (int u = 0; u < 4; ++u) {
+            const bool in = (i0 + u) * 64 + lane < npx;
+            const unsigned q = in ? base + (unsigned)rr * (unsigned)W + (unsigned)xx : base;
+            tv[u] = v[q];
+            tw[u] = wts[q];
+            rr += dr;
+            xx += dx;
+            if (xx >= bw) {
+                xx -= bw;
+                rr += 1;
             }
+        }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const bool in = (i0 + u) * 64 + lane < npx;
-                const double t = in ? (double)tv[u] : 0.0;
-                const double wv = (double)tw[u];
-                if (in) {
-                    wminAll = fmin(wminAll, wv);
-                    wmaxAll = fmax(wmaxAll, wv);
-                }
-                if (t != 0.0) {
-                    n += 1.0;
-                    sv += t;
-                    sv2 += t * t;
-                    wmin = fmin(wmin, wv);
-                    wmax = fmax(wmax, wv);
-                }
+        for (int u = 0; u < 4; ++u) {
+            const bool in = (i0 + u) * 64 + lane < npx;
+            const double t = in ? (double)tv[u] : 0.0;
+            const double wv = (double)tw[u];
+            if (in) {
+                wminAll = fmin(wminAll, wv);
+                wmaxAll = fmax(wmaxAll, wv);
+            }
+            if (t != 0.0) {
+                n += 1.0;
+                sv += t;
+                sv2 += t * t;
+                wmin = fmin(wmin, wv);
+                wmax = fmax(wmax, wv);
             }
         }
     }
@@ -917,80 +922,162 @@ __global__ void __launch_bounds__(64) k_noise_blocks(const VT* __restrict__ v, c
         wminAll = fmin(wminAll, __shfl_xor(wminAll, off, 64));
         wmaxAll = fmax(wmaxAll, __shfl_xor(wmaxAll, off, 64));
     }
-    if (n == 0.0) {
-        if (lane == 0) {
-            rec[0] = 0.0;
-            rec[8] = 0.0;
-            rec[10] = wminAll;
-            rec[11] = wmaxAll;
-        }
-        return;
+    if (lane == 0) {
+        rec[0] = n;
+        rec[1] = wmin;
+        rec[2] = wmax;
+        rec[8] = 0.0;
+        rec[10] = wminAll;
+        rec[11] = wmaxAll;
+        rec[12] = sv;
+        rec[13] = sv2;
     }
-    const double mu = sv / n;
-    // T = 2.5 rms of the block, lowered by 3.5 standard errors of that rms (1 / sqrt(2n) relative): thin blocks with a
-    // noisy rms must not end up above the windows' 3-sigma thresholds (they would be scanned directly every iteration);
-    // blocks of a few pixels get T = 0, i.e. all their pixels in the list
-    const double shrink = 1.0 - 3.5 / sqrt(2.0 * n);
-    double T = shrink > 0.0 ? 2.5 * shrink * sqrt(sv2 / n) : 0.0;
+}
+
+// A robust noise level for every cell's window from the block sums alone (one wavefront per cell, lane = block): the
+// median of the blocks' unclipped standard deviations, weighted by their valid pixels - bright objects sit in a few blocks
+// and leave it alone.  Left in the cell record's rms slot until k_noise_windows overwrites it; -1 for a window without
+// valid pixels.  Windows of more than 64 blocks (a cell over a whole map) take the plain standard deviation of the window.
+__global__ void __launch_bounds__(64) k_noise_window_rms0(NoiseGrid g, BlockWs ws, double* __restrict__ stats) {
+    const int cell = blockIdx.x, lane = threadIdx.x;
+    const int i = cell / g.nx, k = cell - i * g.nx;
+    const int BY0 = ws.wY0[i], BX0 = ws.wX0[k], nbx = ws.wX1[k] - BX0, nblk = (ws.wY1[i] - BY0) * nbx;
+    double r = -1.0;
+    if (nblk <= 64) {
+        double n = 0.0, rb_ = 0.0;
+        if (lane < nblk) {
+            const int byo = lane / nbx;
+            const double* __restrict__ rb = ws.rec + ((long long)(BY0 + byo) * ws.maxBx + BX0 + (lane - byo * nbx)) * NF_BREC;
+            n = rb[0];
+            if (n > 0.0) {
+                const double m = rb[12] / n, var = rb[13] / n - m * m;
+                rb_ = sqrt(var > 0.0 ? var : 0.0);
+            }
+        }
+        double total = n;
+        for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off, 64);
+        if (total > 0.0) {
+            // weight of the blocks ordered before this one (ties by lane); the median block straddles half the total
+            double before = 0.0;
+            for (int j = 0; j < nblk; ++j) {
+                const double nj = __shfl(n, j, 64), rj = __shfl(rb_, j, 64);
+                if (rj < rb_ || (rj == rb_ && j < lane)) before += nj;
+            }
+            const bool med = n > 0.0 && before <= 0.5 * total && 0.5 * total < before + n;
+            const unsigned long long m = __ballot(med);
+            const int src = m ? __ffsll((long long)m) - 1 : 0;
+            r = __shfl(rb_, src, 64);
+        }
+    } else {
+        double n = 0.0, sv = 0.0, sv2 = 0.0;
+        for (int bi = lane; bi < nblk; bi += 64) {
+            const int byo = bi / nbx;
+            const double* __restrict__ rb = ws.rec + ((long long)(BY0 + byo) * ws.maxBx + BX0 + (bi - byo * nbx)) * NF_BREC;
+            n += rb[0];
+            sv += rb[12];
+            sv2 += rb[13];
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            n += __shfl_xor(n, off, 64);
+            sv += __shfl_xor(sv, off, 64);
+            sv2 += __shfl_xor(sv2, off, 64);
+        }
+        if (n > 0.0) {
+            const double m = sv / n, var = sv2 / n - m * m;
+            r = sqrt(var > 0.0 ? var : 0.0);
+        }
+    }
+    if (lane == 0) stats[(long long)cell * cell_stride(1) + 3] = r;
+}
+
+// Second sweep (k_noise_block_core): T = 2.25 x the smallest of those noise levels among the windows that contain the
+// block - the clipped rms of a window is rarely below 3/4 of its median block rms, so T stays under the windows' 3-sigma
+// thresholds whatever the block itself looks like (correlated noise makes single blocks much noisier or quieter than their
+// windows; a bright object fills its block's list instead of raising T).
+// Core sums about the block mean, tail list in pixel order.  The block is found in the L2 / infinity cache.
+template <typename VT>
+__global__ void __launch_bounds__(64) k_noise_block_core(const VT* __restrict__ v, int W, NoiseGrid g, BlockWs ws,
+                                                        const double* __restrict__ stats) {
+    int by, bx;
+    if (!block_of_workgroup(ws, &by, &bx)) return;
+    const int y0 = ws.breakY[by], y1 = ws.breakY[by + 1], x0 = ws.breakX[bx], x1 = ws.breakX[bx + 1];
+    const int bw = x1 - x0, bh = y1 - y0, npx = bw * bh;
+    const int lane = threadIdx.x;
+    double* __restrict__ rec = ws.rec + ((long long)by * ws.maxBx + bx) * NF_BREC;
+    const double n = rec[0];
+    if (n == 0.0) return;
+    int iLo, iHi, kLo, kHi;
+    cell_range(g.yEdges, g.ny, g.overlap, y0, &iLo, &iHi);
+    cell_range(g.xEdges, g.nx, g.overlap, x0, &kLo, &kHi);
+    const int nk = kHi - kLo + 1, ncand = (iHi >= iLo && nk > 0) ? (iHi - iLo + 1) * nk : 0;
+    double rmin = INFINITY;
+    for (int c = lane; c < ncand; c += 64) {
+        const int ci = c / nk;
+        const double r = stats[(long long)((iLo + ci) * g.nx + kLo + (c - ci * nk)) * cell_stride(1) + 3];
+        if (r >= 0.0) rmin = fmin(rmin, r);
+    }
+    for (int off = 32; off > 0; off >>= 1) rmin = fmin(rmin, __shfl_xor(rmin, off, 64));
+    if (ncand == 0) rmin = 0.0;                  // in no window: nothing will ask
+    double T = 2.25 * rmin;
+    const double mu = rec[12] / n;
+    const int r0 = lane / bw, c0 = lane - r0 * bw;
+    const int dr = 64 / bw, dx = 64 - dr * bw;
+    const unsigned base = (unsigned)y0 * (unsigned)W + (unsigned)x0;
     const int cap = tail_cap(bh, bw);
     const long long tailOff = ws.tailRow[by] + (long long)bh * ws.tailCol[bx] + 18LL * bx;
     const bool room = tailOff + cap <= ws.tailCap;
     double* __restrict__ tp = ws.tails + tailOff;
     double s1 = 0.0, s2 = 0.0, nc = 0.0;
     int total = 0;       // tails so far (uniform); list order = pixel order
-    {
-        int rr = r0, xx = c0;
-        for (int i0 = 0; i0 < iters; i0 += 4) {
-            VT tv[4];
+    const int iters = (npx + 63) >> 6;
+    int rr = r0, xx = c0;
+    for (int i0 = 0; i0 < iters; i0 += 4) {
+        VT tv[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const bool in = (i0 + u) * 64 + lane < npx;
-                const unsigned q = in ? base + (unsigned)rr * (unsigned)W + (unsigned)xx : base;
-                tv[u] = v[q];
-                rr += dr;
-                xx += dx;
-                if (xx >= bw) {
-                    xx -= bw;
-                    rr += 1;
+        for (int u = 0; u < 4; ++u) {
+            const bool in = (i0 + u) * 64 + lane < npx;
+            const unsigned q = in ? base + (unsigned)rr * (unsigned)W + (unsigned)xx : base;
+            tv[u] = v[q];
+            rr += dr;
+            xx += dx;
+            if (xx >= bw) {
+                xx -= bw;
+                rr += 1;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool in = (i0 + u) * 64 + lane < npx;
+            const double t = in ? (double)tv[u] : 0.0;
+            bool tail = false;
+            if (t != 0.0) {
+                if (fabs(t) < T) {
+                    const double d = t - mu;
+                    s1 += d;
+                    s2 += d * d;
+                    nc += 1.0;
+                } else {
+                    tail = true;
                 }
             }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const bool in = (i0 + u) * 64 + lane < npx;
-                const double t = in ? (double)tv[u] : 0.0;
-                bool tail = false;
-                if (t != 0.0) {
-                    if (fabs(t) < T) {
-                        const double d = t - mu;
-                        s1 += d;
-                        s2 += d * d;
-                        nc += 1.0;
-                    } else {
-                        tail = true;
-                    }
-                }
-                const unsigned long long m = __ballot(tail);
-                if (tail) {
-                    const int pos = total + __popcll(m & ((1ULL << lane) - 1ULL));
-                    if (room && pos < cap) tp[pos] = t;
-                }
-                total += __popcll(m);
+            const unsigned long long m = __ballot(tail);
+            if (tail) {
+                const int pos = total + __popcll(m & ((1ULL << lane) - 1ULL));
+                if (room && pos < cap) tp[pos] = t;
             }
+            total += __popcll(m);
         }
     }
     s1 = wave_total(s1);
     s2 = wave_total(s2);
     nc = wave_total(nc);
     if (!room || total > cap) {
-        // no list space (or, against Chebyshev, too many tails): the block is scanned directly in every iteration
-        // (thr >= NaN is false)
+        // more tails than the list holds (a block far noisier than its windows): it is scanned directly in every
+        // iteration (thr >= NaN is false)
         T = __longlong_as_double(0x7ff8000000000000LL);
         total = 0;
     }
     if (lane == 0) {
-        rec[0] = n;
-        rec[1] = wmin;
-        rec[2] = wmax;
         rec[3] = T;
         rec[4] = nc;
         rec[5] = mu;
@@ -998,27 +1085,45 @@ __global__ void __launch_bounds__(64) k_noise_blocks(const VT* __restrict__ v, c
         rec[7] = s2;
         rec[8] = (double)total;
         rec[9] = (double)tailOff;
-        rec[10] = wminAll;
-        rec[11] = wmaxAll;
     }
 }
 
-__device__ __forceinline__ void cell_range(const int* __restrict__ e, int ncell, int overlap, int t, int* lo, int* hi);
+
 
 // ---- k_noise_windows: ONE WAVEFRONT per cell (no barriers; reductions on the vector ALU) ----
 #define NF_WIN_MAXBLK 64      // blocks of a window whose records are staged in LDS (more: everything from global memory)
 #define NF_WIN_MAXTAIL 1024   // tail values of a window staged in LDS
 
-// one block scanned pixel by pixel (its T exceeds the threshold of this iteration)
+// one block scanned pixel by pixel (its T exceeds the threshold of this iteration): flat over the block, 4 loads per lane
+// in flight
 template <typename VT>
 __device__ __forceinline__ void scan_block(const VT* __restrict__ v, int W, const BlockWs& ws, int by, int bx, double c0, double thr,
                                            double& s, double& ss, double& nn) {
     const int lane = threadIdx.x & 63;
     const int y0 = ws.breakY[by], y1 = ws.breakY[by + 1], x0 = ws.breakX[bx], x1 = ws.breakX[bx + 1];
-    for (int y = y0; y < y1; ++y) {
-        const VT* __restrict__ row = v + (long long)y * W;
-        for (int x = x0 + lane; x < x1; x += 64) {
-            const double t = (double)row[x];
+    const int bw = x1 - x0, npx = bw * (y1 - y0);
+    const int dr = 64 / bw, dx = 64 - dr * bw;
+    int rr = lane / bw, xx = lane - rr * bw;
+    const unsigned base = (unsigned)y0 * (unsigned)W + (unsigned)x0;
+    const int iters = (npx + 63) >> 6;
+    for (int i0 = 0; i0 < iters; i0 += 4) {
+        VT tv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool in = (i0 + u) * 64 + lane < npx;
+            const unsigned q = in ? base + (unsigned)rr * (unsigned)W + (unsigned)xx : base;
+            tv[u] = v[q];
+            rr += dr;
+            xx += dx;
+            if (xx >= bw) {
+                xx -= bw;
+                rr += 1;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool in = (i0 + u) * 64 + lane < npx;
+            const double t = in ? (double)tv[u] : 0.0;
             if (t != 0.0 && fabs(t) < thr) {
                 const double d = t - c0;
                 s += d;
@@ -1036,6 +1141,16 @@ struct WinLds {
     double tail[NF_WIN_MAXTAIL];
     unsigned char tailBlk[NF_WIN_MAXTAIL];
 };
+
+// the block that owns flat tail index e: binary search in the prefix of the tail counts
+__device__ __forceinline__ int tail_block(const WinLds& L, int nblk, int e) {
+    int lo = 0, hi = nblk - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (L.tailBase[mid] <= e) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
 
 // sum d, sum d^2, count over the valid pixels of the window with |v| < thr, d = v - c0 (every lane gets the totals)
 template <typename VT, bool LDS>
@@ -1060,8 +1175,9 @@ __device__ __forceinline__ void window_sums(const VT* __restrict__ v, int W, con
             }
         }
         const unsigned long long coreMask = __ballot(core);   // bit b: the tails of block b count (it is not scanned directly)
+        const int nStaged = min(ntail, NF_WIN_MAXTAIL);
 #pragma unroll 4
-        for (int e = lane; e < ntail; e += 64) {
+        for (int e = lane; e < nStaged; e += 64) {
             const double t = L.tail[e];
             if (((coreMask >> L.tailBlk[e]) & 1ULL) && fabs(t) < thr) {
                 const double d = t - c0;
@@ -1070,7 +1186,19 @@ __device__ __forceinline__ void window_sums(const VT* __restrict__ v, int W, con
                 nn += 1.0;
             }
         }
+#pragma unroll 4
+        for (int e = NF_WIN_MAXTAIL + lane; e < ntail; e += 64) {       // beyond the LDS room: from the lists themselves
+            const int bl = tail_block(L, nblk, e);
+            const double t = ws.tails[L.tailOff[bl] + (e - L.tailBase[bl])];
+            if (((coreMask >> bl) & 1ULL) && fabs(t) < thr) {
+                const double d = t - c0;
+                s += d;
+                ss += d * d;
+                nn += 1.0;
+            }
+        }
         unsigned long long todo = __ballot(scan);
+        if (todo && lane == 0) atomicAdd(&ws.hdr[2], __popcll(todo));    // diagnostics: direct block scans
         while (todo) {
             const int bi = __ffsll((long long)todo) - 1;
             todo &= todo - 1;
@@ -1186,8 +1314,9 @@ __global__ void __launch_bounds__(64) k_noise_windows(const VT* __restrict__ v, 
         return;
     }
     double rms;
-    if (nblk <= NF_WIN_MAXBLK && tcSum <= NF_WIN_MAXTAIL) {
-        // stage the block records (lane = block) and, through a prefix of the tail counts, all tail values
+    if (nblk <= NF_WIN_MAXBLK) {
+        // stage the block records (lane = block) and, through a prefix of the tail counts, the first NF_WIN_MAXTAIL tail
+        // values (a window with more - bright objects - reads the rest from global memory in every iteration)
         int tc = 0;
         if (lane < nblk) {
             const int byo = lane / nbx;
@@ -1209,19 +1338,14 @@ __global__ void __launch_bounds__(64) k_noise_windows(const VT* __restrict__ v, 
         if (lane < nblk) L.tailBase[lane] = incl - tc;
         __syncthreads();
         // the block of flat tail index e by binary search in the prefix (LDS only), then the loads, all independent
-        for (int e = lane; e < tcSum; e += 64) {
-            int lo = 0, hi = nblk - 1;
-            while (lo < hi) {
-                const int mid = (lo + hi + 1) >> 1;
-                if (L.tailBase[mid] <= e) lo = mid; else hi = mid - 1;
-            }
-            L.tailBlk[e] = (unsigned char)lo;
-        }
+        const int nStaged = min(tcSum, NF_WIN_MAXTAIL);
+        for (int e = lane; e < nStaged; e += 64) L.tailBlk[e] = (unsigned char)tail_block(L, nblk, e);
 #pragma unroll 8
-        for (int e = lane; e < tcSum; e += 64) {
+        for (int e = lane; e < nStaged; e += 64) {
             const int bl = L.tailBlk[e];
             L.tail[e] = ws.tails[L.tailOff[bl] + (e - L.tailBase[bl])];
         }
+        if (tcSum > NF_WIN_MAXTAIL && lane == 0) atomicAdd(&ws.hdr[3], 1);   // diagnostics: windows with more tails than LDS room
         __syncthreads();
         rms = window_clip<VT, true>(v, W, ws, L, BY0, BX0, nbx, nblk, tcSum);
     } else {
@@ -1486,7 +1610,9 @@ int noise_map(int vtype, const void* filtered, const void* weights, int wtype, f
         dim3 gb(blocks_grid(ws)), gw(g.ny * g.nx);
 #define NF_NB(VT, WT)                                                                                                      \
     do {                                                                                                                   \
-        hipLaunchKernelGGL((k_noise_blocks<VT, WT>), gb, dim3(64), 0, s, (const VT*)filtered, (const WT*)weights, W, ws); \
+        hipLaunchKernelGGL((k_noise_block_stats<VT, WT>), gb, dim3(64), 0, s, (const VT*)filtered, (const WT*)weights, W, ws); \
+        hipLaunchKernelGGL(k_noise_window_rms0, gw, dim3(64), 0, s, g, ws, stats);                                         \
+        hipLaunchKernelGGL((k_noise_block_core<VT>), gb, dim3(64), 0, s, (const VT*)filtered, W, g, ws, stats);            \
         hipLaunchKernelGGL((k_noise_windows<VT>), gw, dim3(64), 0, s, (const VT*)filtered, W, g, ws, stats);               \
     } while (0)
         if (vtype == NF_F64 && wtype == NF_F64) NF_NB(double, double);

@@ -388,6 +388,7 @@ class TileEngine(object):
         check(self.lib.nf_noise_map(prec_of(filtered), ptr(filtered), ptr(medWeights), prec_of(medWeights), ptr(rms),
                                     self.H, self.W, ncy, ncx, ptr(yE), ptr(xE), overlap, nb, quant, 1 if estimator == 'percentile' else 0, ptr(work),
                                     work.numel() * 8, stream_ptr()), "nf_noise_map")
+        self._lastNoiseWork = (work, ncy, ncx, nb)       # diagnostics (tools/noisedbg.py)
         return rms
 
     def edge_check(self, filtered, psMask, size):

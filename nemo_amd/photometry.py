@@ -70,6 +70,30 @@ def getObjectPositions(mapData, threshold, findCenterOfMass=True):
     return objIDs, positions, numPix, seg
 
 
+def _lookupDev(dMap, iy, ix):
+    """dMap[iy, ix] as a float64 device tensor (not fetched)."""
+    t = engine.torch()
+    return dMap[t.as_tensor(iy, device=dMap.device), t.as_tensor(ix, device=dMap.device)].to(t.float64)
+
+
+def _numpyDtype(tensor):
+    return engine.torch().empty(0, dtype=tensor.dtype).numpy().dtype
+
+
+def _fetchTogether(queued):
+    """One device-to-host transfer for several small 1-D device results: {key: float64 numpy array}."""
+    t = engine.torch()
+    if len(queued) == 0:
+        return {}
+    parts = [v.reshape(-1).to(t.float64) for k, v in queued]
+    flat = (t.cat(parts) if len(parts) > 1 else parts[0]).cpu().numpy()
+    out, pos = {}, 0
+    for (k, v), p in zip(queued, parts):
+        out[k] = flat[pos:pos + p.numel()]
+        pos += p.numel()
+    return out
+
+
 def _lookup(mapLike, iy, ix):
     """mapLike[iy, ix] for a numpy array or a device tensor; returns numpy."""
     if hasattr(mapLike, 'is_cuda'):
@@ -81,9 +105,14 @@ def _lookup(mapLike, iy, ix):
 def findObjects(filteredMapDict, threshold=3.0, minObjPix=3, rejectBorder=10, findCenterOfMass=True, flagRings=True,
                 ringThresholdSigma=0, ringFlagDistArcmin=12.0, ringFlagMinRingerSNR=20, invertMap=False,
                 objIdent='ACT-CL', longNames=False, verbose=True, useInterpolator=True, measureShapes=False,
-                DS9RegionsPath=None):
+                DS9RegionsPath=None, _prefetch=None):
     """Finds objects in the S/N map of ``filteredMapDict`` (nemo/photometry.py:25-210).  Returns a
-    :class:`nemo_amd.catalogs.Table` (or [] if nothing is found, as the reference does)."""
+    :class:`nemo_amd.catalogs.Table` (or [] if nothing is found, as the reference does).
+
+    Everything that is read off device maps at the object positions (S/N, ring labels, flags) is enqueued first and
+    fetched in ONE transfer.  ``_prefetch`` (used by pipelines._detectAndMeasure): a list of (mapData, negate) whose
+    values at the objects' sky positions :func:`measureFluxes` / :func:`getSNRValues` will ask for next - they join the
+    same transfer and wait on the returned table, so that those calls do not go back to the device."""
     if measureShapes:
         raise NotImplementedError("measureShapes (nemo/photometry.py:133-184) is not part of this build yet")
     if threshold < 0:
@@ -118,25 +147,47 @@ def findObjects(filteredMapDict, threshold=3.0, minObjPix=3, rejectBorder=10, fi
         xs = (idx % W).astype(np.float64)
 
     iyr, ixr = np.round(ys).astype(np.int64), np.round(xs).astype(np.int64)      # int(round()): half to even, as np.round
+    t = engine.torch()
+    queued = []        # device results wanted on the host: (key, 1-D tensor), fetched together below
     if useInterpolator == True:                                                   # :81-84,128
-        SNRs = eng.spline_eval(dSN, np.stack([ys, xs], axis=1), negate=invertMap)
+        queued.append(('SNR', eng.spline_eval(dSN, np.stack([ys, xs], axis=1), negate=invertMap, to_host=False)))
     else:
-        SNRs = _lookup(dSN, iyr, ixr).astype(np.float64) * (-1.0 if invertMap else 1.0)
-
-    ringFlags = np.zeros(len(sel), dtype=bool)
+        queued.append(('SNR', _lookupDev(dSN, iyr, ixr) * (-1.0 if invertMap else 1.0)))
     if ringLabels is not None:                                                    # :112-114
-        t = engine.torch()
         iy = t.as_tensor(ys.astype(np.int64), device=dSN.device)                  # int() truncation
         ix = t.as_tensor(xs.astype(np.int64), device=dSN.device)
         lab = ringLabels[iy, ix].to(t.int64)
-        ringFlags = isRing[lab].cpu().numpy() > 0
+        queued.append(('ring', isRing[lab]))
+    flagsOnDevice = hasattr(flagMask, 'is_cuda')
+    if flagsOnDevice:
+        queued.append(('flags', _lookupDev(flagMask, iyr, ixr)))
 
     RADeg, decDeg = wcs.pix2wcs(xs, ys)                                           # :115-117
     RADeg = np.where(RADeg < 0, 360.0 + RADeg, RADeg)
+    pre = []
+    if _prefetch:
+        # the positions measureFluxes will compute from the catalogue's coordinates (_splineAt)
+        x2, y2 = wcs.wcs2pix(np.asarray(RADeg, dtype=np.float64), np.asarray(decDeg, dtype=np.float64))
+        x2, y2 = np.atleast_1d(x2), np.atleast_1d(y2)
+        inside = (x2.astype(np.int64) > 0) & (x2.astype(np.int64) < W) & (y2.astype(np.int64) > 0) & (y2.astype(np.int64) < H)
+        if inside.any():
+            yy = np.clip(y2[inside], 0.0, H - 1.0)
+            xx = np.clip(x2[inside], 0.0, W - 1.0)
+            for k, (mapLike, neg) in enumerate(_prefetch):
+                d = engine.to_dev(mapLike)
+                if useInterpolator:
+                    queued.append(('pre%d' % k, eng.spline_eval(d, np.stack([yy, xx], axis=1), negate=neg, to_host=False)))
+                else:
+                    queued.append(('pre%d' % k, _lookupDev(d, np.clip(np.round(yy).astype(np.int64), 0, H - 1),
+                                                           np.clip(np.round(xx).astype(np.int64), 0, W - 1)) * (-1.0 if neg else 1.0)))
+        pre = [(mapLike, neg) for mapLike, neg in _prefetch]
+    got = _fetchTogether(queued)
+    SNRs = got['SNR']
+    ringFlags = got['ring'] > 0 if 'ring' in got else np.zeros(len(sel), dtype=bool)
     keep = SNRs > threshold                                                       # :186
     if keep.sum() == 0:
         return []
-    flags = _lookup(flagMask, iyr, ixr)
+    flags = got['flags'].astype(_numpyDtype(flagMask)) if flagsOnDevice else np.asarray(flagMask)[iyr, ixr]
     tab = catalogs.Table()
     tab.setLazyNames(objIdent, longNames)                                          # :120-123 (built on first access)
     tab['RADeg'] = RADeg[keep]
@@ -161,7 +212,24 @@ def findObjects(filteredMapDict, threshold=3.0, minObjPix=3, rejectBorder=10, fi
             if np.logical_and((rDeg * 60) < ringFlagDistArcmin, rDeg > 0).sum() == 0:
                 rf[i] = False
     tab['flags'] = tab['flags'] + tab['ringFlag']
+    if pre:
+        tab._prefetched = {}
+        for k, (mapLike, neg) in enumerate(pre):
+            vals = np.zeros(len(sel), dtype=np.float64)
+            if inside.any():
+                vals[inside] = got['pre%d' % k]
+            tab._prefetched[(id(mapLike), bool(neg))] = (vals[keep], inside[keep], len(tab))
     return tab
+
+
+def _valuesAt(catalog, mapData, wcs, useInterpolator, negate=False):
+    """_splineAt at the catalogue's positions, or what findObjects already fetched for this map (``_prefetch``)."""
+    pre = getattr(catalog, '_prefetched', None)
+    if pre is not None:
+        hit = pre.get((id(mapData), bool(negate)), None)
+        if hit is not None and hit[2] == len(catalog):
+            return hit[0].copy(), hit[1]
+    return _splineAt(mapData, wcs, catalog['RADeg'], catalog['decDeg'], useInterpolator, negate=negate)
 
 
 def _splineAt(mapData, wcs, RADeg, decDeg, useInterpolator, negate=False):
@@ -192,7 +260,7 @@ def getSNRValues(catalog, SNMap, wcs, useInterpolator=True, invertMap=False, pre
     """S/N at catalogue positions, added in place as ``prefix+'SNR'`` (nemo/photometry.py:251-281)."""
     if len(catalog) == 0:
         return
-    vals, inside = _splineAt(SNMap, wcs, catalog['RADeg'], catalog['decDeg'], useInterpolator, negate=invertMap)
+    vals, inside = _valuesAt(catalog, SNMap, wcs, useInterpolator, negate=invertMap)
     col = np.zeros(len(catalog))
     col[inside] = vals[inside]
     catalog[prefix + 'SNR'] = col
@@ -241,7 +309,7 @@ def measureFluxes(catalog, filteredMapDict, diagnosticsDir, photFilteredMapDict=
         for k in keysToAdd:
             catalog[prefix + k] = np.zeros(n)
     for data, prefix in zip(mapDataList, prefixList):
-        mapValue, inside = _splineAt(data, wcs, catalog['RADeg'], catalog['decDeg'], useInterpolator)
+        mapValue, inside = _valuesAt(catalog, data, wcs, useInterpolator)
         with np.errstate(divide='ignore', invalid='ignore'):
             if mapUnits == 'yc':
                 catalog[prefix + 'y_c'] = mapValue / 1e-4

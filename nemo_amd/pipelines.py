@@ -130,7 +130,17 @@ def _detectAndMeasure(config, job, stream, invertMap, measureFluxes, photFilter,
             catalog = photometry.makeForcedPhotometryCatalog(filteredMapDict, config.parDict['forcedPhotometryCatalog'],
                                                              useInterpolator=config.parDict['useInterpolator'])
         else:
-            catalog = photometry.findObjects(filteredMapDict, threshold=config.parDict['thresholdSigma'],
+            # what measureFluxes / getSNRValues will read at the object positions: fetched with findObjects' own results
+            prefetch = []
+            if measureFluxes == True:
+                if photFilteredMapDict is not None:
+                    prefetch.append((photFilteredMapDict['SNMap'], False))
+                prefetch.append((filteredMapDict['data'], False))
+                if photFilteredMapDict is not None:
+                    prefetch.append((photFilteredMapDict['data'], False))
+            elif photFilter is not None:
+                prefetch.append((photFilteredMapDict['SNMap'], invertMap))
+            catalog = photometry.findObjects(filteredMapDict, threshold=config.parDict['thresholdSigma'], _prefetch=prefetch,
                                              minObjPix=config.parDict['minObjPix'],
                                              findCenterOfMass=config.parDict['findCenterOfMass'],
                                              flagRings=config.parDict['flagRings'],

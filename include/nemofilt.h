@@ -81,7 +81,8 @@ int nf_cross_power(int prec, const void* F_d, void* NP_d, int N, long long npix,
  *   nf_fft2_forward_half  = nf_fft2_forward of real input (NF_IN_REAL64 / NF_IN_REAL32), columns x <= W/2 only
  *   nf_fft2_inverse_half  = nf_fft2_inverse_fused with real output of half-stored input planes; the float32 filter and the
  *                           window tables stay full planes / full tables (the smoothed noise power of nemo/filters.py:580
- *                           is not exactly symmetric under (y,x) -> (-y,-x), so both filter values enter)
+ *                           is not exactly symmetric under (y,x) -> (-y,-x), so both filter values enter; the window tables
+ *                           must be even, wy[H-y] == wy[y], as enmap.apply_window's sinc(fftfreq) tables are)
  *   nf_cross_power_half, nf_build_filter_half = nf_cross_power / nf_build_filter reading half-stored F_d / S_d and writing
  *                           full planes */
 int nf_fft2_forward_half(nf_plan* plan, int prec, const void* in_d, int inType, void* out_d, int batch,

@@ -316,6 +316,40 @@ __device__ __forceinline__ void fft_stage(cpx<T>* __restrict__ buf, const nf::Li
                     for (int k = 0; k < R; ++k)
                         x[k] = fused_ops_herm<T>(a, G, x[k], lo + idx[k] * (unsigned)a.inElemStride, G.line0 + line, (int)idx[k]);
                 }
+                if (COLS && SPEC == 3) {
+                    // One half-stored plane (the matched filter's own case): the mode and its mirror mode - the conjugate -
+                    // differ only in their filter values, because the pixel-window tables are even (sinc of fftfreq), so
+                    // 0.5 (G[k] + conj G[-k]) = M[k] * win[k] * 0.5 (filt[k] + filt[-k]): one real factor per element,
+                    // formed in float64, all its operands fetched in one batch.
+                    const int col = G.line0 + line;
+                    const int colM = col == 0 ? 0 : a.realW - col;
+                    double f[R];
+                    if (a.mulF32 != nullptr) {
+                        const float* __restrict__ mul = a.mulF32 + (size_t)blockIdx.y * (size_t)a.mulBatchStride;
+                        float h1[R], h2[R];
+#pragma unroll
+                        for (int k = 0; k < R; ++k) {
+                            const unsigned rowM = idx[k] == 0u ? 0u : (unsigned)a.realH - idx[k];
+                            h1[k] = mul[lo + idx[k] * (unsigned)a.inElemStride];
+                            h2[k] = mul[(unsigned)colM * (unsigned)a.inLineStride + rowM * (unsigned)a.inElemStride];
+                        }
+#pragma unroll
+                        for (int k = 0; k < R; ++k) f[k] = 0.5 * ((double)h1[k] + (double)h2[k]);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < R; ++k) f[k] = 1.0;
+                    }
+                    if (a.winElem != nullptr) {
+                        const double wl = a.winLine[col];
+#pragma unroll
+                        for (int k = 0; k < R; ++k) f[k] *= a.winElem[idx[k]] * wl;
+                    }
+#pragma unroll
+                    for (int k = 0; k < R; ++k) {
+                        x[k].x = (T)((double)x[k].x * f[k]);
+                        x[k].y = (T)((double)x[k].y * f[k]);
+                    }
+                }
             } else {
 #pragma unroll
                 for (int k = 0; k < R; ++k) x[k] = lb[idx[k]];
@@ -703,7 +737,7 @@ __global__ void __launch_bounds__(NF_FFT_MAXTHREADS) k_fft_cols(nf::LineArgs<T> 
                 if (i < p.n) {
                     const unsigned off = (unsigned)(G.line0 + G.tl) * (unsigned)a.inLineStride + (unsigned)i * (unsigned)a.inElemStride;
                     v = load_elem<T, 0>(a, G.inP, off, 1.0, i);
-                    if (SPEC == 2) v = fused_ops_herm<T>(a, G, v, off, G.line0 + G.tl, i);
+                    if (SPEC >= 2) v = fused_ops_herm<T>(a, G, v, off, G.line0 + G.tl, i);
                     v = cmul(v, p.chirp[i]);
                 } else {
                     v.x = 0;
@@ -955,6 +989,9 @@ int launch_lines(const LineArgs<T>& a, bool cols, int batch, int threads, hipStr
         NF_ATTR3(k_fft_cols, 0);
         NF_ATTR3(k_fft_cols, 1);
         NF_ATTR3(k_fft_cols, 2);
+        NF_ATTR((k_fft_cols<T, 0, 3>));
+        NF_ATTR((k_fft_cols<T, 1, 3>));
+        NF_ATTR((k_fft_cols<T, 2, 3>));
 #undef NF_ATTR3
 #undef NF_ATTR
         attrSet[which] = true;
@@ -980,7 +1017,8 @@ int launch_lines(const LineArgs<T>& a, bool cols, int batch, int threads, hipStr
         return NF_ERR_SIZE;
     }
     dim3 grid = cols ? dim3(((a.nTiles + 7) / 8) * 8, batch) : dim3(nf_div_up(a.nLines, a.linesPerWG), batch);
-    const int spec = cols ? (a.mirror ? 1 : (a.fused ? 2 : 0)) : a.pairMode;
+    // 3: the fused load of ONE half-stored plane (batched form of 2)
+    const int spec = cols ? (a.mirror ? 1 : (a.fused ? ((a.herm && a.halfIn && a.nSum <= 1) ? 3 : 2) : 0)) : a.pairMode;
 #define NF_LAUNCH2(K, M, SP) hipLaunchKernelGGL((K<T, M, SP>), grid, dim3(threads), lds, stream, a)
 #define NF_LAUNCH(K, M)                          \
     do {                                         \
@@ -988,7 +1026,11 @@ int launch_lines(const LineArgs<T>& a, bool cols, int batch, int threads, hipStr
         else if (spec == 1) NF_LAUNCH2(K, M, 1); \
         else NF_LAUNCH2(K, M, 2);                \
     } while (0)
-    if (cols) {
+    if (cols && spec == 3) {
+        if (mode == 0) NF_LAUNCH2(k_fft_cols, 0, 3);
+        else if (mode == 1) NF_LAUNCH2(k_fft_cols, 1, 3);
+        else NF_LAUNCH2(k_fft_cols, 2, 3);
+    } else if (cols) {
         if (mode == 0) NF_LAUNCH(k_fft_cols, 0);
         else if (mode == 1) NF_LAUNCH(k_fft_cols, 1);
         else NF_LAUNCH(k_fft_cols, 2);

@@ -79,15 +79,18 @@ int nf_cross_power(int prec, const void* F_d, void* NP_d, int N, long long npix,
  * column pass of each transform then moves half of the bytes.  Values are those of the full-spectrum calls: the missing
  * modes are used through the symmetry, in the same arithmetic.
  *   nf_fft2_forward_half  = nf_fft2_forward of real input (NF_IN_REAL64 / NF_IN_REAL32), columns x <= W/2 only
- *   nf_fft2_inverse_half  = nf_fft2_inverse_fused with real output of half-stored input planes; the float32 filter and the
- *                           window tables stay full planes / full tables (the smoothed noise power of nemo/filters.py:580
- *                           is not exactly symmetric under (y,x) -> (-y,-x), so both filter values enter; the window tables
- *                           must be even, wy[H-y] == wy[y], as enmap.apply_window's sinc(fftfreq) tables are)
+ *   nf_symmetrise_filter  filtSym[k] = 0.5 (filt[k] + filt[-k]) in float64, half-stored: the smoothed noise power of
+ *                           nemo/filters.py:580 is not exactly symmetric under k -> -k, so neither is the filter, and
+ *                           real(ifft2(F * filt)) = ifft2(F * filtSym) for the spectrum F of a real map
+ *   nf_fft2_inverse_half  = nf_fft2_inverse_fused with real output of half-stored input planes and the symmetrised filter
+ *                           (NULL = none); the window tables must be even, wy[H-y] == wy[y], as enmap.apply_window's
+ *                           sinc(fftfreq) tables are
  *   nf_cross_power_half, nf_build_filter_half = nf_cross_power / nf_build_filter reading half-stored F_d / S_d and writing
  *                           full planes */
 int nf_fft2_forward_half(nf_plan* plan, int prec, const void* in_d, int inType, void* out_d, int batch,
                          const double* apodY_d, const double* apodX_d, int unitary, void* stream);
-int nf_fft2_inverse_half(nf_plan* plan, int prec, const void* in_d, const float* filt_d, int nSum, int filtPerBatch,
+int nf_symmetrise_filter(const float* filt_d, double* filtSym_d, int N, int H, int W, void* stream);
+int nf_fft2_inverse_half(nf_plan* plan, int prec, const void* in_d, const double* filtSym_d, int nSum, int filtPerBatch,
                          const double* wy_d, const double* wx_d, void* work_d, void* out_d, int outType, int batch,
                          int unitary, void* stream);
 int nf_cross_power_half(int prec, const void* F_d, void* NP_d, int N, int H, int W, void* stream);
@@ -138,7 +141,7 @@ int nf_scale_mask_dev(int vtype, const float* in_d, void* out_d, const double* s
  * with `numBins` weight-percentile bins per cell (quantiles: numBins host doubles = percentiles/100).
  * weights_d: the median weight map (float32/float64).  work_d: nf_noise_workspace_bytes() bytes of device scratch (for the
  * default estimator with one bin this includes the per-block sums and tail lists of the single-read evaluation, about
- * 2 bytes per pixel).
+ * 8 bytes per pixel).
  * estimator: 0 = 3-sigma clipped standard deviation (10 iterations, the default), 1 = RMSEstimator 'percentile'
  * (np.percentile(abs(values), 68.3), nemo/filters.py:459-460).  'biweight' needs astropy.stats and is not provided. */
 size_t nf_noise_workspace_bytes(int H, int W, int ny, int nx, int numBins);

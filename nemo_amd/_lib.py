@@ -41,6 +41,7 @@ SIGNATURES = {
     'nf_fft2_forward_half': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     'nf_fft2_inverse_half': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_int, c_int, c_int, c_void_p]),
+    'nf_symmetrise_filter': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'nf_cross_power_half': (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'nf_build_filter_half': (c_int, [c_int, c_int, c_void_p, c_void_p, ctypes.POINTER(c_double), c_void_p, c_int, c_int, c_int,
                                      c_void_p]),

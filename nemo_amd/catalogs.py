@@ -280,42 +280,35 @@ def _unitVectors(RADeg, decDeg):
 
 def _pairsWithin(RA1, dec1, RA2, dec2, radiusDeg, inclusive=False):
     """All (i, j) with calcAngSepDeg(row i of set 1, row j of set 2) < radiusDeg (<= if inclusive), sorted by (i, j).
-    Candidates from a k-d tree (chord length, 0.1 % margin), decided by the exact great-circle formula."""
-    from scipy.spatial import cKDTree
+    Candidates by a sweep along z = sin(dec) (two unit vectors closer than a chord differ by less than it in every
+    coordinate; set 2 sorted by z, one searchsorted window per row of set 1), cut by chord length with a 0.1 % margin, then
+    decided by the exact great-circle formula where the chord is not conclusive."""
     if len(RA1) == 0 or len(RA2) == 0:
         return np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64)
-    chord = 2.0 * np.sin(np.radians(radiusDeg) / 2.0) * 1.001 + 1e-12
+    lim = 2.0 * np.sin(np.radians(radiusDeg) / 2.0)
+    chord = lim * 1.001 + 1e-12
     sameSets = len(RA1) == len(RA2) and np.array_equal(np.asarray(RA1), np.asarray(RA2)) and \
         np.array_equal(np.asarray(dec1), np.asarray(dec2))
-    t1 = cKDTree(_unitVectors(RA1, dec1))
-    if sameSets:
-        # a set against itself: unordered pairs from one tree (zero distances included), mirrored, plus every row with itself
-        pairs = t1.query_pairs(chord, output_type='ndarray').astype(np.int64)
-        selfIdx = np.arange(len(RA1), dtype=np.int64)
-        i = np.concatenate([selfIdx, pairs[:, 0], pairs[:, 1]])
-        j = np.concatenate([selfIdx, pairs[:, 1], pairs[:, 0]])
-    else:
-        t2 = cKDTree(_unitVectors(RA2, dec2))
-        sp = t1.sparse_distance_matrix(t2, chord, output_type='coo_matrix')
-        i, j = sp.row.astype(np.int64), sp.col.astype(np.int64)
-        # zero-distance pairs are dropped by the sparse format: identical positions are added back
-        zi = t1.query_ball_tree(t2, 1e-15)
-        zp = [(a, b) for a, lst in enumerate(zi) for b in lst]
-        if len(zp) > 0:
-            zp = np.array(zp, dtype=np.int64)
-            i = np.concatenate([i, zp[:, 0]])
-            j = np.concatenate([j, zp[:, 1]])
-    if len(i) > 0:
-        key = i * np.int64(len(RA2)) + j
-        key = np.sort(key) if sameSets else np.unique(key)      # (i, j) pairs of the self-match are already distinct
-        i, j = key // np.int64(len(RA2)), key % np.int64(len(RA2))
-    # Decision by the exact great-circle formula (what the reference evaluates) - but only for the pairs whose chord is
-    # within 1e-9 (relative) of the limit; the chord of two unit vectors is good to ~1e-12 of it, so the others are decided.
     u1 = _unitVectors(RA1, dec1)
     u2 = u1 if sameSets else _unitVectors(RA2, dec2)
+    n2 = np.int64(len(u2))
+    order = np.argsort(u2[:, 2], kind='stable')
+    zs = u2[order, 2]
+    lo = np.searchsorted(zs, u1[:, 2] - chord, side='left')
+    hi = np.searchsorted(zs, u1[:, 2] + chord, side='right')
+    cnt = hi - lo
+    i = np.repeat(np.arange(len(u1), dtype=np.int64), cnt)
+    k = np.arange(int(cnt.sum()), dtype=np.int64) + np.repeat(lo - (np.cumsum(cnt) - cnt), cnt)
+    j = order[k].astype(np.int64)
     d = u1[i] - u2[j]
     chord2 = np.einsum('ij,ij->i', d, d)
-    lim = 2.0 * np.sin(np.radians(radiusDeg) / 2.0)
+    cand = chord2 <= chord * chord
+    key = np.sort(i[cand] * n2 + j[cand])
+    i, j = key // n2, key % n2
+    # Decision by the exact great-circle formula (what the reference evaluates) - but only for the pairs whose chord is
+    # within 1e-9 (relative) of the limit; the chord of two unit vectors is good to ~1e-12 of it, so the others are decided.
+    d = u1[i] - u2[j]
+    chord2 = np.einsum('ij,ij->i', d, d)
     ok = chord2 < (lim * (1.0 - 1e-9)) ** 2
     near = np.flatnonzero(~ok & (chord2 <= (lim * (1.0 + 1e-9)) ** 2))
     if len(near) > 0:

@@ -234,21 +234,30 @@ int nf_fft2_inverse_fused(nf_plan* p, int prec, const void* in, const float* fil
     return p->pd.inverse(in, work, out, outType, batch, unitary ? 1 : 0, scale, S(stream), filt, nSum, fbs, wy, wx);
 }
 
-int nf_fft2_inverse_half(nf_plan* p, int prec, const void* in, const float* filt, int nSum, int filtPerBatch,
+int nf_fft2_inverse_half(nf_plan* p, int prec, const void* in, const double* filtSym, int nSum, int filtPerBatch,
                          const double* wy, const double* wx, void* work, void* out, int outType, int batch, int unitary,
                          void* stream) {
     if (!p || !in || !work || !out || batch < 1 || (outType != NF_IN_REAL64 && outType != NF_IN_REAL32) || nSum < 1 ||
-        (nSum > 1 && (!filt || batch != 1)) || ((wy == nullptr) != (wx == nullptr))) {
+        (nSum > 1 && (!filtSym || batch != 1)) || ((wy == nullptr) != (wx == nullptr))) {
         nf_set_error("nf_fft2_inverse_half: bad arguments (the output must be real)");
         return NF_ERR_ARG;
     }
     int rc = ensure_prec(p, prec);
     if (rc) return rc;
     double scale = std::sqrt((double)p->H * (double)p->W);
-    const long long fbs = (filt && filtPerBatch) ? (long long)p->H * p->W : 0;
+    const long long fbs = (filtSym && filtPerBatch) ? (long long)p->H * p->W : 0;
     if (prec == NF_F32)
-        return p->pf.inverse(in, work, out, outType, batch, unitary ? 1 : 0, scale, S(stream), filt, nSum, fbs, wy, wx, 1);
-    return p->pd.inverse(in, work, out, outType, batch, unitary ? 1 : 0, scale, S(stream), filt, nSum, fbs, wy, wx, 1);
+        return p->pf.inverse_half(in, work, out, outType, batch, unitary ? 1 : 0, scale, S(stream), filtSym, nSum, fbs, wy, wx);
+    return p->pd.inverse_half(in, work, out, outType, batch, unitary ? 1 : 0, scale, S(stream), filtSym, nSum, fbs, wy, wx);
+}
+
+int nf_symmetrise_filter(const float* filt, double* filtSym, int N, int H, int W, void* stream) {
+    if (!filt || !filtSym || N < 1 || H < 1 || W < 1) {
+        nf_set_error("nf_symmetrise_filter: bad arguments");
+        return NF_ERR_ARG;
+    }
+    nf::ProfScope ps(nf::PT_BUILD_FILTER, S(stream), (double)N * H * W * (4.0 + 4.0));
+    return nf::symmetrise_filter(filt, filtSym, N, H, W, S(stream));
 }
 
 int nf_cross_power(int prec, const void* F, void* NP, int N, long long npix, void* stream) {

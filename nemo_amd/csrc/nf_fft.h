@@ -47,6 +47,7 @@ struct LineArgs {
     // pointwise work fused into the columns kernel's load (inverse transforms): see fused_ops() in nf_fft.hip
     int fused;               // any of the following present
     const float* mulF32;     // float32 filter, indexed like the input plane
+    const double* mulSym;    // halfIn: the symmetrised filter 0.5 (filt[k] + filt[-k]) in float64, half-stored like the input (instead of mulF32)
     long long mulBatchStride;  // filter plane offset per batch entry (elements; 0 = the same filter for every batch entry)
     int nSum;                // planes summed as sum_i in_i * mul_i (1 = none)
     long long sumStride;     // plane pitch of in / mul for the sum (elements)
@@ -78,7 +79,11 @@ struct Plan2D {
                 int scaleDiv, double scale, hipStream_t stream, int half = 0);
     int inverse(const void* in, void* work, void* out, int outType, int batch, int scaleDiv, double scale,
                 hipStream_t stream, const float* filt = nullptr, int nSum = 1, long long filtBatchStride = 0,
-                const double* winY = nullptr, const double* winX = nullptr, int halfIn = 0);
+                const double* winY = nullptr, const double* winX = nullptr);
+    // inverse of half-stored spectra (real output): filtSym = symmetrised float64 filter planes, half-stored (or NULL)
+    int inverse_half(const void* in, void* work, void* out, int outType, int batch, int scaleDiv, double scale,
+                     hipStream_t stream, const double* filtSym, int nSum, long long filtBatchStride, const double* winY,
+                     const double* winX);
 };
 
 }  // namespace nf

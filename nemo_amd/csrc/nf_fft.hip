@@ -243,22 +243,39 @@ __device__ __forceinline__ cpx<T> fused_ops(const nf::LineArgs<T>& a, const Geo&
 // load and the same pointwise factors, then u = 0.5 * (u1 + conj u2).
 template <typename T>
 __device__ __forceinline__ cpx<T> fused_ops_herm(const nf::LineArgs<T>& a, const Geo& G, cpx<T> v, unsigned off, int col, int row) {
+    if (a.herm && a.halfIn) {
+        // Half-stored spectra of real maps: the mirror mode is the conjugate of the stored one, the window tables are even,
+        // so 0.5 (G[k] + conj G[-k]) = win[k] * sum_i M_i[k] * filtSym_i[k] with the symmetrised filter - one real factor
+        // per plane, formed in float64.
+        double re = 0.0, im = 0.0;
+        const double* __restrict__ ms = a.mulSym ? a.mulSym + (size_t)blockIdx.y * (size_t)a.mulBatchStride : nullptr;
+        const int np_ = a.nSum > 1 ? a.nSum : 1;
+        for (int pl = 0; pl < np_; ++pl) {
+            cpx<T> f = v;
+            if (pl > 0) {
+                f = ((const cpx<T>*)G.inP)[(size_t)pl * (size_t)a.sumStride + off];
+                f.y *= (T)a.conjInSign;
+            }
+            const double g = ms ? ms[(size_t)pl * (size_t)a.sumStride + off] : 1.0;
+            re += (double)f.x * g;
+            im += (double)f.y * g;
+        }
+        if (a.winElem != nullptr) {
+            const double win = a.winElem[row] * a.winLine[col];
+            re *= win;
+            im *= win;
+        }
+        cpx<T> h;
+        h.x = (T)re;
+        h.y = (T)im;
+        return h;
+    }
     cpx<T> u1 = fused_ops<T>(a, G, v, off, (T)1, off, col, row);
     if (!a.herm) return u1;
     const int rowM = row == 0 ? 0 : a.realH - row;
     const int colM = col == 0 ? 0 : a.realW - col;
     const unsigned offM = (unsigned)colM * (unsigned)a.inLineStride + (unsigned)rowM * (unsigned)a.inElemStride;
-    cpx<T> u2;
-    if (a.halfIn) {
-        // spectrum of a real map of which only the columns c <= W/2 are stored: the mirror mode is the conjugate of this
-        // one, only its filter value and window factor sit elsewhere
-        cpx<T> vm;
-        vm.x = v.x;
-        vm.y = -v.y;
-        u2 = fused_ops<T>(a, G, vm, off, (T)-1, offM, colM, rowM);
-    } else {
-        u2 = fused_ops<T>(a, G, load_elem<T, 0>(a, G.inP, offM, 1.0, rowM), offM, (T)1, offM, colM, rowM);
-    }
+    const cpx<T> u2 = fused_ops<T>(a, G, load_elem<T, 0>(a, G.inP, offM, 1.0, rowM), offM, (T)1, offM, colM, rowM);
     cpx<T> h;
     h.x = (T)0.5 * (u1.x + u2.x);
     h.y = (T)0.5 * (u1.y - u2.y);
@@ -317,24 +334,14 @@ __device__ __forceinline__ void fft_stage(cpx<T>* __restrict__ buf, const nf::Li
                         x[k] = fused_ops_herm<T>(a, G, x[k], lo + idx[k] * (unsigned)a.inElemStride, G.line0 + line, (int)idx[k]);
                 }
                 if (COLS && SPEC == 3) {
-                    // One half-stored plane (the matched filter's own case): the mode and its mirror mode - the conjugate -
-                    // differ only in their filter values, because the pixel-window tables are even (sinc of fftfreq), so
-                    // 0.5 (G[k] + conj G[-k]) = M[k] * win[k] * 0.5 (filt[k] + filt[-k]): one real factor per element,
-                    // formed in float64, all its operands fetched in one batch.
+                    // fused_ops_herm for ONE half-stored plane (the matched filter's own case): the real factor
+                    // filtSym[k] * win[k] per element, its operands fetched in one batch like the data
                     const int col = G.line0 + line;
-                    const int colM = col == 0 ? 0 : a.realW - col;
                     double f[R];
-                    if (a.mulF32 != nullptr) {
-                        const float* __restrict__ mul = a.mulF32 + (size_t)blockIdx.y * (size_t)a.mulBatchStride;
-                        float h1[R], h2[R];
+                    if (a.mulSym != nullptr) {
+                        const double* __restrict__ ms = a.mulSym + (size_t)blockIdx.y * (size_t)a.mulBatchStride;
 #pragma unroll
-                        for (int k = 0; k < R; ++k) {
-                            const unsigned rowM = idx[k] == 0u ? 0u : (unsigned)a.realH - idx[k];
-                            h1[k] = mul[lo + idx[k] * (unsigned)a.inElemStride];
-                            h2[k] = mul[(unsigned)colM * (unsigned)a.inLineStride + rowM * (unsigned)a.inElemStride];
-                        }
-#pragma unroll
-                        for (int k = 0; k < R; ++k) f[k] = 0.5 * ((double)h1[k] + (double)h2[k]);
+                        for (int k = 0; k < R; ++k) f[k] = ms[lo + idx[k] * (unsigned)a.inElemStride];
                     } else {
 #pragma unroll
                         for (int k = 0; k < R; ++k) f[k] = 1.0;
@@ -1002,12 +1009,11 @@ int launch_lines(const LineArgs<T>& a, bool cols, int batch, int threads, hipStr
     const int tag = sizeof(T) == 8 ? (cols ? PT_FFT_COLS_F64 : PT_FFT_ROWS_F64) : (cols ? PT_FFT_COLS_F32 : PT_FFT_ROWS_F32);
     // algorithmic bytes per line element: pair lines carry two real rows (or two half-rows); the mirrored store writes the
     // element twice; the symmetrised load reads it (and its filter value) twice
-    double lineIn = cols ? ((a.nSum > 1 ? a.nSum : 1) * (inB + (a.mulF32 ? 4.0 : 0.0))) : inB, lineOut = outB;
+    double lineIn = cols ? ((a.nSum > 1 ? a.nSum : 1) * (inB + (a.mulF32 ? 4.0 : 0.0) + (a.mulSym ? 8.0 : 0.0))) : inB, lineOut = outB;
     if (!cols && a.pairMode == 1) lineIn *= 2.0;
     if (!cols && a.pairMode == 2) lineOut *= 2.0;
     if (cols && a.mirror) lineOut *= 2.0;
     if (cols && a.herm && !a.halfIn) lineIn *= 2.0;
-    if (cols && a.herm && a.halfIn && a.mulF32) lineIn += (a.nSum > 1 ? a.nSum : 1) * 4.0;   // the mirror mode's filter value
     ProfScope ps(tag, stream, npixTotal * (lineIn + lineOut));
     int mode = a.plan.bluestein ? 2 : 0;
     for (int s = 0; s < a.plan.nst; ++s)
@@ -1181,7 +1187,7 @@ int Plan2D<T>::forward(const void* in, int inType, void* out, int batch, const d
 template <typename T>
 int Plan2D<T>::inverse(const void* in, void* work, void* out, int outType, int batch, int scaleDiv, double scale,
                        hipStream_t stream, const float* filt, int nSum, long long filtBatchStride, const double* winY,
-                       const double* winX, int halfIn) {
+                       const double* winX) {
     LineArgs<T> c = col_args<T>(*this, in, work);
     c.conjInSign = -1.0;  // conj(FFT(conj x)): the conj between the two passes cancels, so only the ends matter
     c.mulF32 = filt;
@@ -1194,16 +1200,11 @@ int Plan2D<T>::inverse(const void* in, void* work, void* out, int outType, int b
     LineArgs<T> a = row_args<T>(*this, work, out, 0, outType);
     a.conjOutSign = -1.0;
     if (scaleDiv) a.scale = 1.0 / scale;
-    if (halfIn && outType == 0) {
-        nf_set_error("a half-stored spectrum has a real inverse transform: ask for real output");
-        return NF_ERR_ARG;
-    }
-    if (outType != 0 && (useReal || halfIn)) {
+    if (outType != 0 && useReal) {
         // only the real part is wanted: transform the symmetrised spectrum - half of the columns, two rows per line.
         // The half plane left in `work` is conj(column-inverse), which is Hermitian along x like the column-inverse
         // itself; packed as Z = V1 + i V2 its forward row transform is x1 + i x2 with no conjugation at either end.
         c.herm = 1;
-        c.halfIn = halfIn ? 1 : 0;
         c.fused = 1;
         c.nLines = W / 2 + 1;
         c.nTiles = nf_div_up(c.nLines, colsPerWG);
@@ -1211,6 +1212,37 @@ int Plan2D<T>::inverse(const void* in, void* work, void* out, int outType, int b
         a.nLines = (H + 1) / 2;
         a.conjOutSign = 1.0;
     }
+    int rc = launch_lines<T>(c, true, batch, threadsCol, stream);
+    if (rc) return rc;
+    return launch_lines<T>(a, false, batch, threadsRow, stream);
+}
+
+template <typename T>
+int Plan2D<T>::inverse_half(const void* in, void* work, void* out, int outType, int batch, int scaleDiv, double scale,
+                            hipStream_t stream, const double* filtSym, int nSum, long long filtBatchStride, const double* winY,
+                            const double* winX) {
+    if (outType == 0) {
+        nf_set_error("a half-stored spectrum has a real inverse transform: ask for real output");
+        return NF_ERR_ARG;
+    }
+    LineArgs<T> c = col_args<T>(*this, in, work);
+    c.conjInSign = -1.0;
+    c.mulSym = filtSym;
+    c.mulBatchStride = filtBatchStride;
+    c.nSum = nSum < 1 ? 1 : nSum;
+    c.sumStride = (long long)H * W;
+    c.winLine = winX;
+    c.winElem = winY;
+    c.herm = 1;
+    c.halfIn = 1;
+    c.fused = 1;
+    c.nLines = W / 2 + 1;
+    c.nTiles = nf_div_up(c.nLines, colsPerWG);
+    LineArgs<T> a = row_args<T>(*this, work, out, 0, outType);
+    if (scaleDiv) a.scale = 1.0 / scale;
+    a.pairMode = 2;
+    a.nLines = (H + 1) / 2;
+    a.conjOutSign = 1.0;
     int rc = launch_lines<T>(c, true, batch, threadsCol, stream);
     if (rc) return rc;
     return launch_lines<T>(a, false, batch, threadsRow, stream);

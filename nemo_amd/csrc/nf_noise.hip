@@ -627,8 +627,6 @@ struct BlockWs {
     double* rec;                   // [maxBy][maxBx][NF_BREC]
     double* tails;
     long long tailCap;             // room in `tails`
-    int* tailCol;                  // [maxBx] and
-    long long* tailRow;            // [maxBy]: tail list offset tables (see tail_cap)
     int maxBy, maxBx;
 };
 
@@ -670,8 +668,6 @@ __device__ __forceinline__ int find_break(const int* __restrict__ b, int n, int 
     }
     return lo;
 }
-
-__device__ __forceinline__ int tail_cap(int h, int w);
 
 #define NF_BRK_MAXCELLS 1023
 #define NF_BRK_MAXOUT 4096
@@ -810,30 +806,6 @@ __global__ void __launch_bounds__(256) k_noise_breaks(NoiseGrid g, int H, int W,
         ws.wX0[k] = find_break(bX, nBx, max(g.xEdges[k] - g.overlap, 0));
         ws.wX1[k] = find_break(bX, nBx, min(g.xEdges[k + 1] + g.overlap, W));
     }
-    // tail list offsets (see tail_cap): tailCol[c] = sum over c' < c of ceil(w_c' / 3); tailRow[r] = sum over r' < r of the
-    // rows' totals h_r' * tailCol[nbx] + 18 nbx
-    const int nby = nBy - 1, nbx = nBx - 1;
-    {
-        const int per = (nbx + 255) / 256, c0 = threadIdx.x * per, c1 = min(c0 + per, nbx);
-        int mine = 0;
-        for (int c = c0; c < c1; ++c) mine += (bX[c + 1] - bX[c] + 2) / 3;
-        int total;
-        int pos = block_excl_scan256(mine, wsum, &total);
-        for (int c = c0; c < c1; ++c) {
-            ws.tailCol[c] = pos;
-            pos += (bX[c + 1] - bX[c] + 2) / 3;
-        }
-        const int rowUnit = total;      // per pixel row of a block row
-        const int perR = (nby + 255) / 256, r0 = threadIdx.x * perR, r1 = min(r0 + perR, nby);
-        int mineR = 0;
-        for (int r = r0; r < r1; ++r) mineR += (bY[r + 1] - bY[r]) * rowUnit + 18 * nbx;
-        int totalR;
-        long long posR = block_excl_scan256(mineR, wsum, &totalR);   // below H * W / 3 + ...: fits an int
-        for (int r = r0; r < r1; ++r) {
-            ws.tailRow[r] = posR;
-            posR += (bY[r + 1] - bY[r]) * rowUnit + 18 * nbx;
-        }
-    }
 }
 
 // Workgroup -> block: workgroups go to the 8 XCDs round robin, so XCD x takes the block rows x, x + 8, ... and walks each
@@ -849,10 +821,9 @@ __device__ __forceinline__ bool block_of_workgroup(const BlockWs& ws, int* by, i
 }
 static inline int blocks_grid(const BlockWs& ws) { return ((ws.maxBy - 1 + 7) / 8) * (ws.maxBx - 1) * 8; }
 
-// Tail list room of block (r, c): h_r * ceil(w_c / 3) + 18 values (at least a third of the block, and 18 for the
-// smallest: the rule for T below lets fewer than n / (2.5 shrink)^2 <= max(18, n / 3 + 8) of n valid pixels reach T).
-// Separable, so the list offsets are two short prefix tables (k_noise_breaks): tailRow[r] + h_r * tailCol[c] + 18 c.
-__device__ __forceinline__ int tail_cap(int h, int w) { return h * ((w + 2) / 3) + 18; }
+// Tail list room of block (r, c): the whole block (a block under a bright object can be all tails), so the lists tile a
+// buffer of one value per pixel: offset = pixels of the block rows above + pixels of this row's blocks to the left.
+__device__ __forceinline__ int tail_cap(int h, int w) { return h * w; }
 
 __device__ __forceinline__ double wave_total(double v) {
     v = wave_sum_lane63(v);
@@ -1024,7 +995,8 @@ __global__ void __launch_bounds__(64) k_noise_block_core(const VT* __restrict__ 
     const int dr = 64 / bw, dx = 64 - dr * bw;
     const unsigned base = (unsigned)y0 * (unsigned)W + (unsigned)x0;
     const int cap = tail_cap(bh, bw);
-    const long long tailOff = ws.tailRow[by] + (long long)bh * ws.tailCol[bx] + 18LL * bx;
+    const long long tailOff = (long long)(y0 - ws.breakY[0]) * (ws.breakX[ws.hdr[1] - 1] - ws.breakX[0]) +
+                              (long long)(x0 - ws.breakX[0]) * bh;
     const bool room = tailOff + cap <= ws.tailCap;
     double* __restrict__ tp = ws.tails + tailOff;
     double s1 = 0.0, s2 = 0.0, nc = 0.0;
@@ -1072,7 +1044,7 @@ __global__ void __launch_bounds__(64) k_noise_block_core(const VT* __restrict__ 
     s2 = wave_total(s2);
     nc = wave_total(nc);
     if (!room || total > cap) {
-        // more tails than the list holds (a block far noisier than its windows): it is scanned directly in every
+        // no list room (cannot happen with a workspace of the documented size): the block is scanned directly in every
         // iteration (thr >= NaN is false)
         T = __longlong_as_double(0x7ff8000000000000LL);
         total = 0;
@@ -1092,7 +1064,7 @@ __global__ void __launch_bounds__(64) k_noise_block_core(const VT* __restrict__ 
 
 // ---- k_noise_windows: ONE WAVEFRONT per cell (no barriers; reductions on the vector ALU) ----
 #define NF_WIN_MAXBLK 64      // blocks of a window whose records are staged in LDS (more: everything from global memory)
-#define NF_WIN_MAXTAIL 1024   // tail values of a window staged in LDS
+#define NF_WIN_MAXTAIL 2048   // tail values of a window staged in LDS
 
 // one block scanned pixel by pixel (its T exceeds the threshold of this iteration): flat over the block, 4 loads per lane
 // in flight
@@ -1552,7 +1524,9 @@ int median_stack(int rtype, const void* in, void* out, int N, long long n, hipSt
 static size_t align8(size_t b) { return (b + 7) & ~(size_t)7; }
 // sum of tail_cap over any block decomposition of an H x W map with at most maxBy x maxBx blocks
 static size_t noise_tail_cap(int H, int W, int maxBy, int maxBx) {
-    return (size_t)H * ((size_t)W / 3 + maxBx) + 18 * (size_t)maxBy * maxBx + 8;
+    (void)maxBy;
+    (void)maxBx;
+    return (size_t)H * (size_t)W + 8;
 }
 
 // cell records, then (one-bin clipped-RMS mode) the block tables: see BlockWs
@@ -1560,7 +1534,7 @@ size_t noise_workspace_bytes(const NoiseGrid& g, int H, int W) {
     size_t cells = (size_t)g.ny * g.nx * cell_stride(g.numBins) * sizeof(double);
     if (g.numBins != 1) return cells;
     const size_t maxBy = blocks_max_breaks(g.ny, H), maxBx = blocks_max_breaks(g.nx, W);
-    size_t ints = align8((8 + maxBy + 2 * maxBx + 2 * (size_t)g.ny + 2 * (size_t)g.nx) * sizeof(int)) + maxBy * sizeof(long long);
+    size_t ints = align8((8 + maxBy + maxBx + 2 * (size_t)g.ny + 2 * (size_t)g.nx) * sizeof(int));
     size_t recs = maxBy * maxBx * NF_BREC * sizeof(double);
     size_t tails = noise_tail_cap(H, W, (int)maxBy, (int)maxBx) * sizeof(double);
     return cells + ints + recs + tails;
@@ -1595,10 +1569,7 @@ int noise_map(int vtype, const void* filtered, const void* weights, int wtype, f
         ws.wY1 = ws.wY0 + g.ny;
         ws.wX0 = ws.wY1 + g.ny;
         ws.wX1 = ws.wX0 + g.nx;
-        ws.tailCol = ws.wX1 + g.nx;
-        p += align8((8 + (size_t)ws.maxBy + 2 * (size_t)ws.maxBx + 2 * (size_t)g.ny + 2 * (size_t)g.nx) * sizeof(int));
-        ws.tailRow = (long long*)p;
-        p += (size_t)ws.maxBy * sizeof(long long);
+        p += align8((8 + (size_t)ws.maxBy + (size_t)ws.maxBx + 2 * (size_t)g.ny + 2 * (size_t)g.nx) * sizeof(int));
         ws.rec = (double*)p;
         ws.tails = ws.rec + (size_t)ws.maxBy * ws.maxBx * NF_BREC;
         if ((long long)H * W >= (1LL << 31)) {

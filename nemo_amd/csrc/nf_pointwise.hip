@@ -31,6 +31,27 @@ __device__ __forceinline__ long long half_src(long long p, int H, int W) {
     return (long long)ym * W + ((unsigned)W - x);
 }
 
+// filtSym[n][y][x] = 0.5 (filt[n][y][x] + filt[n][-y][-x]) in float64 for the columns x <= W/2 (plane pitch W; the other
+// columns are not written): real(ifft2(F * filt)) of the spectrum F of a real map is ifft2(F * filtSym).
+__global__ void k_symmetrise_filter(const float* __restrict__ filt, double* __restrict__ sym, int H, int W) {
+    const int hw = W / 2 + 1;
+    const long long plane = (long long)blockIdx.z * H * W;
+    for (int y = blockIdx.y; y < H; y += gridDim.y) {
+        const int ym = y == 0 ? 0 : H - y;
+        for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < hw; x += gridDim.x * blockDim.x) {
+            const int xm = x == 0 ? 0 : W - x;
+            sym[plane + (long long)y * W + x] = 0.5 * ((double)filt[plane + (long long)y * W + x] + (double)filt[plane + (long long)ym * W + xm]);
+        }
+    }
+}
+
+int symmetrise_filter(const float* filt, double* filtSym, int N, int H, int W, hipStream_t s) {
+    dim3 g(nf_div_up(W / 2 + 1, 256), H < 4096 ? H : 4096, N);
+    hipLaunchKernelGGL(k_symmetrise_filter, g, dim3(256), 0, s, filt, filtSym, H, W);
+    NF_CHECK_LAUNCH("k_symmetrise_filter");
+    return NF_OK;
+}
+
 template <typename T, bool HALF>
 __global__ void k_cross_power(const cpx<T>* __restrict__ F, T* __restrict__ NP, int N, long long npix, int H, int W) {
     // NP layout [N][N][npix]; only j >= i computed, mirrored (the product is commutative bit for bit)

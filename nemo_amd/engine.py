@@ -213,8 +213,11 @@ class TileEngine(object):
         perBatch = 0
         if filt is not None:
             f3 = filt.reshape(-1, self.H, self.W)
-            if f3.dtype != t.float32 or not f3.is_contiguous():
-                raise NemoFiltError("the fused filter must be a contiguous float32 tensor")
+            if half and f3.dtype == t.float32:
+                f3 = self.symmetrise_filter(f3)          # the half-spectrum transform takes 0.5 (filt[k] + filt[-k])
+            want = t.float64 if half else t.float32
+            if f3.dtype != want or not f3.is_contiguous():
+                raise NemoFiltError("the fused filter must be a contiguous float32 tensor (float64 if already symmetrised)")
             if f3.shape[0] not in (1, N) or (sum and f3.shape[0] != N):
                 raise NemoFiltError("filter cube and Fourier cube have different numbers of planes")
             perBatch = 1 if (not sum and f3.shape[0] == N and N > 1) else 0
@@ -238,6 +241,16 @@ class TileEngine(object):
         return res.reshape(shape)
 
     # ---- Fourier-domain pointwise --------------------------------------------------------------------------
+    def symmetrise_filter(self, filt):
+        """0.5 (filt[k] + filt[-k]) as float64, half-stored (nf_symmetrise_filter): what ifft(half=True) multiplies by."""
+        t = self.t
+        f3 = filt.reshape(-1, self.H, self.W)
+        if f3.dtype != t.float32 or not f3.is_contiguous():
+            raise NemoFiltError("symmetrise_filter takes a contiguous float32 filter")
+        sym = t.empty(f3.shape, dtype=t.float64, device=self.dev)
+        check(self.lib.nf_symmetrise_filter(ptr(f3), ptr(sym), f3.shape[0], self.H, self.W, stream_ptr()), "nf_symmetrise_filter")
+        return sym.reshape(filt.shape)
+
     def cross_power(self, F, half=False):
         t = self.t
         N = F.shape[0]

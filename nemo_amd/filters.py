@@ -405,7 +405,7 @@ class MatchedFilter(MapFilter):
                 else:
                     maxValue, maxIndex = eng.map_max(filteredSignal)              # :661
                     totalSignal = np.float32(maxValue)
-                    planes = eng.ifft(fSignalMaps, out='f32', filt=self._dFilt, window=1.0, half=True)       # :662-667
+                    planes = eng.ifft(fSignalMaps, out='f32', filt=self._filtFor(True), window=1.0, half=True)       # :662-667
                     vals = planes.reshape(N, -1)[:, maxIndex].cpu().numpy()
                     for i, mapDict in enumerate(self.unfilteredMapsDictList):
                         self.fRelWeights[mapDict['obsFreqGHz']] = np.float32(vals[i]) / totalSignal
@@ -495,6 +495,16 @@ class MatchedFilter(MapFilter):
         raise NotImplementedError("reshapeFilter (nemo/filters.py:793-817) is only reached when map and filter shapes "
                                   "differ; not part of this build yet")
 
+    def _filtFor(self, half):
+        """The filter as the inverse transform wants it: float32 planes, or - for half-stored spectra - their symmetrised
+        float64 form 0.5 (filt[k] + filt[-k]), made once per filter."""
+        if not half:
+            return self._dFilt
+        cached = getattr(self, '_dFiltSymOf', None)
+        if cached is None or cached[0] is not self._dFilt:
+            self._dFiltSymOf = (self._dFilt, self.engine.symmetrise_filter(self._dFilt))
+        return self._dFiltSymOf[1]
+
     def _applyFilterDevice(self, cube, scale=True, window=None, half=False):
         """Device form of applyFilter: complex (Fourier) or real [N,H,W] tensor in, float32 [H,W] map out (``half``: the
         complex cube holds half-stored spectra of real maps, as eng.fft(half=True) returns them); with
@@ -510,14 +520,14 @@ class MatchedFilter(MapFilter):
         else:
             fMaps = eng.fft(cube, apod=True, half=True)                           # :845
             half = True
-        out = eng.ifft(fMaps.reshape(-1, *self.shape), out='f32', unitary=False, filt=self._dFilt, sum=True,
+        out = eng.ifft(fMaps.reshape(-1, *self.shape), out='f32', unitary=False, filt=self._filtFor(half), sum=True,
                        window=window, half=half)                                 # :847  K7 + K3
         if 'bckSub' in self.params.keys() and 'bckSubScaleArcmin' in self.params.keys() and self.params['bckSub'] == True:
             out = maps.subtractBackground(out, self.wcs, smoothScaleDeg=self.params['bckSubScaleArcmin'] / 60.)   # :850-851
         if scale:
             if isinstance(self.signalNorm, np.float64):
                 out = out.to(t.float64) * float(self.signalNorm)
-            else:
+            elif float(np.float32(self.signalNorm)) != 1.0:       # x * 1.0 is x (the normalisation is still being measured)
                 out = out * float(np.float32(self.signalNorm))
         return out
 

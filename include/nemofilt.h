@@ -202,6 +202,15 @@ int nf_object_stats(int vtype, const void* sn_d, int negate, const int* labels_d
 #define NF_MAP_MAX_DOUBLES (4 + 2 * 2048)
 int nf_map_max(int vtype, const void* map_d, long long n, double* out_d, void* stream);
 
+/* catalogs.makeOptimalCatalog, method 'ref-forced' (nemo/catalogs.py:319-362): cross match of the stacked per-scale
+ * catalogues with themselves.  unit_d [n][3] unit vectors of (RA, dec), snr_d [n].  Partners = rows closer than radiusDeg
+ * (chord test; a row is its own partner).  count_d[i] = partners of row i; best_d[i] = the first partner with the highest
+ * SNR (np.argmax over the partner list, first partner if any SNR is NaN); drop_d[j] = 1 if a partner with several partners
+ * prefers another row to j (the rows the reference removes).  *nearFlag_d = 1 if any chord lies within 1e-9 of the limit:
+ * the caller must then decide with the exact great-circle formula (the host implementation does). */
+int nf_xmatch_self(const double* unit_d, const double* snr_d, int n, double radiusDeg, int* count_d, int* best_d,
+                   unsigned char* drop_d, int* nearFlag_d, void* stream);
+
 /* nemo/photometry.py:69-73: isRing_d[id] = 1 if component id has > minRingPix pixels and its centre of mass is
  * not one of its own pixels. */
 int nf_ring_flags(const int* ringLabels_d, const double* ringStats_d, int numRing, int minRingPix, int H, int W,

@@ -273,6 +273,9 @@ def selectFromCatalog(catalog, constraintsList):
 
 
 # ------------------------------------------------------------------------------------------------------------
+GPU_XMATCH_MIN_ROWS = 1024
+
+
 def _unitVectors(RADeg, decDeg):
     ra, dec = np.radians(np.asarray(RADeg, dtype=np.float64)), np.radians(np.asarray(decDeg, dtype=np.float64))
     return np.stack([np.cos(dec) * np.cos(ra), np.cos(dec) * np.sin(ra), np.sin(dec)], axis=1)
@@ -398,12 +401,22 @@ def _makeOptimalCatalogForcedRef(catalogDict, constraintsList=[]):
         return Table(names=('SNR', 'RADeg', 'decDeg', 'name'))
     allCatalogs = vstack(allCatalogs)
     n = len(allCatalogs)
-    i, j = _pairsWithin(allCatalogs['RADeg'], allCatalogs['decDeg'], allCatalogs['RADeg'], allCatalogs['decDeg'],
-                        XMATCH_RADIUS_DEG)
-    count, best = _bestPerGroup(i, j, allCatalogs['SNR'], n)
-    toRemove = np.zeros(n, dtype=bool)
-    drop = (count[i] > 1) & (j != best[i])
-    toRemove[j[drop]] = True
+    toRemove = None
+    if n >= GPU_XMATCH_MIN_ROWS:
+        # the all-pairs test is a few tens of microseconds on the device the maps were filtered on; identical outcome
+        # (tests/test_gpu_kernels.py::test_xmatch_self), and the host path below decides when a chord is too close to call
+        from . import engine
+        if engine.gpu_ready():
+            res = engine.xmatch_self(allCatalogs['RADeg'], allCatalogs['decDeg'], allCatalogs['SNR'], XMATCH_RADIUS_DEG)
+            if res is not None:
+                toRemove = res[2]
+    if toRemove is None:
+        i, j = _pairsWithin(allCatalogs['RADeg'], allCatalogs['decDeg'], allCatalogs['RADeg'], allCatalogs['decDeg'],
+                            XMATCH_RADIUS_DEG)
+        count, best = _bestPerGroup(i, j, allCatalogs['SNR'], n)
+        toRemove = np.zeros(n, dtype=bool)
+        drop = (count[i] > 1) & (j != best[i])
+        toRemove[j[drop]] = True
     merged = allCatalogs[~toRemove]
     merged.sort(['RADeg', 'decDeg'])
     return selectFromCatalog(merged, constraintsList)

@@ -604,4 +604,102 @@ int spline_eval(int vtype, const void* map, int negate, int H, int W, const doub
     return NF_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Cross match of a catalogue with itself (catalogs._makeOptimalCatalogForcedRef, nemo/catalogs.py:319-362): rows are unit
+// vectors; two rows are partners when their chord is shorter than the match radius' chord (every row is its own partner).
+//   k_xmatch_best   per row i: number of partners, and the first partner (lowest index) with the highest SNR - what
+//                   xIndices[np.argmax(SNR[xIndices])] picks; a NaN among the partners' SNRs makes numpy's segment maximum
+//                   NaN, and then the first partner is taken.
+//   k_xmatch_drop   row j is dropped if some partner i has several partners and prefers another row to j.
+// A chord within 1e-9 (relative) of the limit is not decided here: *nearFlag is raised and the host repeats the match with
+// the exact great-circle formula (catalogs._pairsWithin).
+#define NF_XM_THREADS 64
+
+__device__ __forceinline__ int xm_relation(double ax, double ay, double az, double bx, double by, double bz, double lo2, double hi2) {
+    const double dx = ax - bx, dy = ay - by, dz = az - bz;
+    const double c2 = dx * dx + dy * dy + dz * dz;
+    return c2 < lo2 ? 1 : (c2 <= hi2 ? 2 : 0);
+}
+
+__global__ void __launch_bounds__(NF_XM_THREADS) k_xmatch_best(const double* __restrict__ u, const double* __restrict__ snr, int n,
+                                                                double lo2, double hi2, int* __restrict__ count,
+                                                                int* __restrict__ best, int* __restrict__ nearFlag) {
+    __shared__ double sx[NF_XM_THREADS], sy[NF_XM_THREADS], sz[NF_XM_THREADS], ss[NF_XM_THREADS];
+    const int i = blockIdx.x * NF_XM_THREADS + threadIdx.x;
+    const bool live = i < n;
+    const double ax = live ? u[3 * i] : 0.0, ay = live ? u[3 * i + 1] : 0.0, az = live ? u[3 * i + 2] : 2.0;
+    int cnt = 0, bst = -1, first = -1;
+    double mx = 0.0;
+    bool sawNaN = false, near = false;
+    for (int j0 = 0; j0 < n; j0 += NF_XM_THREADS) {
+        const int jl = j0 + threadIdx.x;
+        __syncthreads();
+        sx[threadIdx.x] = jl < n ? u[3 * jl] : 0.0;
+        sy[threadIdx.x] = jl < n ? u[3 * jl + 1] : 0.0;
+        sz[threadIdx.x] = jl < n ? u[3 * jl + 2] : -2.0;     // out of range: further than any chord from every row
+        ss[threadIdx.x] = jl < n ? snr[jl] : 0.0;
+        __syncthreads();
+        const int m = min(NF_XM_THREADS, n - j0);
+        for (int k = 0; k < m; ++k) {
+            const int rel = xm_relation(ax, ay, az, sx[k], sy[k], sz[k], lo2, hi2);
+            if (rel == 2) near = true;
+            if (rel == 1) {
+                const double sj = ss[k];
+                ++cnt;
+                if (first < 0) {
+                    first = j0 + k;
+                    bst = first;
+                    mx = sj;
+                    sawNaN = sj != sj;
+                } else if (sj != sj) {
+                    sawNaN = true;
+                } else if (sj > mx) {
+                    mx = sj;
+                    bst = j0 + k;
+                }
+            }
+        }
+    }
+    if (live) {
+        count[i] = cnt;
+        best[i] = sawNaN ? first : bst;
+        if (near) atomicOr(nearFlag, 1);
+    }
+}
+
+__global__ void __launch_bounds__(NF_XM_THREADS) k_xmatch_drop(const double* __restrict__ u, int n, double lo2, double hi2,
+                                                                const int* __restrict__ count, const int* __restrict__ best,
+                                                                unsigned char* __restrict__ drop) {
+    __shared__ double sx[NF_XM_THREADS], sy[NF_XM_THREADS], sz[NF_XM_THREADS];
+    __shared__ int sc[NF_XM_THREADS], sb[NF_XM_THREADS];
+    const int j = blockIdx.x * NF_XM_THREADS + threadIdx.x;
+    const bool live = j < n;
+    const double ax = live ? u[3 * j] : 0.0, ay = live ? u[3 * j + 1] : 0.0, az = live ? u[3 * j + 2] : 2.0;
+    bool d = false;
+    for (int i0 = 0; i0 < n; i0 += NF_XM_THREADS) {
+        const int il = i0 + threadIdx.x;
+        __syncthreads();
+        sx[threadIdx.x] = il < n ? u[3 * il] : 0.0;
+        sy[threadIdx.x] = il < n ? u[3 * il + 1] : 0.0;
+        sz[threadIdx.x] = il < n ? u[3 * il + 2] : -2.0;
+        sc[threadIdx.x] = il < n ? count[il] : 0;
+        sb[threadIdx.x] = il < n ? best[il] : -1;
+        __syncthreads();
+        const int m = min(NF_XM_THREADS, n - i0);
+        for (int k = 0; k < m; ++k)
+            if (sc[k] > 1 && sb[k] != j && xm_relation(ax, ay, az, sx[k], sy[k], sz[k], lo2, hi2) == 1) d = true;
+    }
+    if (live) drop[j] = d ? 1 : 0;
+}
+
+int xmatch_self(const double* u, const double* snr, int n, double lo2, double hi2, int* count, int* best, unsigned char* drop,
+                int* nearFlag, hipStream_t s) {
+    NF_HIP(hipMemsetAsync(nearFlag, 0, sizeof(int), s));
+    const int g = nf_div_up(n, NF_XM_THREADS);
+    hipLaunchKernelGGL(k_xmatch_best, dim3(g), dim3(NF_XM_THREADS), 0, s, u, snr, n, lo2, hi2, count, best, nearFlag);
+    hipLaunchKernelGGL(k_xmatch_drop, dim3(g), dim3(NF_XM_THREADS), 0, s, u, n, lo2, hi2, count, best, drop);
+    NF_CHECK_LAUNCH("k_xmatch");
+    return NF_OK;
+}
+
 }  // namespace nf

@@ -30,6 +30,36 @@ def require_gpu():
     return t.device('cuda', t.cuda.current_device())
 
 
+def gpu_ready():
+    """True once this process is already working on a HIP device through the library (host-side helpers use it to decide
+    whether a device kernel is worth calling; it never initialises anything)."""
+    from . import _lib as L
+    if L._lib is None:
+        return False
+    t = torch()
+    return t.cuda.is_available() and t.cuda.is_initialized()
+
+
+def xmatch_self(RADeg, decDeg, SNR, radiusDeg):
+    """nf_xmatch_self: (count, best, drop) of the self cross match as numpy arrays, or None when a chord lies within 1e-9 of
+    the limit (the caller then decides on the host with the exact great-circle formula)."""
+    t = torch()
+    dev = require_gpu()
+    ra, dec = np.radians(np.asarray(RADeg, dtype=np.float64)), np.radians(np.asarray(decDeg, dtype=np.float64))
+    u = np.stack([np.cos(dec) * np.cos(ra), np.cos(dec) * np.sin(ra), np.sin(dec)], axis=1)     # catalogs._unitVectors
+    n = len(u)
+    u_d, s_d = to_dev(u), to_dev(np.asarray(SNR, dtype=np.float64))
+    ints = t.empty(2 * n + 1, dtype=t.int32, device=dev)
+    drop = t.empty(n, dtype=t.uint8, device=dev)
+    lib = _lib.load()
+    check(lib.nf_xmatch_self(ptr(u_d), ptr(s_d), n, float(radiusDeg), ptr(ints[:n]), ptr(ints[n:2 * n]), ptr(drop),
+                             ptr(ints[2 * n:]), stream_ptr()), "nf_xmatch_self")
+    h = ints.cpu().numpy()
+    if h[2 * n] != 0:
+        return None
+    return h[:n].astype(np.int64), h[n:2 * n].astype(np.int64), drop.cpu().numpy().astype(bool)
+
+
 def stream_ptr():
     return ctypes.c_void_p(torch().cuda.current_stream().cuda_stream)
 

@@ -446,3 +446,33 @@ def test_paint_radial_matches_numpy_painter():
             ref = helpers.cpu_paint(geom, table)
             assert got.dtype == np.float32
             assert np.array_equal(got, ref)
+
+
+def test_xmatch_self():
+    """nf_xmatch_self against the host implementation of the 'ref-forced' merge (catalogs._pairsWithin + _bestPerGroup):
+    groups of jittered positions, exact duplicates, equal SNRs (first partner wins), a NaN SNR, isolated rows."""
+    from nemo_amd import catalogs
+    rng = np.random.default_rng(77)
+    base_ra, base_dec = rng.uniform(10, 44, 300), rng.uniform(-17, 17, 300)
+    ra = np.concatenate([base_ra + rng.normal(0, 0.006, 300) for _ in range(7)] + [rng.uniform(10, 44, 500), base_ra[:40]])
+    dec = np.concatenate([base_dec + rng.normal(0, 0.006, 300) for _ in range(7)] + [rng.uniform(-17, 17, 500), base_dec[:40]])
+    ra[-40:] = ra[:40]
+    dec[-40:] = dec[:40]                       # exact duplicates of the first rows
+    snr = rng.uniform(4, 40, len(ra))
+    snr[300:600] = snr[:300]                   # ties inside groups
+    snr[17] = np.nan
+    n = len(ra)
+    i, j = catalogs._pairsWithin(ra, dec, ra, dec, catalogs.XMATCH_RADIUS_DEG)
+    count, best = catalogs._bestPerGroup(i, j, snr, n)
+    toRemove = np.zeros(n, dtype=bool)
+    drop = (count[i] > 1) & (j != best[i])
+    toRemove[j[drop]] = True
+    res = engine.xmatch_self(ra, dec, snr, catalogs.XMATCH_RADIUS_DEG)
+    assert res is not None
+    assert np.array_equal(res[0], count)
+    assert np.array_equal(res[1], best)
+    assert np.array_equal(res[2], toRemove)
+    assert toRemove.sum() > 1000 and (~toRemove).sum() > 500
+    # a pair exactly at the limit is handed back to the host
+    d = catalogs.XMATCH_RADIUS_DEG
+    assert engine.xmatch_self(np.array([10.0, 10.0]), np.array([0.0, d]), np.array([5.0, 6.0]), d) is None

@@ -617,8 +617,8 @@ k_noise_cells_reg(const VT* __restrict__ v, const WT* __restrict__ wts, int H, i
 #define NF_BLK 48
 #define NF_BLK_THREADS 256
 #define NF_BLK_VPT (NF_BLK * NF_BLK / NF_BLK_THREADS)
-#define NF_BREC 14   // per block: n valid, wmin, wmax, T, n core, mu, S1, S2, tail count, tail offset, wmin / wmax of all pixels,
-                     // sum v, sum v^2
+#define NF_BREC 16   // per block: n valid, wmin, wmax, T, n core, mu, S1, S2, tail count, tail offset, wmin / wmax of all pixels,
+                     // sum (v - v0), sum (v - v0)^2 over the valid pixels, v0
 
 struct BlockWs {
     int* hdr;                      // [0] breakpoints along y, [1] along x
@@ -848,6 +848,8 @@ __global__ void __launch_bounds__(64) k_noise_block_stats(const VT* __restrict__
     const unsigned base = (unsigned)y0 * (unsigned)W + (unsigned)x0;   // 32-bit pixel offsets: H * W < 2^31 (host check)
     double sv = 0.0, sv2 = 0.0, n = 0.0, wmin = INFINITY, wmax = -INFINITY;
     double wminAll = INFINITY, wmaxAll = -INFINITY;     // over every pixel of the block, valid or not (for the paint step)
+    // sums are taken about v0, the block's first pixel: a map with a large offset loses nothing to cancellation
+    const double v0 = (double)v[base];
     const int iters = (npx + 63) >> 6;
     int rr = r0, xx = c0;
     for (int i0 = 0; i0 < iters; i0 += 4) {
@@ -876,9 +878,10 @@ __global__ void __launch_bounds__(64) k_noise_block_stats(const VT* __restrict__
                 wmaxAll = fmax(wmaxAll, wv);
             }
             if (t != 0.0) {
+                const double d = t - v0;
                 n += 1.0;
-                sv += t;
-                sv2 += t * t;
+                sv += d;
+                sv2 += d * d;
                 wmin = fmin(wmin, wv);
                 wmax = fmax(wmax, wv);
             }
@@ -900,8 +903,9 @@ __global__ void __launch_bounds__(64) k_noise_block_stats(const VT* __restrict__
         rec[8] = 0.0;
         rec[10] = wminAll;
         rec[11] = wmaxAll;
-        rec[12] = sv;
-        rec[13] = sv2;
+        rec[12] = sv;          // sum (v - v0) over the valid pixels
+        rec[13] = sv2;         // sum (v - v0)^2
+        rec[14] = v0;
     }
 }
 
@@ -921,7 +925,7 @@ __global__ void __launch_bounds__(64) k_noise_window_rms0(NoiseGrid g, BlockWs w
             const double* __restrict__ rb = ws.rec + ((long long)(BY0 + byo) * ws.maxBx + BX0 + (lane - byo * nbx)) * NF_BREC;
             n = rb[0];
             if (n > 0.0) {
-                const double m = rb[12] / n, var = rb[13] / n - m * m;
+                const double m = rb[12] / n, var = rb[13] / n - m * m;      // about the block's v0: the variance does not care
                 rb_ = sqrt(var > 0.0 ? var : 0.0);
             }
         }
@@ -944,9 +948,12 @@ __global__ void __launch_bounds__(64) k_noise_window_rms0(NoiseGrid g, BlockWs w
         for (int bi = lane; bi < nblk; bi += 64) {
             const int byo = bi / nbx;
             const double* __restrict__ rb = ws.rec + ((long long)(BY0 + byo) * ws.maxBx + BX0 + (bi - byo * nbx)) * NF_BREC;
-            n += rb[0];
-            sv += rb[12];
-            sv2 += rb[13];
+            // re-centre the block's sums on zero (this fallback serves whole-map cells; the robust median above is not
+            // available for them)
+            const double nb_ = rb[0], v0 = rb[14];
+            n += nb_;
+            sv += rb[12] + nb_ * v0;
+            sv2 += rb[13] + 2.0 * v0 * rb[12] + nb_ * v0 * v0;
         }
         for (int off = 32; off > 0; off >>= 1) {
             n += __shfl_xor(n, off, 64);
@@ -990,7 +997,7 @@ __global__ void __launch_bounds__(64) k_noise_block_core(const VT* __restrict__ 
     for (int off = 32; off > 0; off >>= 1) rmin = fmin(rmin, __shfl_xor(rmin, off, 64));
     if (ncand == 0) rmin = 0.0;                  // in no window: nothing will ask
     double T = 2.25 * rmin;
-    const double mu = rec[12] / n;
+    const double mu = rec[14] + rec[12] / n;
     const int r0 = lane / bw, c0 = lane - r0 * bw;
     const int dr = 64 / bw, dx = 64 - dr * bw;
     const unsigned base = (unsigned)y0 * (unsigned)W + (unsigned)x0;
@@ -1064,7 +1071,7 @@ __global__ void __launch_bounds__(64) k_noise_block_core(const VT* __restrict__ 
 
 // ---- k_noise_windows: ONE WAVEFRONT per cell (no barriers; reductions on the vector ALU) ----
 #define NF_WIN_MAXBLK 64      // blocks of a window whose records are staged in LDS (more: everything from global memory)
-#define NF_WIN_MAXTAIL 2048   // tail values of a window staged in LDS
+#define NF_WIN_MAXTAIL 1536   // tail values of a window held in LDS
 
 // one block scanned pixel by pixel (its T exceeds the threshold of this iteration): flat over the block, 4 loads per lane
 // in flight
@@ -1108,7 +1115,8 @@ __device__ __forceinline__ void scan_block(const VT* __restrict__ v, int W, cons
 
 struct WinLds {
     double T[NF_WIN_MAXBLK], nc[NF_WIN_MAXBLK], mu[NF_WIN_MAXBLK], S1[NF_WIN_MAXBLK], S2[NF_WIN_MAXBLK];
-    int tailBase[NF_WIN_MAXBLK];
+    double nAll[NF_WIN_MAXBLK], v0[NF_WIN_MAXBLK], A1[NF_WIN_MAXBLK], A2[NF_WIN_MAXBLK];   // all valid pixels, about v0
+    int tailBase[NF_WIN_MAXBLK], tailCnt[NF_WIN_MAXBLK];
     long long tailOff[NF_WIN_MAXBLK];
     double tail[NF_WIN_MAXTAIL];
     unsigned char tailBlk[NF_WIN_MAXTAIL];
@@ -1124,10 +1132,19 @@ __device__ __forceinline__ int tail_block(const WinLds& L, int nblk, int e) {
     return lo;
 }
 
+// The tail values the LDS currently holds (the "working set"): all tails with |v| < thrW if `complete`.  Thresholds fall
+// from one clipping iteration to the next, so after one pass over a long list the following iterations stay in LDS.
+struct WinState {
+    int nW;
+    double thrW;
+    bool complete;
+};
+
 // sum d, sum d^2, count over the valid pixels of the window with |v| < thr, d = v - c0 (every lane gets the totals)
 template <typename VT, bool LDS>
-__device__ __forceinline__ void window_sums(const VT* __restrict__ v, int W, const BlockWs& ws, const WinLds& L, int BY0, int BX0,
-                                            int nbx, int nblk, int ntail, double c0, double thr, double& s, double& ss, double& nn) {
+__device__ __forceinline__ void window_sums(const VT* __restrict__ v, int W, const BlockWs& ws, WinLds& L, WinState& st, int BY0,
+                                            int BX0, int nbx, int nblk, int ntail, double c0, double thr, double& s, double& ss,
+                                            double& nn) {
     const int lane = threadIdx.x & 63;
     s = 0.0;
     ss = 0.0;
@@ -1147,27 +1164,74 @@ __device__ __forceinline__ void window_sums(const VT* __restrict__ v, int W, con
             }
         }
         const unsigned long long coreMask = __ballot(core);   // bit b: the tails of block b count (it is not scanned directly)
-        const int nStaged = min(ntail, NF_WIN_MAXTAIL);
-#pragma unroll 4
-        for (int e = lane; e < nStaged; e += 64) {
-            const double t = L.tail[e];
-            if (((coreMask >> L.tailBlk[e]) & 1ULL) && fabs(t) < thr) {
-                const double d = t - c0;
-                s += d;
-                ss += d * d;
-                nn += 1.0;
+        if (thr == INFINITY) {
+            // no clipping yet (iteration 0): every valid pixel counts - the blocks' all-pixel sums, no lists
+            s = 0.0;
+            ss = 0.0;
+            nn = 0.0;
+            if (lane < nblk && L.nc[lane] >= 0.0) {
+                const double na = L.nAll[lane], dv = L.v0[lane] - c0, A1 = L.A1[lane], A2 = L.A2[lane];
+                s = A1 + na * dv;
+                ss = A2 + 2.0 * dv * A1 + na * dv * dv;
+                nn = na;
             }
-        }
+            scan = false;
+        } else if (st.complete && thr <= st.thrW) {
 #pragma unroll 4
-        for (int e = NF_WIN_MAXTAIL + lane; e < ntail; e += 64) {       // beyond the LDS room: from the lists themselves
-            const int bl = tail_block(L, nblk, e);
-            const double t = ws.tails[L.tailOff[bl] + (e - L.tailBase[bl])];
-            if (((coreMask >> bl) & 1ULL) && fabs(t) < thr) {
-                const double d = t - c0;
-                s += d;
-                ss += d * d;
-                nn += 1.0;
+            for (int e = lane; e < st.nW; e += 64) {
+                const double t = L.tail[e];
+                if (((coreMask >> L.tailBlk[e]) & 1ULL) && fabs(t) < thr) {
+                    const double d = t - c0;
+                    s += d;
+                    ss += d * d;
+                    nn += 1.0;
+                }
             }
+        } else {
+            // one pass over the lists themselves, block after block (coalesced, 4 loads per lane in flight); the values
+            // below thr become the new working set if they fit
+            int nW = 0;
+            bool fits = true;
+            for (int b = 0; b < nblk; ++b) {
+                const int tc = L.tailCnt[b];
+                if (tc == 0) continue;
+                const bool coreB = (coreMask >> b) & 1ULL;
+                const double* __restrict__ tp = ws.tails + L.tailOff[b];
+                for (int e0 = 0; e0 < tc; e0 += 256) {
+                    double tv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int e = e0 + u * 64 + lane;
+                        tv[u] = tp[e < tc ? e : 0];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int e = e0 + u * 64 + lane;
+                        const double t = tv[u];
+                        const bool below = e < tc && fabs(t) < thr;
+                        if (below && coreB) {
+                            const double d = t - c0;
+                            s += d;
+                            ss += d * d;
+                            nn += 1.0;
+                        }
+                        const unsigned long long m = __ballot(below);
+                        if (below && fits) {
+                            const int pos = nW + __popcll(m & ((1ULL << lane) - 1ULL));
+                            if (pos < NF_WIN_MAXTAIL) {
+                                L.tail[pos] = t;
+                                L.tailBlk[pos] = (unsigned char)b;
+                            }
+                        }
+                        nW += __popcll(m);
+                        if (nW > NF_WIN_MAXTAIL) fits = false;
+                    }
+                }
+            }
+            st.complete = fits;
+            st.nW = fits ? nW : 0;
+            st.thrW = thr;
+            __syncthreads();
         }
         unsigned long long todo = __ballot(scan);
         if (todo && lane == 0) atomicAdd(&ws.hdr[2], __popcll(todo));    // diagnostics: direct block scans
@@ -1224,21 +1288,21 @@ __device__ __forceinline__ void window_sums(const VT* __restrict__ v, int W, con
 
 // 3-sigma clipping exactly as k_noise_cells_reg runs it (nemo/filters.py:417-433)
 template <typename VT, bool LDS>
-__device__ __forceinline__ double window_clip(const VT* __restrict__ v, int W, const BlockWs& ws, const WinLds& L, int BY0, int BX0,
-                                              int nbx, int nblk, int ntail) {
+__device__ __forceinline__ double window_clip(const VT* __restrict__ v, int W, const BlockWs& ws, WinLds& L, WinState& st, int BY0,
+                                              int BX0, int nbx, int nblk, int ntail) {
     double thr = INFINITY, mean = 0.0, rms = 0.0;
     bool have = false;
     for (int it = 0; it <= 10; ++it) {
         double m, r, s, ss, n;
         if (it == 0) {
-            window_sums<VT, LDS>(v, W, ws, L, BY0, BX0, nbx, nblk, ntail, 0.0, INFINITY, s, ss, n);
+            window_sums<VT, LDS>(v, W, ws, L, st, BY0, BX0, nbx, nblk, ntail, 0.0, INFINITY, s, ss, n);
             if (n == 0.0) break;
             m = s / n;
-            window_sums<VT, LDS>(v, W, ws, L, BY0, BX0, nbx, nblk, ntail, m, INFINITY, s, ss, n);
+            window_sums<VT, LDS>(v, W, ws, L, st, BY0, BX0, nbx, nblk, ntail, m, INFINITY, s, ss, n);
             r = sqrt(ss / n);
         } else {
             const double c0 = mean;
-            window_sums<VT, LDS>(v, W, ws, L, BY0, BX0, nbx, nblk, ntail, c0, thr, s, ss, n);
+            window_sums<VT, LDS>(v, W, ws, L, st, BY0, BX0, nbx, nblk, ntail, c0, thr, s, ss, n);
             if (n == 0.0) continue;
             const double dm = s / n;
             m = c0 + dm;
@@ -1301,6 +1365,11 @@ __global__ void __launch_bounds__(64) k_noise_windows(const VT* __restrict__ v, 
             L.S2[lane] = rb[7];
             tc = live ? (int)rb[8] : 0;
             L.tailOff[lane] = (long long)rb[9];
+            L.tailCnt[lane] = tc;
+            L.nAll[lane] = rb[0];
+            L.A1[lane] = rb[12];
+            L.A2[lane] = rb[13];
+            L.v0[lane] = rb[14];
         }
         int incl = tc;
         for (int off = 1; off < 64; off <<= 1) {
@@ -1310,18 +1379,28 @@ __global__ void __launch_bounds__(64) k_noise_windows(const VT* __restrict__ v, 
         if (lane < nblk) L.tailBase[lane] = incl - tc;
         __syncthreads();
         // the block of flat tail index e by binary search in the prefix (LDS only), then the loads, all independent
-        const int nStaged = min(tcSum, NF_WIN_MAXTAIL);
-        for (int e = lane; e < nStaged; e += 64) L.tailBlk[e] = (unsigned char)tail_block(L, nblk, e);
+        WinState st;
+        st.complete = tcSum <= NF_WIN_MAXTAIL;
+        st.nW = st.complete ? tcSum : 0;
+        st.thrW = st.complete ? INFINITY : 0.0;
+        if (st.complete) {
+            for (int e = lane; e < tcSum; e += 64) L.tailBlk[e] = (unsigned char)tail_block(L, nblk, e);
 #pragma unroll 8
-        for (int e = lane; e < nStaged; e += 64) {
-            const int bl = L.tailBlk[e];
-            L.tail[e] = ws.tails[L.tailOff[bl] + (e - L.tailBase[bl])];
+            for (int e = lane; e < tcSum; e += 64) {
+                const int bl = L.tailBlk[e];
+                L.tail[e] = ws.tails[L.tailOff[bl] + (e - L.tailBase[bl])];
+            }
+        } else if (lane == 0) {
+            atomicAdd(&ws.hdr[3], 1);        // diagnostics: windows with more tails than LDS room
         }
-        if (tcSum > NF_WIN_MAXTAIL && lane == 0) atomicAdd(&ws.hdr[3], 1);   // diagnostics: windows with more tails than LDS room
         __syncthreads();
-        rms = window_clip<VT, true>(v, W, ws, L, BY0, BX0, nbx, nblk, tcSum);
+        rms = window_clip<VT, true>(v, W, ws, L, st, BY0, BX0, nbx, nblk, tcSum);
     } else {
-        rms = window_clip<VT, false>(v, W, ws, L, BY0, BX0, nbx, nblk, 0);
+        WinState st;
+        st.complete = false;
+        st.nW = 0;
+        st.thrW = 0.0;
+        rms = window_clip<VT, false>(v, W, ws, L, st, BY0, BX0, nbx, nblk, 0);
     }
     if (lane == 0) {
         rec[0] = 1.0;

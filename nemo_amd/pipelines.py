@@ -14,6 +14,7 @@ finding.  Only catalogue rows reach the host.
 import concurrent.futures
 import contextlib
 import os
+import threading
 import time
 
 import numpy as np
@@ -117,11 +118,26 @@ def _loadCachedRMSMap(config, tileName, photFilter):
     raise Exception("useCachedRMSMap: no RMS map of filter '%s' for tile '%s' (run the pipeline once without it)" % (photFilter, tileName))
 
 
+class _WorkerStreams(object):
+    """One HIP stream per detection worker thread, made when the thread first asks."""
+
+    def __init__(self):
+        self._local = threading.local()
+
+    def get(self):
+        s = getattr(self._local, 'stream', None)
+        if s is None:
+            s = self._local.stream = engine.torch().cuda.Stream()
+        return s
+
+
 def _detectAndMeasure(config, job, stream, invertMap, measureFluxes, photFilter, verbose):
     """photometry.findObjects + measureFluxes for one (filter, tile) - nemo/pipelines.py:267-311.  With ``stream`` the
     work is enqueued on that HIP stream (called from the detection worker thread) after the filtered maps are complete."""
     label, f, filteredMapDict, photFilteredMapDict, ready = job
     t = engine.torch()
+    if isinstance(stream, _WorkerStreams):
+        stream = stream.get()
     ctx = t.cuda.stream(stream) if stream is not None else contextlib.nullcontext()
     with ctx:
         if stream is not None:
@@ -238,9 +254,14 @@ def _filterMapsAndMakeCatalogs(config, rootOutDir=None, useCachedFilters=False, 
     t = engine.torch()
     engine.require_gpu()
     pool, detStream, pending = None, None, []
+    timing = os.environ.get('NEMO_AMD_TIMING') == '1'       # host-side milestones of the step (diagnostics)
+    marks = [('start', time.perf_counter())]
     if config.parDict.get('asyncDetection', True):
-        pool = concurrent.futures.ThreadPoolExecutor(max_workers=1)
-        detStream = t.cuda.Stream()
+        # detection workers, each with a HIP stream of its own (scales are independent of each other: with two, the host
+        # round trips of one scale's detection overlap the next one's)
+        numWorkers = max(1, int(os.environ.get('NEMO_AMD_ASYNC_WORKERS', config.parDict.get('asyncWorkers', 1))))
+        pool = concurrent.futures.ThreadPoolExecutor(max_workers=numWorkers)
+        detStream = _WorkerStreams()
     try:
         for tileName in config.tileNames:
             if verbose == True:
@@ -301,19 +322,28 @@ def _filterMapsAndMakeCatalogs(config, rootOutDir=None, useCachedFilters=False, 
                     catalogDict[label]['catalog'] = _detectAndMeasure(config, job, None, invertMap, measureFluxes, photFilter,
                                                                       verbose)
                 del job
-                if len(pending) > 2:          # bound the maps kept alive for the worker to a few scales
-                    pending[-3][1].result()
+                # bound the maps kept alive for the worker to a few scales (≈0.7 GB each at 4096^2); deep enough that the
+                # enqueueing thread is not put to sleep while the GPU still has less than a scale of work queued
+                depth = int(os.environ.get('NEMO_AMD_ASYNC_DEPTH', config.parDict.get('asyncDepth', 2)))
+                if len(pending) > depth:
+                    pending[-depth - 1][1].result()
+            marks.append(('filters enqueued', time.perf_counter()))
             for label, fut in pending:
                 catalogDict[label]['catalog'] = fut.result()
             pending = []
+            marks.append(('detection done', time.perf_counter()))
             del tileCache
     finally:
         filters.RETURN_DEVICE_ARRAYS = keepDevice
         if pool is not None:
             pool.shutdown(wait=True)
 
+    marks.append(('pool closed', time.perf_counter()))
     optimalCatalog = catalogs.makeOptimalCatalog(catalogDict, constraintsList=config.parDict['catalogCuts'],
                                                  photFilter=photFilter, method=config.parDict['optimalCatalogMethod'])
+    marks.append(('optimal catalogue', time.perf_counter()))
+    if timing:
+        print("[timing] " + "  ".join("%s +%.2f ms" % (k, 1e3 * (v - marks[0][1])) for k, v in marks[1:]), flush=True)
     if config.MPIEnabled == True and config.size > 1:
         optimalCatalog = _gatherCatalogs(optimalCatalog, config)
         if len(optimalCatalog) > 0:

@@ -23,6 +23,10 @@ def wrapped(filtered, medWeights, noiseParams, pixSizeDeg):
     f = filtered.cpu().numpy()
     print("breaks", hdr[0], hdr[1], "scans", hdr[2], "nonLDS windows", hdr[3], "| map std %.3e  kurtosis %.2f  cell rms min/med/max %.3e %.3e %.3e"
           % (f.std(), ((f - f.mean()) ** 4).mean() / f.var() ** 2, stats[:, 3].min(), np.median(stats[:, 3]), stats[:, 3].max()), flush=True)
+    import time
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(10): orig(filtered, medWeights, noiseParams, pixSizeDeg)
+    torch.cuda.synchronize(); print("   standalone noise_map on this map: %.1f us" % (1e5 * (time.perf_counter() - t0)), flush=True)
     return rms
 
 eng.noise_map = wrapped

@@ -504,8 +504,8 @@ __device__ double nak_spline_eval(const double* y, int st, int n, double u, doub
             if (i == 2) rhs -= M[1];
             if (i == n - 3) rhs -= M[n - 2];
             int k = i - 2;
-            double denom = (k == 0) ? 4.0 : 4.0 - cp[k - 1];
-            double val = (k == 0) ? rhs / denom : (rhs - prev) / denom;
+            // 1 / (4 - cp[k-1]) is cp[k] itself (cp[0] = 1/4): a multiplication instead of an IEEE division in the chain
+            double val = (k == 0) ? rhs * cp[0] : (rhs - prev) * cp[k];
             M[i] = val;
             prev = val;
         }

@@ -5,6 +5,7 @@ and exposes one thin method per C-ABI entry point.  Nothing here computes on the
 1-D tables (apodisation profile, sinc window, Gaussian taps, noise-grid edges) that parametrise kernels.
 """
 import ctypes
+import os
 
 import numpy as np
 
@@ -522,11 +523,13 @@ class TileEngine(object):
         yx = np.ascontiguousarray(np.asarray(yx, dtype=np.float64).reshape(-1, 2))
         if len(yx) == 0:
             return np.zeros(0)
-        # which kernel serves which point is known here (the positions come from the host): tell the library, so that it
-        # does not launch a kernel in which every workgroup would only find out that it has nothing to do
         iy, ix = np.floor(yx[:, 0]), np.floor(yx[:, 1])
         interior = (iy - halfWin - 1 >= 0) & (iy + halfWin + 2 <= self.H - 1) & (ix - halfWin - 1 >= 0) & \
             (ix + halfWin + 2 <= self.W - 1) & (yx[:, 0] >= 0) & (yx[:, 0] <= self.H - 1) & (yx[:, 1] >= 0) & (yx[:, 1] <= self.W - 1)
+        # which kernel serves which point is known here (the positions come from the host): tell the library, so that it
+        # does not launch a kernel in which every workgroup would only find out that it has nothing to do.  (Launching the
+        # two kernels on separate point subsets was tried: the extra small copies and scatter launches cost more than the
+        # idle workgroups do.)
         pointsClass = 1 if interior.all() else (2 if not interior.any() else 0)
         yx_d = to_dev(yx)
         out = t.empty(len(yx), dtype=t.float64, device=self.dev)

@@ -8,6 +8,8 @@ sub-pixel positions (windowed not-a-knot spline = RectBivariateSpline(kx=ky=3)),
 maps at catalogue positions.
 Only per-object scalars cross to the host, as whole columns (no per-object Python loop).
 """
+import os
+
 import numpy as np
 
 from . import engine, catalogs
@@ -23,6 +25,20 @@ def galacticLatDeg(RADeg, decDeg):
 
 
 _galacticLatDeg = galacticLatDeg
+
+
+_TIMING = os.environ.get('NEMO_AMD_TIMING') == '1'
+_acc = {}
+
+
+def _mark(key, t0):
+    """Diagnostics (NEMO_AMD_TIMING=1): accumulate host wall time per phase of the detection worker."""
+    if _TIMING:
+        import time
+        now = time.perf_counter()
+        _acc[key] = _acc.get(key, 0.0) + (now - t0)
+        return now
+    return t0
 
 
 def _segment(eng, dMap, threshold, findCenterOfMass=True, negate=False):
@@ -123,15 +139,20 @@ def findObjects(filteredMapDict, threshold=3.0, minObjPix=3, rejectBorder=10, fi
     eng = engine.TileEngine.get(dSN.shape)
     H, W = dSN.shape
 
+    import time
+    tm = time.perf_counter() if _TIMING else 0.0
     numObjects, labels, stats = _segment(eng, dSN, threshold, findCenterOfMass, negate=invertMap)   # :59
     if numObjects == 0:
         return []
+    tm = _mark('label+stats enqueue', tm)
     st = stats.cpu().numpy()
+    tm = _mark('stats fetch', tm)
 
     ringLabels = isRing = None
     if flagRings == True:                                                         # :65-75
         numRing, ringLabels, ringStats = _segment(eng, dSN, ringThresholdSigma, True, negate=invertMap)
         isRing = eng.ring_flags(ringLabels, ringStats, numRing, minRingPix=30)
+    tm = _mark('ring label', tm)
 
     # objects passing the size cut, in label order (label 0 has numPix 0 and never passes unless minObjPix <= 0)
     ids = np.arange(1, numObjects + 1)
@@ -181,7 +202,9 @@ def findObjects(filteredMapDict, threshold=3.0, minObjPix=3, rejectBorder=10, fi
                     queued.append(('pre%d' % k, _lookupDev(d, np.clip(np.round(yy).astype(np.int64), 0, H - 1),
                                                            np.clip(np.round(xx).astype(np.int64), 0, W - 1)) * (-1.0 if neg else 1.0)))
         pre = [(mapLike, neg) for mapLike, neg in _prefetch]
+    tm = _mark('positions + enqueue reads', tm)
     got = _fetchTogether(queued)
+    tm = _mark('fetch reads', tm)
     SNRs = got['SNR']
     ringFlags = got['ring'] > 0 if 'ring' in got else np.zeros(len(sel), dtype=bool)
     keep = SNRs > threshold                                                       # :186
@@ -212,6 +235,7 @@ def findObjects(filteredMapDict, threshold=3.0, minObjPix=3, rejectBorder=10, fi
             if np.logical_and((rDeg * 60) < ringFlagDistArcmin, rDeg > 0).sum() == 0:
                 rf[i] = False
     tab['flags'] = tab['flags'] + tab['ringFlag']
+    tm = _mark('table', tm)
     if pre:
         tab._prefetched = {}
         for k, (mapLike, neg) in enumerate(pre):

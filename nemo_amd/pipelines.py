@@ -344,6 +344,8 @@ def _filterMapsAndMakeCatalogs(config, rootOutDir=None, useCachedFilters=False, 
     marks.append(('optimal catalogue', time.perf_counter()))
     if timing:
         print("[timing] " + "  ".join("%s +%.2f ms" % (k, 1e3 * (v - marks[0][1])) for k, v in marks[1:]), flush=True)
+        print("[timing] worker: " + "  ".join("%s %.2f ms" % (k, 1e3 * v) for k, v in photometry._acc.items()), flush=True)
+        photometry._acc.clear()
     if config.MPIEnabled == True and config.size > 1:
         optimalCatalog = _gatherCatalogs(optimalCatalog, config)
         if len(optimalCatalog) > 0:

@@ -221,9 +221,11 @@ int nf_ring_flags(const int* ringLabels_d, const double* ringStats_d, int numRin
  * Points further than halfWin + 2 pixels from every edge are evaluated as one weighted sum over the window (Green's
  * function of the spline's tridiagonal system), the others by a windowed not-a-knot solve that honours the map border.
  * pointsClass: 0 = unknown (both kernels are launched, each skips the other's points), 1 = the caller guarantees that
- * all points are interior, 2 = that none is - saves the launch that would do nothing. */
+ * all points are interior, 2 = that none is - saves the launch that would do nothing.  With pointsClass 0 the caller may
+ * name the non-interior points (edgeSel_d: nEdge indices into yx_d, or NULL): the windowed solve, whose workgroups hold
+ * 85 KB of LDS each, is then launched for those only. */
 int nf_spline_eval(int vtype, const void* map_d, int negate, int H, int W, const double* yx_d, int nPts, int halfWin,
-                   int pointsClass, double* out_d, void* stream);
+                   int pointsClass, const int* edgeSel_d, int nEdge, double* out_d, void* stream);
 
 /* Instrumentation (no counterpart in the reference; used by bench.py): when enabled, every entry point above brackets
  * the work it enqueues with a HIP event pair on the caller's stream.  nf_profile_enable(on) switches recording and

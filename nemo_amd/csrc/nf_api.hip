@@ -537,13 +537,14 @@ int nf_ring_flags(const int* ringLabels, const double* ringStats, int numRing, i
 }
 
 int nf_spline_eval(int vtype, const void* map, int negate, int H, int W, const double* yx, int nPts, int halfWin,
-                   int pointsClass, double* out, void* stream) {
-    if (!map || (nPts > 0 && (!yx || !out)) || nPts < 0 || halfWin < 2 || pointsClass < 0 || pointsClass > 2) {
+                   int pointsClass, const int* edgeSel, int nEdge, double* out, void* stream) {
+    if (!map || (nPts > 0 && (!yx || !out)) || nPts < 0 || halfWin < 2 || pointsClass < 0 || pointsClass > 2 ||
+        (edgeSel && (nEdge < 1 || nEdge > nPts || pointsClass != 0))) {
         nf_set_error("nf_spline_eval: bad arguments");
         return NF_ERR_ARG;
     }
     nf::ProfScope ps(nf::PT_SPLINE, S(stream), (double)nPts * (2.0 * halfWin + 1) * (2.0 * halfWin + 1) * (vtype == NF_F32 ? 4.0 : 8.0));
-    return nf::spline_eval(vtype, map, negate, H, W, yx, nPts, halfWin, pointsClass, out, S(stream));
+    return nf::spline_eval(vtype, map, negate, H, W, yx, nPts, halfWin, pointsClass, edgeSel, nEdge, out, S(stream));
 }
 
 }  // extern "C"

@@ -535,10 +535,11 @@ __global__ void __launch_bounds__(128) k_spline_eval_interior(const VT* __restri
 
 template <typename VT>
 __global__ void k_spline_eval(const VT* __restrict__ map, int negate, int H, int W, const double* __restrict__ yx, int halfWin,
-                              double* __restrict__ out) {
+                              const int* __restrict__ sel, double* __restrict__ out) {
     extern __shared__ __align__(16) unsigned char nf_smem[];
     double* win = (double*)nf_smem;                         // [ny][nxp]
-    const double py = yx[2 * blockIdx.x], px = yx[2 * blockIdx.x + 1];
+    const int pt = sel ? sel[blockIdx.x] : (int)blockIdx.x; // `sel`: the points this kernel serves (the others are interior)
+    const double py = yx[2 * pt], px = yx[2 * pt + 1];
     int iy = (int)floor(py), ix = (int)floor(px);
     int y0 = max(0, iy - halfWin), y1 = min(H - 1, iy + 1 + halfWin);
     int x0 = max(0, ix - halfWin), x1 = min(W - 1, ix + 1 + halfWin);
@@ -548,7 +549,7 @@ __global__ void k_spline_eval(const VT* __restrict__ map, int negate, int H, int
     double* colv = mwork + NF_SPL_MAXN * (NF_SPL_MAXN + 1);  // [ny]
     double* cp = colv + NF_SPL_MAXN;                         // [NF_SPL_MAXN]
     if (!(py >= 0.0 && py <= (double)(H - 1) && px >= 0.0 && px <= (double)(W - 1)) || ny < 4 || nx < 4) {
-        if (threadIdx.x == 0) out[blockIdx.x] = nan("");
+        if (threadIdx.x == 0) out[pt] = nan("");
         return;
     }
     if (spline_interior(iy, ix, H, W, halfWin)) return;      // k_spline_eval_interior wrote this point
@@ -569,11 +570,11 @@ __global__ void k_spline_eval(const VT* __restrict__ map, int negate, int H, int
     for (int r = threadIdx.x; r < ny; r += blockDim.x)
         colv[r] = nak_spline_eval(win + r * nxp, 1, nx, px - (double)x0, mwork + r * nxp, cp);
     __syncthreads();
-    if (threadIdx.x == 0) out[blockIdx.x] = nak_spline_eval(colv, 1, ny, py - (double)y0, mwork, cp);
+    if (threadIdx.x == 0) out[pt] = nak_spline_eval(colv, 1, ny, py - (double)y0, mwork, cp);
 }
 
 int spline_eval(int vtype, const void* map, int negate, int H, int W, const double* yx, int nPts, int halfWin, int pointsClass,
-                double* out, hipStream_t s) {
+                const int* edgeSel, int nEdge, double* out, hipStream_t s) {
     if (nPts <= 0) return NF_OK;
     if (2 * halfWin + 2 > NF_SPL_MAXN) {
         nf_set_error("spline_eval: window too large");
@@ -589,7 +590,8 @@ int spline_eval(int vtype, const void* map, int negate, int H, int W, const doub
         if (pointsClass != 2)
             hipLaunchKernelGGL(k_spline_eval_interior<double>, dim3(nPts), dim3(128), 0, s, (const double*)map, negate, H, W, yx, halfWin, out);
         if (pointsClass != 1)
-            hipLaunchKernelGGL(k_spline_eval<double>, dim3(nPts), dim3(128), lds, s, (const double*)map, negate, H, W, yx, halfWin, out);
+            hipLaunchKernelGGL(k_spline_eval<double>, dim3(edgeSel ? nEdge : nPts), dim3(128), lds, s, (const double*)map, negate, H, W, yx,
+                               halfWin, edgeSel, out);
     } else {
         if (!attr[0]) {
             NF_HIP(hipFuncSetAttribute((const void*)k_spline_eval<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -598,7 +600,8 @@ int spline_eval(int vtype, const void* map, int negate, int H, int W, const doub
         if (pointsClass != 2)
             hipLaunchKernelGGL(k_spline_eval_interior<float>, dim3(nPts), dim3(128), 0, s, (const float*)map, negate, H, W, yx, halfWin, out);
         if (pointsClass != 1)
-            hipLaunchKernelGGL(k_spline_eval<float>, dim3(nPts), dim3(128), lds, s, (const float*)map, negate, H, W, yx, halfWin, out);
+            hipLaunchKernelGGL(k_spline_eval<float>, dim3(edgeSel ? nEdge : nPts), dim3(128), lds, s, (const float*)map, negate, H, W, yx,
+                               halfWin, edgeSel, out);
     }
     NF_CHECK_LAUNCH("k_spline_eval");
     return NF_OK;

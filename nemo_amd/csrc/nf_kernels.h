@@ -66,7 +66,7 @@ int object_stats(int vtype, const void* sn, int negate, const int* labels, int H
 int map_max(int vtype, const void* m, long long n, double* out, hipStream_t s);
 int ring_flags(const int* ringLabels, const double* ringStats, int numRing, int minRingPix, int H, int W, unsigned char* isRing,
                hipStream_t s);
-int spline_eval(int vtype, const void* map, int negate, int H, int W, const double* yx, int nPts, int halfWin, int pointsClass,
+int spline_eval(int vtype, const void* map, int negate, int H, int W, const double* yx, int nPts, int halfWin, int pointsClass, const int* edgeSel, int nEdge,
                 double* out, hipStream_t s);
 
 }  // namespace nf

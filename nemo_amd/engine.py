@@ -113,6 +113,9 @@ def gaussian_kernel1d(sigma, truncate=4.0):
     return phi / phi.sum(), radius
 
 
+_EDGE_SEL = os.environ.get('NEMO_AMD_SPLINE_EDGESEL', '0') != '0'    # measured: no gain on the C2 bench
+
+
 class DeviceScalar(object):
     """A float64 / float32 scalar that lives on the device until somebody needs it on the host (``value``): keeps the
     host from waiting for the GPU in the middle of a filter build.  ``wide`` = numpy float64 semantics (else float32)."""
@@ -533,8 +536,11 @@ class TileEngine(object):
         pointsClass = 1 if interior.all() else (2 if not interior.any() else 0)
         yx_d = to_dev(yx)
         out = t.empty(len(yx), dtype=t.float64, device=self.dev)
+        # mixed: the windowed-solve kernel (85 KB of LDS per workgroup) is launched for the edge points only
+        edge = to_dev(np.flatnonzero(~interior).astype(np.int32)) if (pointsClass == 0 and _EDGE_SEL) else None
         check(self.lib.nf_spline_eval(prec_of(m), ptr(m), 1 if negate else 0, self.H, self.W, ptr(yx_d), len(yx), halfWin,
-                                      pointsClass, ptr(out), stream_ptr()), "nf_spline_eval")
+                                      pointsClass, ptr(edge), 0 if edge is None else edge.numel(), ptr(out), stream_ptr()),
+              "nf_spline_eval")
         if not to_host:
             return out
         return out.cpu().numpy()

@@ -93,6 +93,15 @@ int nf_symmetrise_filter(const float* filt_d, double* filtSym_d, int N, int H, i
 int nf_fft2_inverse_half(nf_plan* plan, int prec, const void* in_d, const double* filtSym_d, int nSum, int filtPerBatch,
                          const double* wy_d, const double* wx_d, void* work_d, void* out_d, int outType, int batch,
                          int unitary, void* stream);
+/* nf_fft2_inverse_half of ONE map (nSum planes summed, or one plane) with the pointwise steps that follow it on the path
+ * applied while the real rows are stored (they would otherwise re-read and re-write the map):
+ *   scale_d (device scalar) [+ mask_d]: out = float32(value) * scale [* mask], in the output type - the cast of
+ *       nemo/filters.py:847, the signalNorm product of :853 and the point-source mask of :714 (= nf_scale_mask_dev);
+ *   zeroRef_d (map of the output type): out = 0 where zeroRef is 0 - nemo/filters.py:99-101 (= nf_restore_zeros).
+ * Either may be NULL.  Other arguments as nf_fft2_inverse_half. */
+int nf_fft2_inverse_half_epi(nf_plan* plan, int prec, const void* in_d, const double* filtSym_d, int nSum, const double* wy_d,
+                             const double* wx_d, void* work_d, void* out_d, int outType, int unitary, const double* scale_d,
+                             const unsigned char* mask_d, const void* zeroRef_d, void* stream);
 int nf_cross_power_half(int prec, const void* F_d, void* NP_d, int N, int H, int W, void* stream);
 int nf_build_filter_half(int covType, int sigType, const void* cov_d, const void* S_d, const double* w, float* filt_d,
                          int N, int H, int W, void* stream);
@@ -125,6 +134,13 @@ int nf_window_mul(int prec, void* F_d, const double* wy_d, const double* wx_d, i
 int nf_paint_radial(float* out_d, int H, int W, const double* A_d, const double* B_d, const double* C_d,
                     const double* r_d, const double* prof_d, const double* slope_d, int ntab, double r0, double dlnr,
                     double amp, double sign, void* stream);
+
+/* Two templates on the same radii in one pass (the unit template of nemo/filters.py:611-618 and the amplitude-scaled one
+ * of :639-646 are painted at the same place: angle and table search are shared); each output as nf_paint_radial gives it. */
+int nf_paint_radial2(float* out_d, float* out2_d, int H, int W, const double* A_d, const double* B_d, const double* C_d,
+                     const double* r_d, const double* prof_d, const double* slope_d, const double* prof2_d,
+                     const double* slope2_d, int ntab, double r0, double dlnr, double amp, double sign, double amp2,
+                     double sign2, void* stream);
 
 /* nemo/filters.py:853 + :714: out = float32 map * signalNorm * psMask, in float64 (vtype NF_F64: signalNorm is a
  * float64 scalar, 'yc') or float32 (vtype NF_F32: 'uK').  psMask_d may be NULL. */

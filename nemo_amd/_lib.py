@@ -41,6 +41,8 @@ SIGNATURES = {
     'nf_fft2_forward_half': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     'nf_fft2_inverse_half': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_int, c_int, c_int, c_void_p]),
+    'nf_fft2_inverse_half_epi': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                         c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     'nf_symmetrise_filter': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'nf_cross_power_half': (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'nf_build_filter_half': (c_int, [c_int, c_int, c_void_p, c_void_p, ctypes.POINTER(c_double), c_void_p, c_int, c_int, c_int,
@@ -50,6 +52,8 @@ SIGNATURES = {
     'nf_build_filter': (c_int, [c_int, c_int, c_void_p, c_void_p, ctypes.POINTER(c_double), c_void_p, c_int, c_ll, c_void_p]),
     'nf_apply_filter': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_ll, c_void_p]),
     'nf_window_mul': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    'nf_paint_radial2': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                 c_void_p, c_int, c_double, c_double, c_double, c_double, c_double, c_double, c_void_p]),
     'nf_paint_radial': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_double,
                                 c_double, c_double, c_double, c_void_p]),
     'nf_scale_mask': (c_int, [c_int, c_void_p, c_void_p, c_double, c_void_p, c_ll, c_void_p]),

@@ -251,6 +251,24 @@ int nf_fft2_inverse_half(nf_plan* p, int prec, const void* in, const double* fil
     return p->pd.inverse_half(in, work, out, outType, batch, unitary ? 1 : 0, scale, S(stream), filtSym, nSum, fbs, wy, wx);
 }
 
+int nf_fft2_inverse_half_epi(nf_plan* p, int prec, const void* in, const double* filtSym, int nSum, const double* wy,
+                             const double* wx, void* work, void* out, int outType, int unitary, const double* scale_d,
+                             const unsigned char* mask_d, const void* zeroRef_d, void* stream) {
+    if (!p || !in || !work || !out || (outType != NF_IN_REAL64 && outType != NF_IN_REAL32) || nSum < 1 || (nSum > 1 && !filtSym) ||
+        ((wy == nullptr) != (wx == nullptr)) || (mask_d && !scale_d)) {
+        nf_set_error("nf_fft2_inverse_half_epi: bad arguments (real output, one map; a mask needs a scale)");
+        return NF_ERR_ARG;
+    }
+    int rc = ensure_prec(p, prec);
+    if (rc) return rc;
+    double scale = std::sqrt((double)p->H * (double)p->W);
+    if (prec == NF_F32)
+        return p->pf.inverse_half(in, work, out, outType, 1, unitary ? 1 : 0, scale, S(stream), filtSym, nSum, 0, wy, wx, scale_d,
+                                  mask_d, zeroRef_d);
+    return p->pd.inverse_half(in, work, out, outType, 1, unitary ? 1 : 0, scale, S(stream), filtSym, nSum, 0, wy, wx, scale_d, mask_d,
+                              zeroRef_d);
+}
+
 int nf_symmetrise_filter(const float* filt, double* filtSym, int N, int H, int W, void* stream) {
     if (!filt || !filtSym || N < 1 || H < 1 || W < 1) {
         nf_set_error("nf_symmetrise_filter: bad arguments");
@@ -353,6 +371,18 @@ int nf_paint_radial(float* out, int H, int W, const double* A, const double* B, 
     }
     nf::ProfScope ps(nf::PT_PAINT, S(stream), (double)H * W * 4.0);
     return nf::paint_radial(out, H, W, A, B, C, r, prof, slope, ntab, r0, dlnr, amp, sign, S(stream));
+}
+
+int nf_paint_radial2(float* out, float* out2, int H, int W, const double* A, const double* B, const double* C, const double* r,
+                     const double* prof, const double* slope, const double* prof2, const double* slope2, int ntab, double r0,
+                     double dlnr, double amp, double sign, double amp2, double sign2, void* stream) {
+    if (!out || !out2 || !A || !B || !C || !r || !prof || !prof2 || ntab < 2 || H < 1 || W < 1 || !(dlnr > 0) || !(r0 > 0)) {
+        nf_set_error("nf_paint_radial2: bad arguments");
+        return NF_ERR_ARG;
+    }
+    nf::ProfScope ps(nf::PT_PAINT, S(stream), (double)H * W * 8.0);
+    return nf::paint_radial2(out, out2, H, W, A, B, C, r, prof, slope, prof2, slope2, ntab, r0, dlnr, amp, sign, amp2, sign2,
+                             S(stream));
 }
 
 int nf_scale_mask(int vtype, const float* in, void* out, double norm, const unsigned char* psMask, long long n, void* stream) {

@@ -63,6 +63,10 @@ struct LineArgs {
     int halfIn;              //   ... of a spectrum of a real map that is stored for c <= W/2 only (the mirror mode is the
                              //   conjugate of the stored one; only its filter value and window factor are fetched)
     int realH, realW;        // shape of the real map (H rows, W columns)
+    // rows kernel, pairMode 2 (real output): optional epilogues on the value being stored (batch 1 only)
+    const double* epiScale;          // device scalar: out = (float)value * scale (* epiMask), formed in the output type
+    const unsigned char* epiMask;    //   mask multiplied in after the scale
+    const void* epiZeroRef;          // map of the output type: where it is zero the output is zero
     const double* apodLine;  // optional per-line apodisation factors (length nLines); rows kernel, real input only
     const double* apodElem;  // optional per-element apodisation factors (length n)
 };
@@ -83,7 +87,8 @@ struct Plan2D {
     // inverse of half-stored spectra (real output): filtSym = symmetrised float64 filter planes, half-stored (or NULL)
     int inverse_half(const void* in, void* work, void* out, int outType, int batch, int scaleDiv, double scale,
                      hipStream_t stream, const double* filtSym, int nSum, long long filtBatchStride, const double* winY,
-                     const double* winX);
+                     const double* winX, const double* epiScale = nullptr, const unsigned char* epiMask = nullptr,
+                     const void* epiZeroRef = nullptr);
 };
 
 }  // namespace nf

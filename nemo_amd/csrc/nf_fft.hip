@@ -401,19 +401,52 @@ __device__ __forceinline__ void fft_stage(cpx<T>* __restrict__ buf, const nf::Li
                     const unsigned rowA = 2u * (unsigned)(G.line0 + line);
                     const bool haveB = rowA + 1u < (unsigned)a.realH;
                     const T r = (T)a.scale, rb = r * (T)a.conjOutSign;
+                    // optional epilogues of the matched-filter path, applied to the real value on its way out:
+                    //   epiScale  float32 map * signalNorm * psMask (nemo/filters.py:847,853,714: the filtered map is cast to
+                    //             float32, then multiplied by the scalar and the mask in the output type)
+                    //   epiZeroRef  pixels that are zero in the reference map stay zero (nemo/filters.py:99-101)
+                    const bool doScale = a.epiScale != nullptr;
+                    const double es = doScale ? *a.epiScale : 1.0;
 #pragma unroll
                     for (int k = 0; k < R; ++k) {
                         const unsigned e = base + (unsigned)k * L;
                         if (!BLUE || e < (unsigned)p.n) {
                             cpx<T> v = x[k];
                             if (BLUE) v = cmul(cconj(v), p.chirp[e]);
-                            const unsigned oa = rowA * (unsigned)a.realW + e;
+                            const unsigned oa = rowA * (unsigned)a.realW + e, ob = oa + (unsigned)a.realW;
+                            T va = v.x * r, vb = v.y * rb;
                             if (a.outType == 1) {
-                                ((double*)G.outP)[oa] = (double)(v.x * r);
-                                if (haveB) ((double*)G.outP)[oa + (unsigned)a.realW] = (double)(v.y * rb);
+                                double wa = (double)va, wb = (double)vb;
+                                if (doScale) {
+                                    wa = (double)(float)va * es;
+                                    wb = (double)(float)vb * es;
+                                    if (a.epiMask != nullptr) {
+                                        wa = wa * (double)a.epiMask[oa];
+                                        if (haveB) wb = wb * (double)a.epiMask[ob];
+                                    }
+                                }
+                                if (a.epiZeroRef != nullptr) {
+                                    if (((const double*)a.epiZeroRef)[oa] == 0.0) wa = 0.0;
+                                    if (haveB && ((const double*)a.epiZeroRef)[ob] == 0.0) wb = 0.0;
+                                }
+                                ((double*)G.outP)[oa] = wa;
+                                if (haveB) ((double*)G.outP)[ob] = wb;
                             } else {
-                                ((float*)G.outP)[oa] = (float)(v.x * r);
-                                if (haveB) ((float*)G.outP)[oa + (unsigned)a.realW] = (float)(v.y * rb);
+                                float wa = (float)va, wb = (float)vb;
+                                if (doScale) {
+                                    wa = wa * (float)es;
+                                    wb = wb * (float)es;
+                                    if (a.epiMask != nullptr) {
+                                        wa = wa * (float)a.epiMask[oa];
+                                        if (haveB) wb = wb * (float)a.epiMask[ob];
+                                    }
+                                }
+                                if (a.epiZeroRef != nullptr) {
+                                    if (((const float*)a.epiZeroRef)[oa] == 0.0f) wa = 0.0f;
+                                    if (haveB && ((const float*)a.epiZeroRef)[ob] == 0.0f) wb = 0.0f;
+                                }
+                                ((float*)G.outP)[oa] = wa;
+                                if (haveB) ((float*)G.outP)[ob] = wb;
                             }
                         }
                     }
@@ -1012,6 +1045,8 @@ int launch_lines(const LineArgs<T>& a, bool cols, int batch, int threads, hipStr
     double lineIn = cols ? ((a.nSum > 1 ? a.nSum : 1) * (inB + (a.mulF32 ? 4.0 : 0.0) + (a.mulSym ? 8.0 : 0.0))) : inB, lineOut = outB;
     if (!cols && a.pairMode == 1) lineIn *= 2.0;
     if (!cols && a.pairMode == 2) lineOut *= 2.0;
+    if (!cols && a.epiMask) lineIn += 2.0;
+    if (!cols && a.epiZeroRef) lineIn += 2.0 * outB;
     if (cols && a.mirror) lineOut *= 2.0;
     if (cols && a.herm && !a.halfIn) lineIn *= 2.0;
     ProfScope ps(tag, stream, npixTotal * (lineIn + lineOut));
@@ -1220,7 +1255,7 @@ int Plan2D<T>::inverse(const void* in, void* work, void* out, int outType, int b
 template <typename T>
 int Plan2D<T>::inverse_half(const void* in, void* work, void* out, int outType, int batch, int scaleDiv, double scale,
                             hipStream_t stream, const double* filtSym, int nSum, long long filtBatchStride, const double* winY,
-                            const double* winX) {
+                            const double* winX, const double* epiScale, const unsigned char* epiMask, const void* epiZeroRef) {
     if (outType == 0) {
         nf_set_error("a half-stored spectrum has a real inverse transform: ask for real output");
         return NF_ERR_ARG;
@@ -1243,6 +1278,9 @@ int Plan2D<T>::inverse_half(const void* in, void* work, void* out, int outType, 
     a.pairMode = 2;
     a.nLines = (H + 1) / 2;
     a.conjOutSign = 1.0;
+    a.epiScale = epiScale;
+    a.epiMask = epiMask;
+    a.epiZeroRef = epiZeroRef;
     int rc = launch_lines<T>(c, true, batch, threadsCol, stream);
     if (rc) return rc;
     return launch_lines<T>(a, false, batch, threadsRow, stream);

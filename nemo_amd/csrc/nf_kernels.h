@@ -23,6 +23,9 @@ int window_mul(void* F, const double* wy, const double* wx, int H, int W, int ba
 int paint_radial(float* out, int H, int W, const double* A, const double* B, const double* C, const double* r,
                  const double* prof, const double* slope, int ntab, double r0, double dlnr, double amp, double sign,
                  hipStream_t s);
+int paint_radial2(float* out, float* out2, int H, int W, const double* A, const double* B, const double* C, const double* r,
+                  const double* prof, const double* slope, const double* prof2, const double* slope2, int ntab, double r0,
+                  double dlnr, double amp, double sign, double amp2, double sign2, hipStream_t s);
 int scale_mask(int vtype, const float* in, void* out, double norm, const double* normDev, const unsigned char* psMask,
                long long n, hipStream_t s);
 int finalize(int vtype, void* filtered, const float* rms, const unsigned char* surveyMask, const unsigned char* psMask,

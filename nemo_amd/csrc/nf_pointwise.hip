@@ -305,11 +305,17 @@ __device__ __forceinline__ double theta_from_hav(double h) {
     return __dmul_rn(__dmul_rn(2.0, s), poly);
 }
 
-__global__ void __launch_bounds__(256) k_paint_radial(float* __restrict__ out, int H, int W, const double* __restrict__ A,
-                                                      const double* __restrict__ B, const double* __restrict__ C,
-                                                      const double* __restrict__ r, const double* __restrict__ prof,
-                                                      const double* __restrict__ slope, int ntab, float log2r0,
-                                                      float invDlog2, double amp, float sign) {
+// DUAL: a second template from a second profile / slope table on the same radii, painted in the same pass (the matched
+// filter paints the unit template and the amplitude-scaled one at the same place: the haversine, its arcsine and the
+// table search are shared, only the two interpolations differ).
+template <bool DUAL>
+__global__ void __launch_bounds__(256) k_paint_radial(float* __restrict__ out, float* __restrict__ out2, int H, int W,
+                                                      const double* __restrict__ A, const double* __restrict__ B,
+                                                      const double* __restrict__ C, const double* __restrict__ r,
+                                                      const double* __restrict__ prof, const double* __restrict__ slope,
+                                                      const double* __restrict__ prof2, const double* __restrict__ slope2, int ntab,
+                                                      float log2r0, float invDlog2, double amp, float sign, double amp2,
+                                                      float sign2) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     if (x >= W) return;
     const double rlast = r[ntab - 1];
@@ -318,13 +324,15 @@ __global__ void __launch_bounds__(256) k_paint_radial(float* __restrict__ out, i
     for (int y = blockIdx.y; y < H; y += gridDim.y) {
         double h = __dadd_rn(A[y], __dmul_rn(B[y], cx));
         double th = theta_from_hav(h);
-        double val;
+        double val, val2 = 0.0;
         if (th < rfirst) {
             val = prof[0];
+            if (DUAL) val2 = prof2[0];
         } else if (th > rlast) {
             val = 0.0;
         } else if (th == rlast) {
             val = prof[ntab - 1];
+            if (DUAL) val2 = prof2[ntab - 1];
         } else {
             // interval index from a float32 log2 (the table is log-uniform); the two loops below make it exact
             int j = (int)((__log2f((float)th) - log2r0) * invDlog2);
@@ -332,11 +340,20 @@ __global__ void __launch_bounds__(256) k_paint_radial(float* __restrict__ out, i
             if (j > ntab - 2) j = ntab - 2;
             while (j > 0 && r[j] > th) --j;
             while (j < ntab - 2 && r[j + 1] <= th) ++j;
+            const double dr = __dsub_rn(th, r[j]);
             const double sl = slope != nullptr ? slope[j] : __ddiv_rn(__dsub_rn(prof[j + 1], prof[j]), __dsub_rn(r[j + 1], r[j]));
-            val = __dadd_rn(__dmul_rn(sl, __dsub_rn(th, r[j])), prof[j]);
+            val = __dadd_rn(__dmul_rn(sl, dr), prof[j]);
+            if (DUAL) {
+                const double sl2 = slope2 != nullptr ? slope2[j] : __ddiv_rn(__dsub_rn(prof2[j + 1], prof2[j]), __dsub_rn(r[j + 1], r[j]));
+                val2 = __dadd_rn(__dmul_rn(sl2, dr), prof2[j]);
+            }
         }
         float v = (float)__dmul_rn(amp, val);
         out[(long long)y * W + x] = (sign < 0.0f) ? v * -1.0f : v;
+        if (DUAL) {
+            float v2 = (float)__dmul_rn(amp2, val2);
+            out2[(long long)y * W + x] = (sign2 < 0.0f) ? v2 * -1.0f : v2;
+        }
     }
 }
 
@@ -344,13 +361,24 @@ int paint_radial(float* out, int H, int W, const double* A, const double* B, con
                  const double* prof, const double* slope, int ntab, double r0, double dlnr, double amp, double sign,
                  hipStream_t s) {
     const int gy = H < 1024 ? H : 1024;
-    hipLaunchKernelGGL(k_paint_radial, dim3((W + 255) / 256, gy), dim3(256), 0, s, out, H, W, A, B, C, r, prof, slope, ntab,
-                       (float)(log(r0) / log(2.0)), (float)(1.0 / (dlnr / log(2.0))), amp, (float)sign);
+    hipLaunchKernelGGL(k_paint_radial<false>, dim3((W + 255) / 256, gy), dim3(256), 0, s, out, (float*)nullptr, H, W, A, B, C, r, prof,
+                       slope, (const double*)nullptr, (const double*)nullptr, ntab, (float)(log(r0) / log(2.0)),
+                       (float)(1.0 / (dlnr / log(2.0))), amp, (float)sign, 0.0, 1.0f);
     NF_CHECK_LAUNCH("k_paint_radial");
     return NF_OK;
 }
 
-// ---------------------------------------------------------------------------------------------------
+int paint_radial2(float* out, float* out2, int H, int W, const double* A, const double* B, const double* C, const double* r,
+                  const double* prof, const double* slope, const double* prof2, const double* slope2, int ntab, double r0,
+                  double dlnr, double amp, double sign, double amp2, double sign2, hipStream_t s) {
+    const int gy = H < 1024 ? H : 1024;
+    hipLaunchKernelGGL(k_paint_radial<true>, dim3((W + 255) / 256, gy), dim3(256), 0, s, out, out2, H, W, A, B, C, r, prof, slope,
+                       prof2, slope2, ntab, (float)(log(r0) / log(2.0)), (float)(1.0 / (dlnr / log(2.0))), amp, (float)sign, amp2,
+                       (float)sign2);
+    NF_CHECK_LAUNCH("k_paint_radial");
+    return NF_OK;
+}
+
 // filtered(VT) = float32 map * signalNorm * psMask.  VT = double when signalNorm is a float64 scalar
 // ('yc' mode under numpy >= 2 promotion), float when it is a float32 scalar ('uK' mode).
 template <typename VT>

@@ -23,12 +23,22 @@ def torch():
     return _torch
 
 
+_device = None       # (torch.device, index) once a HIP device and the library have been found: one process drives one GPU
+
+
 def require_gpu():
+    """The HIP device of this process; raises when there is none (no CPU fallback).  Checked once, then cached: this is
+    called from every tensor hand-over, and the availability probe alone costs microseconds of interpreter time."""
+    global _device
+    if _device is not None:
+        return _device[0]
     t = torch()
     if not t.cuda.is_available():
         raise NemoFiltError("no HIP device visible: nemo_amd runs on MI355X (gfx950) only and has no CPU fallback")
     _lib.load()
-    return t.device('cuda', t.cuda.current_device())
+    idx = t.cuda.current_device()
+    _device = (t.device('cuda', idx), idx)
+    return _device[0]
 
 
 def gpu_ready():
@@ -62,7 +72,11 @@ def xmatch_self(RADeg, decDeg, SNR, radiusDeg):
 
 
 def stream_ptr():
-    return ctypes.c_void_p(torch().cuda.current_stream().cuda_stream)
+    """The current HIP stream of the calling thread as a void* (raw handle: no Stream object is built)."""
+    t = torch()
+    if _device is None:
+        require_gpu()
+    return ctypes.c_void_p(t._C._cuda_getCurrentRawStream(_device[1]))
 
 
 def ptr(t):
@@ -114,6 +128,13 @@ def gaussian_kernel1d(sigma, truncate=4.0):
 
 
 _EDGE_SEL = os.environ.get('NEMO_AMD_SPLINE_EDGESEL', '0') != '0'    # measured: no gain on the C2 bench
+
+
+class _SplinePoints(object):
+    __slots__ = ('dev', 'n', 'pointsClass', 'halfWin')
+
+    def __init__(self, dev, n, pointsClass, halfWin):
+        self.dev, self.n, self.pointsClass, self.halfWin = dev, n, pointsClass, halfWin
 
 
 class DeviceScalar(object):
@@ -168,6 +189,7 @@ class TileEngine(object):
         self._win = {}
         self._gauss = {}
         self._geom = {}
+        self._geomLast = None
         self._geom2 = {}
 
     # ---- tables --------------------------------------------------------------------------------------------
@@ -342,18 +364,46 @@ class TileEngine(object):
         return self.ifft(F, out='f64' if m.dtype == self.t.float64 else 'f32', unitary=True, clobber=True, window=pow, half=True)
 
     # ---- templates -----------------------------------------------------------------------------------------
+    def _tableDev(self, table):
+        if not hasattr(table, '_dev'):
+            # radii, profile and slopes in ONE upload (three views of it): every upload is host time on the enqueueing thread
+            r_, p_ = np.asarray(table.r, dtype=np.float64), np.asarray(table.prof, dtype=np.float64)
+            n_ = len(r_)
+            packed = to_dev(np.concatenate([r_, p_, (p_[1:] - p_[:-1]) / (r_[1:] - r_[:-1])]))
+            table._dev = (packed[:n_], packed[n_:2 * n_], packed[2 * n_:])
+        return table._dev
+
+    def _geomDev(self, geom):
+        # the device copy is kept for the tables last seen: the same tuple object (every scale of a tile) costs one identity
+        # test, anything else is compared by content
+        if self._geomLast is not None and self._geomLast[0] is geom:
+            return self._geomLast[1]
+        g64 = tuple(np.ascontiguousarray(g, dtype=np.float64) for g in geom)
+        key = hash(b"".join(g.tobytes() for g in g64))
+        if key not in self._geom:
+            self._geom = {key: tuple(to_dev(g) for g in g64)}
+        self._geomLast = (geom, self._geom[key])
+        return self._geom[key]
+
+    def paint2(self, geom, table, table2):
+        """Two float32 templates [2, H, W] on the same radii in one pass (nf_paint_radial2)."""
+        t = self.t
+        if len(table.r) != len(table2.r) or table.r0 != table2.r0 or table.dlnr != table2.dlnr:
+            raise NemoFiltError("paint2: the two tables must share their radii")
+        A, B, C = self._geomDev(geom)
+        r, prof, slope = self._tableDev(table)
+        r2, prof2, slope2 = self._tableDev(table2)
+        out = t.empty((2, self.H, self.W), dtype=t.float32, device=self.dev)
+        check(self.lib.nf_paint_radial2(ptr(out[0]), ptr(out[1]), self.H, self.W, ptr(A), ptr(B), ptr(C), ptr(r), ptr(prof),
+                                        ptr(slope), ptr(prof2), ptr(slope2), len(table.r), table.r0, table.dlnr, table.amp,
+                                        table.sign, table2.amp, table2.sign, stream_ptr()), "nf_paint_radial2")
+        return out
+
     def paint(self, geom, table):
         """float32 template from a signals.RadialTable and the (A, B, C) haversine tables."""
         t = self.t
-        geom = tuple(np.ascontiguousarray(g, dtype=np.float64) for g in geom)
-        key = hash(b"".join(g.tobytes() for g in geom))
-        if key not in self._geom:
-            self._geom = {key: tuple(to_dev(g) for g in geom)}
-        A, B, C = self._geom[key]
-        if not hasattr(table, '_dev'):
-            r_, p_ = np.asarray(table.r, dtype=np.float64), np.asarray(table.prof, dtype=np.float64)
-            table._dev = (to_dev(r_), to_dev(p_), to_dev((p_[1:] - p_[:-1]) / (r_[1:] - r_[:-1])))
-        r, prof, slope = table._dev
+        A, B, C = self._geomDev(geom)
+        r, prof, slope = self._tableDev(table)
         out = t.empty((self.H, self.W), dtype=t.float32, device=self.dev)
         check(self.lib.nf_paint_radial(ptr(out), self.H, self.W, ptr(A), ptr(B), ptr(C), ptr(r), ptr(prof), ptr(slope), len(table.r),
                                        table.r0, table.dlnr, table.amp, table.sign, stream_ptr()), "nf_paint_radial")
@@ -464,10 +514,51 @@ class TileEngine(object):
         return sn
 
     def undo_pixel_window(self, data):
-        """filterMaps' last step (nemo/filters.py:98-101)."""
-        out = self.apply_window(data, -1.0)
-        check(self.lib.nf_restore_zeros(prec_of(data), ptr(out), ptr(data), self.npix, stream_ptr()), "nf_restore_zeros")
-        return out
+        """filterMaps' last step (nemo/filters.py:98-101): apply_window(data, -1), zeros of ``data`` kept (restored while the
+        inverse transform stores its rows)."""
+        F = self.fft(data, unitary=True, half=True)
+        return self.ifft_half_epi(F, window=-1.0, unitary=True, out='f64' if data.dtype == self.t.float64 else 'f32',
+                                  zero_ref=data, clobber=True)
+
+    def ifft_half_epi(self, X, filtSym=None, sum=False, window=None, unitary=False, out='f32', scale=None, mask=None,
+                      zero_ref=None, clobber=False):
+        """nf_fft2_inverse_half_epi: inverse transform of half-stored spectra into ONE real map with the pointwise steps that
+        follow on the path fused into the store: ``scale`` (DeviceScalar or numpy scalar: float32(map) * scale, in float64
+        if the scalar is wide, else float32 - then ``out`` follows the scalar) and ``mask`` (uint8), and / or ``zero_ref``."""
+        t = self.t
+        X3 = X.reshape(-1, self.H, self.W)
+        N = X3.shape[0]
+        if not sum and N != 1:
+            raise NemoFiltError("ifft_half_epi makes one map: one plane, or sum=True")
+        f3 = None
+        if filtSym is not None:
+            f3 = filtSym.reshape(-1, self.H, self.W)
+            if f3.dtype == t.float32:
+                f3 = self.symmetrise_filter(f3)
+            if f3.dtype != t.float64 or not f3.is_contiguous() or f3.shape[0] != N:
+                raise NemoFiltError("ifft_half_epi: the filter must be symmetrised float64 planes, one per Fourier plane")
+        wy = wx = None
+        if window is not None:
+            wy, wx = self.window(window)
+        sc = None
+        if scale is not None:
+            if not isinstance(scale, DeviceScalar):
+                wide = isinstance(scale, np.float64)
+                v = float(scale) if wide else float(np.float32(scale))
+                scale = DeviceScalar(to_dev(np.array([v], dtype=np.float64)), wide=wide)
+            sc = scale.tensor
+            out = 'f64' if scale.wide else 'f32'
+        if mask is not None and (mask.dtype != t.uint8 or not mask.is_contiguous()):
+            raise NemoFiltError("ifft_half_epi: the mask must be a contiguous uint8 map")
+        odt = t.float64 if out == 'f64' else t.float32
+        if zero_ref is not None and (zero_ref.dtype != odt or not zero_ref.is_contiguous()):
+            raise NemoFiltError("ifft_half_epi: zero_ref must be a contiguous map of the output dtype")
+        work = X3 if clobber else t.empty((1, self.H, self.W), dtype=X3.dtype, device=self.dev)
+        res = t.empty((self.H, self.W), dtype=odt, device=self.dev)
+        check(self.lib.nf_fft2_inverse_half_epi(self.plan, prec_of(X3), ptr(X3), ptr(f3), N, ptr(wy), ptr(wx), ptr(work), ptr(res),
+                                                IN_REAL64 if out == 'f64' else IN_REAL32, 1 if unitary else 0, ptr(sc), ptr(mask),
+                                                ptr(zero_ref), stream_ptr()), "nf_fft2_inverse_half_epi")
+        return res
 
     def subtract_background(self, data, sigmaYX):
         """maps.subtractBackground (nemo/maps.py:1279-1292)."""
@@ -521,8 +612,24 @@ class TileEngine(object):
         res = out[:2].cpu().numpy()
         return res[0], int(res[1])
 
+    def spline_points(self, yx, halfWin=32):
+        """Evaluation points uploaded once, for several spline_eval calls at the same positions (different maps)."""
+        yx = np.ascontiguousarray(np.asarray(yx, dtype=np.float64).reshape(-1, 2))
+        iy, ix = np.floor(yx[:, 0]), np.floor(yx[:, 1])
+        interior = (iy - halfWin - 1 >= 0) & (iy + halfWin + 2 <= self.H - 1) & (ix - halfWin - 1 >= 0) & \
+            (ix + halfWin + 2 <= self.W - 1) & (yx[:, 0] >= 0) & (yx[:, 0] <= self.H - 1) & (yx[:, 1] >= 0) & (yx[:, 1] <= self.W - 1)
+        pointsClass = 1 if interior.all() else (2 if not interior.any() else 0)
+        return _SplinePoints(to_dev(yx) if len(yx) > 0 else None, len(yx), pointsClass, halfWin)
+
     def spline_eval(self, m, yx, negate=False, halfWin=32, to_host=True):
         t = self.t
+        if isinstance(yx, _SplinePoints):
+            if yx.n == 0:
+                return np.zeros(0)
+            out = t.empty(yx.n, dtype=t.float64, device=self.dev)
+            check(self.lib.nf_spline_eval(prec_of(m), ptr(m), 1 if negate else 0, self.H, self.W, ptr(yx.dev), yx.n, yx.halfWin,
+                                          yx.pointsClass, None, 0, ptr(out), stream_ptr()), "nf_spline_eval")
+            return out.cpu().numpy() if to_host else out
         yx = np.ascontiguousarray(np.asarray(yx, dtype=np.float64).reshape(-1, 2))
         if len(yx) == 0:
             return np.zeros(0)

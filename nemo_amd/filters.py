@@ -232,11 +232,31 @@ class MapFilter(object):
         """Device float32 template centred on the tile centre (template mixins, nemo/filters.py:1214-1266)."""
         if self.templateKind is None:
             raise Exception("Called a base filter class without a makeSignalTemplateMap() function implemented.")
-        if self._geom is None:
-            RADeg, decDeg = self.wcs.getCentreWCSCoords()
-            self._geom = signals.paintGeometry(self.shape, self.wcs, RADeg, decDeg)
+        self._ensureGeom()
         table = signals.templateTables(self.templateKind, self._beamOf(beamFileName), self.params, amplitude=amplitude)
         return self.engine.paint(self._geom, table)
+
+    def _ensureGeom(self):
+        if self._geom is None:
+            # the haversine tables of the tile centre are the same for every filter scale of the tile
+            shared = self._shared
+            if shared is not None and 'paintGeom' in shared:
+                self._geom = shared['paintGeom']
+            else:
+                RADeg, decDeg = self.wcs.getCentreWCSCoords()
+                self._geom = signals.paintGeometry(self.shape, self.wcs, RADeg, decDeg)
+                if shared is not None:
+                    shared['paintGeom'] = self._geom
+
+    def _paintTemplatePair(self, beamFileName, amplitude):
+        """The unit template and the amplitude-scaled one, float32 [2, H, W], painted in one pass."""
+        if self.templateKind is None:
+            raise Exception("Called a base filter class without a makeSignalTemplateMap() function implemented.")
+        self._ensureGeom()
+        beam = self._beamOf(beamFileName)
+        t1 = signals.templateTables(self.templateKind, beam, self.params, amplitude=None)
+        t2 = signals.templateTables(self.templateKind, beam, self.params, amplitude=amplitude)
+        return self.engine.paint2(self._geom, t1, t2)
 
     def makeSignalTemplateMap(self, beamFileName, amplitude=None):
         out = self._paintTemplate(beamFileName, amplitude=amplitude)
@@ -370,26 +390,29 @@ class MatchedFilter(MapFilter):
                     shared[('noiseCov', method)] = noiseCov
 
             w = self._frequencyWeights()                                          # :587-608
-            fSignals = [eng.fft(self._paintTemplate(m['beamFileName']), half=True) for m in self.unfilteredMapsDictList]   # :611-618
+            y0 = 2e-4
+            fSignalMaps = None
+            if self.params['outputUnits'] == 'yc':
+                # the unit templates (:611-618) and the amplitude-scaled ones of the normalisation (:639-646) are painted
+                # and transformed pairwise: one painter pass, one two-plane transform
+                fSignals, fSignalMaps = [], []
+                for mapDict in self.unfilteredMapsDictList:
+                    amp = y0 if mapDict['units'] == 'yc' else maps.convertToDeltaT(y0, mapDict['obsFreqGHz'])
+                    F2 = eng.fft(self._paintTemplatePair(mapDict['beamFileName'], amp), half=True)
+                    fSignals.append(F2[0])
+                    fSignalMaps.append(F2[1])
+                fSignalMaps = t.stack(fSignalMaps) if N > 1 else fSignalMaps[0].reshape(1, *self.shape)
+            else:
+                fSignals = [eng.fft(self._paintTemplate(m['beamFileName']), half=True) for m in self.unfilteredMapsDictList]   # :611-618
             fSignals = t.stack(fSignals) if N > 1 else fSignals[0].reshape(1, *self.shape)
             self._dFilt = eng.build_filter(noiseCov, fSignals, w, half=True)              # :621-627  K6
             del noiseCov
 
             if self.params['outputUnits'] == 'yc':                                # :632-668
-                y0 = 2e-4
                 # The reference pushes the amplitude-scaled template through enmap.apply_window (FFT . W . IFFT, :644)
                 # and transforms it again (:646).  FFT(template) . W is Hermitian, so that inverse / forward pair is the
                 # identity up to float32 round-off: here the window is multiplied into the spectrum directly, together
                 # with the filter, while the inverse transform of :847 loads it.
-                fSignalMaps = []
-                for mapDict in self.unfilteredMapsDictList:
-                    if mapDict['units'] == 'yc':
-                        signalMap = self._paintTemplate(mapDict['beamFileName'], amplitude=y0)
-                    else:
-                        deltaT0 = maps.convertToDeltaT(y0, mapDict['obsFreqGHz'])
-                        signalMap = self._paintTemplate(mapDict['beamFileName'], amplitude=deltaT0)
-                    fSignalMaps.append(eng.fft(signalMap, half=True))                      # :644-646  K8
-                fSignalMaps = t.stack(fSignalMaps) if N > 1 else fSignalMaps[0].reshape(1, *self.shape)
                 filteredSignal = self._applyFilterDevice(fSignalMaps, window=1.0, half=True)
                 cRADeg, cDecDeg = self.wcs.getCentreWCSCoords()
                 cx, cy = self.wcs.wcs2pix(cRADeg, cDecDeg)
@@ -427,10 +450,16 @@ class MatchedFilter(MapFilter):
             self.params['savePlots'] = False
 
         # Apply filter (:696), point-source mask (:714)
-        filtered32 = self._applyFilterDevice(fMapsToFilter, scale=False, half=True)
+        bckSub = 'bckSub' in self.params.keys() and 'bckSubScaleArcmin' in self.params.keys() and self.params['bckSub'] == True
+        if not bckSub and tuple(fMapsToFilter.shape[-2:]) == self.shape:
+            # the float32 cast, the signalNorm product and the mask are applied while the inverse transform stores its rows
+            dFiltered = eng.ifft_half_epi(fMapsToFilter.reshape(-1, *self.shape), filtSym=self._filtFor(True), sum=True,
+                                          scale=self._signalNorm, mask=self._dPSMask)
+        else:
+            filtered32 = self._applyFilterDevice(fMapsToFilter, scale=False, half=True)
+            dFiltered = eng.scale_mask(filtered32, self._signalNorm, self._dPSMask)
         del fMapsToFilter
         mapUnits, combinedObsFreqGHz, beamSolidAngle_nsr = self._unitsInfo()
-        dFiltered = eng.scale_mask(filtered32, self._signalNorm, self._dPSMask)
 
         if 'edgeTrimArcmin' in self.params.keys() and self.params['edgeTrimArcmin'] > 0:      # :725-733
             trimSizePix = int(round((self.params['edgeTrimArcmin'] / 60.) / self.wcs.getPixelSizeDeg()))

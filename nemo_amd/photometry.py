@@ -194,10 +194,11 @@ def findObjects(filteredMapDict, threshold=3.0, minObjPix=3, rejectBorder=10, fi
         if inside.any():
             yy = np.clip(y2[inside], 0.0, H - 1.0)
             xx = np.clip(x2[inside], 0.0, W - 1.0)
+            pts = eng.spline_points(np.stack([yy, xx], axis=1)) if useInterpolator else None     # one upload for all maps
             for k, (mapLike, neg) in enumerate(_prefetch):
                 d = engine.to_dev(mapLike)
                 if useInterpolator:
-                    queued.append(('pre%d' % k, eng.spline_eval(d, np.stack([yy, xx], axis=1), negate=neg, to_host=False)))
+                    queued.append(('pre%d' % k, eng.spline_eval(d, pts, negate=neg, to_host=False)))
                 else:
                     queued.append(('pre%d' % k, _lookupDev(d, np.clip(np.round(yy).astype(np.int64), 0, H - 1),
                                                            np.clip(np.round(xx).astype(np.int64), 0, W - 1)) * (-1.0 if neg else 1.0)))

@@ -118,6 +118,19 @@ def _loadCachedRMSMap(config, tileName, photFilter):
     raise Exception("useCachedRMSMap: no RMS map of filter '%s' for tile '%s' (run the pipeline once without it)" % (photFilter, tileName))
 
 
+_workers = {}
+
+
+def _detectionWorkers(numWorkers):
+    """The detection thread pool and its streams, made once per process and worker count.  A new stream per call would
+    strand the device memory cached for the old one (the allocator keeps one pool per stream), and costs device
+    allocations on every call."""
+    if numWorkers not in _workers:
+        _workers[numWorkers] = (concurrent.futures.ThreadPoolExecutor(max_workers=numWorkers,
+                                                                      thread_name_prefix="nemo-amd-detect"), _WorkerStreams())
+    return _workers[numWorkers]
+
+
 class _WorkerStreams(object):
     """One HIP stream per detection worker thread, made when the thread first asks."""
 
@@ -260,8 +273,7 @@ def _filterMapsAndMakeCatalogs(config, rootOutDir=None, useCachedFilters=False, 
         # detection workers, each with a HIP stream of its own (scales are independent of each other: with two, the host
         # round trips of one scale's detection overlap the next one's)
         numWorkers = max(1, int(os.environ.get('NEMO_AMD_ASYNC_WORKERS', config.parDict.get('asyncWorkers', 1))))
-        pool = concurrent.futures.ThreadPoolExecutor(max_workers=numWorkers)
-        detStream = _WorkerStreams()
+        pool, detStream = _detectionWorkers(numWorkers)
     try:
         for tileName in config.tileNames:
             if verbose == True:
@@ -335,8 +347,8 @@ def _filterMapsAndMakeCatalogs(config, rootOutDir=None, useCachedFilters=False, 
             del tileCache
     finally:
         filters.RETURN_DEVICE_ARRAYS = keepDevice
-        if pool is not None:
-            pool.shutdown(wait=True)
+        for label, fut in pending:        # (only after an exception: let the worker finish with the maps it holds)
+            fut.cancel()
 
     marks.append(('pool closed', time.perf_counter()))
     optimalCatalog = catalogs.makeOptimalCatalog(catalogDict, constraintsList=config.parDict['catalogCuts'],

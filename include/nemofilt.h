@@ -249,6 +249,9 @@ int nf_spline_eval(int vtype, const void* map_d, int negate, int H, int W, const
  * their summed device time (ms) and their summed algorithmic HBM bytes (inputs read once + outputs written once).
  * Tags 0..nf_profile_num_tags()-1 are named by nf_profile_tag_name (fft_rows_f64, fft_cols_f64, ..., spline_eval). */
 int nf_profile_enable(int on);
+/* restrict the recording to the entry points whose tag bit is set (default: all).  An event pair costs a few microseconds of
+ * queue time; a throughput run that only needs one entry point's timing records only that one. */
+int nf_profile_select(unsigned long long tagMask);
 int nf_profile_num_tags(void);
 const char* nf_profile_tag_name(int tag);
 int nf_profile_read(int tag, long long* count, double* totalMs, double* totalBytes);

@@ -78,6 +78,7 @@ SIGNATURES = {
     'nf_map_max': (c_int, [c_int, c_void_p, c_ll, c_void_p, c_void_p]),
     'nf_ring_flags': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     'nf_profile_enable': (c_int, [c_int]),
+    'nf_profile_select': (c_int, [ctypes.c_ulonglong]),
     'nf_profile_num_tags': (c_int, []),
     'nf_profile_tag_name': (ctypes.c_char_p, [c_int]),
     'nf_profile_read': (c_int, [c_int, ctypes.POINTER(c_ll), ctypes.POINTER(c_double), ctypes.POINTER(c_double)]),

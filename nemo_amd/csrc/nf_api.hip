@@ -29,6 +29,7 @@ struct ProfRec {
 };
 const int kProfMax = 1 << 16;
 bool g_profOn = false;
+unsigned long long g_profMask = ~0ULL;      // entry points (tags) that record events while profiling is on
 std::mutex g_profMu;
 std::vector<ProfRec> g_profRecs;       // used records [0, g_profUsed)
 int g_profUsed = 0;
@@ -39,7 +40,7 @@ const char* kProfNames[nf::PT_COUNT] = {
 }  // namespace
 
 nf::ProfScope::ProfScope(int tag, hipStream_t s, double bytes) : slot(-1), stream(s) {
-    if (!g_profOn) return;
+    if (!g_profOn || !((g_profMask >> tag) & 1ULL)) return;
     std::lock_guard<std::mutex> lock(g_profMu);
     if (g_profUsed >= kProfMax) return;
     if (g_profUsed >= (int)g_profRecs.size()) {
@@ -117,6 +118,12 @@ int nf_profile_enable(int on) {
     std::lock_guard<std::mutex> lock(g_profMu);
     g_profOn = on != 0;
     g_profUsed = 0;
+    return NF_OK;
+}
+
+int nf_profile_select(unsigned long long tagMask) {
+    std::lock_guard<std::mutex> lock(g_profMu);
+    g_profMask = tagMask;
     return NF_OK;
 }
 

@@ -1197,16 +1197,17 @@ __device__ __forceinline__ void window_sums(const VT* __restrict__ v, int W, con
                 if (tc == 0) continue;
                 const bool coreB = (coreMask >> b) & 1ULL;
                 const double* __restrict__ tp = ws.tails + L.tailOff[b];
-                for (int e0 = 0; e0 < tc; e0 += 256) {
-                    double tv[4];
+                for (int e0 = 0; e0 < tc; e0 += 512) {
+                    double tv[8];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
+                    for (int u = 0; u < 8; ++u) {
                         const int e = e0 + u * 64 + lane;
                         tv[u] = tp[e < tc ? e : 0];
                     }
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
+                    for (int u = 0; u < 8; ++u) {
                         const int e = e0 + u * 64 + lane;
+                        if (e0 + u * 64 >= tc) break;           // uniform
                         const double t = tv[u];
                         const bool below = e < tc && fabs(t) < thr;
                         if (below && coreB) {

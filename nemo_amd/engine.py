@@ -30,9 +30,13 @@ def require_gpu():
     """The HIP device of this process; raises when there is none (no CPU fallback).  Checked once, then cached: this is
     called from every tensor hand-over, and the availability probe alone costs microseconds of interpreter time."""
     global _device
-    if _device is not None:
-        return _device[0]
     t = torch()
+    if _device is not None:
+        if t._C._cuda_getDevice() == _device[1]:      # (a raw call: ~0.1 us; follows a later torch.cuda.set_device)
+            return _device[0]
+        idx = t._C._cuda_getDevice()
+        _device = (t.device('cuda', idx), idx)
+        return _device[0]
     if not t.cuda.is_available():
         raise NemoFiltError("no HIP device visible: nemo_amd runs on MI355X (gfx950) only and has no CPU fallback")
     _lib.load()
@@ -74,8 +78,7 @@ def xmatch_self(RADeg, decDeg, SNR, radiusDeg):
 def stream_ptr():
     """The current HIP stream of the calling thread as a void* (raw handle: no Stream object is built)."""
     t = torch()
-    if _device is None:
-        require_gpu()
+    require_gpu()
     return ctypes.c_void_p(t._C._cuda_getCurrentRawStream(_device[1]))
 
 

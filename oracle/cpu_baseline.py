@@ -22,6 +22,8 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--size", type=int, default=1536)
+    ap.add_argument("--faithful", action="store_true",
+                    help="per-mode inverse by the reference's own Python double loop (nemo/filters.py:622-627)")
     args = ap.parse_args()
     import numpy as np
     import helpers
@@ -32,11 +34,11 @@ def main():
     params = {'noiseParams': {'method': 'dataMap', 'noiseGridArcmin': 40.0}, 'outputUnits': 'yc', 'z': 0.4,
               'M500MSun': 2.0e14, 'edgeTrimArcmin': 0.0}
     t0 = time.perf_counter()
-    ref, omf = helpers.oracle_matched(mapsL, wcs, params, 'arnaud')
+    ref, omf = helpers.oracle_matched(mapsL, wcs, params, 'arnaud', faithfulLoop=args.faithful)
     ofilt.undo_pixel_window(ref['data'])
     cat = helpers.oracle_find(ref['SNMap'], np.zeros(shape, dtype=int), wcs, threshold=4.0, minObjPix=1)
     dt = time.perf_counter() - t0
-    print(json.dumps({"seconds": dt, "objects": len(cat), "size": args.size}))
+    print(json.dumps({"seconds": dt, "objects": len(cat), "size": args.size, "faithful": bool(args.faithful)}))
 
 
 if __name__ == "__main__":

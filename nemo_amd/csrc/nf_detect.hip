@@ -619,7 +619,9 @@ int spline_eval(int vtype, const void* map, int negate, int H, int W, const doub
 #define NF_XM_THREADS 64
 
 __device__ __forceinline__ int xm_relation(double ax, double ay, double az, double bx, double by, double bz, double lo2, double hi2) {
-    const double dx = ax - bx, dy = ay - by, dz = az - bz;
+    const double dz = az - bz;
+    if (dz * dz > hi2) return 0;          // most rows differ by more than the radius in declination alone
+    const double dx = ax - bx, dy = ay - by;
     const double c2 = dx * dx + dy * dy + dz * dz;
     return c2 < lo2 ? 1 : (c2 <= hi2 ? 2 : 0);
 }

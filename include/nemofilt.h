@@ -223,9 +223,11 @@ int nf_map_max(int vtype, const void* map_d, long long n, double* out_d, void* s
  * (chord test; a row is its own partner).  count_d[i] = partners of row i; best_d[i] = the first partner with the highest
  * SNR (np.argmax over the partner list, first partner if any SNR is NaN); drop_d[j] = 1 if a partner with several partners
  * prefers another row to j (the rows the reference removes).  *nearFlag_d = 1 if any chord lies within 1e-9 of the limit:
- * the caller must then decide with the exact great-circle formula (the host implementation does). */
+ * the caller must then decide with the exact great-circle formula (the host implementation does).  work_d:
+ * nf_xmatch_workspace_bytes(n) bytes of device scratch (per-slice partial results). */
+size_t nf_xmatch_workspace_bytes(int n);
 int nf_xmatch_self(const double* unit_d, const double* snr_d, int n, double radiusDeg, int* count_d, int* best_d,
-                   unsigned char* drop_d, int* nearFlag_d, void* stream);
+                   unsigned char* drop_d, int* nearFlag_d, void* work_d, size_t workBytes, void* stream);
 
 /* nemo/photometry.py:69-73: isRing_d[id] = 1 if component id has > minRingPix pixels and its centre of mass is
  * not one of its own pixels. */

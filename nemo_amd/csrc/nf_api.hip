@@ -543,15 +543,17 @@ int nf_object_stats(int vtype, const void* sn, int negate, const int* labels, in
     return nf::object_stats(vtype, sn, negate, labels, H, W, numObjects, stats, S(stream));
 }
 
+size_t nf_xmatch_workspace_bytes(int n) { return n > 0 ? nf::xmatch_workspace_bytes(n) : 0; }
+
 int nf_xmatch_self(const double* unit_d, const double* snr_d, int n, double radiusDeg, int* count_d, int* best_d,
-                   unsigned char* drop_d, int* nearFlag_d, void* stream) {
-    if (!unit_d || !snr_d || !count_d || !best_d || !drop_d || !nearFlag_d || n < 1 || !(radiusDeg > 0.0)) {
+                   unsigned char* drop_d, int* nearFlag_d, void* work_d, size_t workBytes, void* stream) {
+    if (!unit_d || !snr_d || !count_d || !best_d || !drop_d || !nearFlag_d || !work_d || n < 1 || !(radiusDeg > 0.0)) {
         nf_set_error("nf_xmatch_self: bad arguments");
         return NF_ERR_ARG;
     }
     const double lim = 2.0 * std::sin(radiusDeg * 3.14159265358979323846 / 180.0 / 2.0);
     const double lo = lim * (1.0 - 1e-9), hi = lim * (1.0 + 1e-9);
-    return nf::xmatch_self(unit_d, snr_d, n, lo * lo, hi * hi, count_d, best_d, drop_d, nearFlag_d, S(stream));
+    return nf::xmatch_self(unit_d, snr_d, n, lo * lo, hi * hi, count_d, best_d, drop_d, nearFlag_d, work_d, workBytes, S(stream));
 }
 
 int nf_map_max(int vtype, const void* map, long long n, double* out, void* stream) {

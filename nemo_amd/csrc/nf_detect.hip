@@ -626,25 +626,34 @@ __device__ __forceinline__ int xm_relation(double ax, double ay, double az, doub
     return c2 < lo2 ? 1 : (c2 <= hi2 ? 2 : 0);
 }
 
-__global__ void __launch_bounds__(NF_XM_THREADS) k_xmatch_best(const double* __restrict__ u, const double* __restrict__ snr, int n,
-                                                                double lo2, double hi2, int* __restrict__ count,
-                                                                int* __restrict__ best, int* __restrict__ nearFlag) {
+#define NF_XM_SLICES 16      // the partner loop of every row is cut into this many slices (blockIdx.y): 16 x more wavefronts
+
+struct XmPart {          // partners of one row inside one slice
+    int cnt, first, best, sawNaN;
+    double mx;
+};
+
+__global__ void __launch_bounds__(NF_XM_THREADS) k_xmatch_best_part(const double* __restrict__ u, const double* __restrict__ snr, int n,
+                                                                     double lo2, double hi2, XmPart* __restrict__ part,
+                                                                     int* __restrict__ nearFlag) {
     __shared__ double sx[NF_XM_THREADS], sy[NF_XM_THREADS], sz[NF_XM_THREADS], ss[NF_XM_THREADS];
     const int i = blockIdx.x * NF_XM_THREADS + threadIdx.x;
     const bool live = i < n;
     const double ax = live ? u[3 * i] : 0.0, ay = live ? u[3 * i + 1] : 0.0, az = live ? u[3 * i + 2] : 2.0;
+    const int per = ((n + NF_XM_SLICES - 1) / NF_XM_SLICES + NF_XM_THREADS - 1) / NF_XM_THREADS * NF_XM_THREADS;
+    const int jBeg = blockIdx.y * per, jEnd = min(n, jBeg + per);
     int cnt = 0, bst = -1, first = -1;
     double mx = 0.0;
     bool sawNaN = false, near = false;
-    for (int j0 = 0; j0 < n; j0 += NF_XM_THREADS) {
+    for (int j0 = jBeg; j0 < jEnd; j0 += NF_XM_THREADS) {
         const int jl = j0 + threadIdx.x;
         __syncthreads();
-        sx[threadIdx.x] = jl < n ? u[3 * jl] : 0.0;
-        sy[threadIdx.x] = jl < n ? u[3 * jl + 1] : 0.0;
-        sz[threadIdx.x] = jl < n ? u[3 * jl + 2] : -2.0;     // out of range: further than any chord from every row
-        ss[threadIdx.x] = jl < n ? snr[jl] : 0.0;
+        sx[threadIdx.x] = jl < jEnd ? u[3 * jl] : 0.0;
+        sy[threadIdx.x] = jl < jEnd ? u[3 * jl + 1] : 0.0;
+        sz[threadIdx.x] = jl < jEnd ? u[3 * jl + 2] : -2.0;
+        ss[threadIdx.x] = jl < jEnd ? snr[jl] : 0.0;
         __syncthreads();
-        const int m = min(NF_XM_THREADS, n - j0);
+        const int m = min(NF_XM_THREADS, jEnd - j0);
         for (int k = 0; k < m; ++k) {
             const int rel = xm_relation(ax, ay, az, sx[k], sy[k], sz[k], lo2, hi2);
             if (rel == 2) near = true;
@@ -666,10 +675,41 @@ __global__ void __launch_bounds__(NF_XM_THREADS) k_xmatch_best(const double* __r
         }
     }
     if (live) {
-        count[i] = cnt;
-        best[i] = sawNaN ? first : bst;
+        XmPart p;
+        p.cnt = cnt;
+        p.first = first;
+        p.best = bst;
+        p.sawNaN = sawNaN ? 1 : 0;
+        p.mx = mx;
+        part[(long long)blockIdx.y * n + i] = p;
         if (near) atomicOr(nearFlag, 1);
     }
+}
+
+// slices in ascending partner order: the first slice with partners gives `first`; a later slice only takes `best` over with
+// a strictly higher SNR (np.argmax keeps the first maximum)
+__global__ void k_xmatch_merge(const XmPart* __restrict__ part, int n, int* __restrict__ count, int* __restrict__ best) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int cnt = 0, first = -1, bst = -1;
+    double mx = 0.0;
+    bool sawNaN = false;
+    for (int sl = 0; sl < NF_XM_SLICES; ++sl) {
+        const XmPart p = part[(long long)sl * n + i];
+        if (p.cnt == 0) continue;
+        cnt += p.cnt;
+        sawNaN = sawNaN || p.sawNaN != 0;
+        if (first < 0) {
+            first = p.first;
+            bst = p.best;
+            mx = p.mx;
+        } else if (p.mx > mx) {
+            mx = p.mx;
+            bst = p.best;
+        }
+    }
+    count[i] = cnt;
+    best[i] = sawNaN ? first : bst;
 }
 
 __global__ void __launch_bounds__(NF_XM_THREADS) k_xmatch_drop(const double* __restrict__ u, int n, double lo2, double hi2,
@@ -680,29 +720,39 @@ __global__ void __launch_bounds__(NF_XM_THREADS) k_xmatch_drop(const double* __r
     const int j = blockIdx.x * NF_XM_THREADS + threadIdx.x;
     const bool live = j < n;
     const double ax = live ? u[3 * j] : 0.0, ay = live ? u[3 * j + 1] : 0.0, az = live ? u[3 * j + 2] : 2.0;
+    const int per = ((n + NF_XM_SLICES - 1) / NF_XM_SLICES + NF_XM_THREADS - 1) / NF_XM_THREADS * NF_XM_THREADS;
+    const int iBeg = blockIdx.y * per, iEnd = min(n, iBeg + per);
     bool d = false;
-    for (int i0 = 0; i0 < n; i0 += NF_XM_THREADS) {
+    for (int i0 = iBeg; i0 < iEnd; i0 += NF_XM_THREADS) {
         const int il = i0 + threadIdx.x;
         __syncthreads();
-        sx[threadIdx.x] = il < n ? u[3 * il] : 0.0;
-        sy[threadIdx.x] = il < n ? u[3 * il + 1] : 0.0;
-        sz[threadIdx.x] = il < n ? u[3 * il + 2] : -2.0;
-        sc[threadIdx.x] = il < n ? count[il] : 0;
-        sb[threadIdx.x] = il < n ? best[il] : -1;
+        sx[threadIdx.x] = il < iEnd ? u[3 * il] : 0.0;
+        sy[threadIdx.x] = il < iEnd ? u[3 * il + 1] : 0.0;
+        sz[threadIdx.x] = il < iEnd ? u[3 * il + 2] : -2.0;
+        sc[threadIdx.x] = il < iEnd ? count[il] : 0;
+        sb[threadIdx.x] = il < iEnd ? best[il] : -1;
         __syncthreads();
-        const int m = min(NF_XM_THREADS, n - i0);
+        const int m = min(NF_XM_THREADS, iEnd - i0);
         for (int k = 0; k < m; ++k)
             if (sc[k] > 1 && sb[k] != j && xm_relation(ax, ay, az, sx[k], sy[k], sz[k], lo2, hi2) == 1) d = true;
     }
-    if (live) drop[j] = d ? 1 : 0;
+    if (live && d) drop[j] = 1;        // (every slice that finds a reason writes the same 1; cleared beforehand)
 }
 
+size_t xmatch_workspace_bytes(int n) { return (size_t)NF_XM_SLICES * (size_t)n * sizeof(XmPart); }
+
 int xmatch_self(const double* u, const double* snr, int n, double lo2, double hi2, int* count, int* best, unsigned char* drop,
-                int* nearFlag, hipStream_t s) {
+                int* nearFlag, void* work, size_t workBytes, hipStream_t s) {
+    if (workBytes < xmatch_workspace_bytes(n)) {
+        nf_set_error("xmatch_self: workspace too small");
+        return NF_ERR_SIZE;
+    }
     NF_HIP(hipMemsetAsync(nearFlag, 0, sizeof(int), s));
+    NF_HIP(hipMemsetAsync(drop, 0, (size_t)n, s));
     const int g = nf_div_up(n, NF_XM_THREADS);
-    hipLaunchKernelGGL(k_xmatch_best, dim3(g), dim3(NF_XM_THREADS), 0, s, u, snr, n, lo2, hi2, count, best, nearFlag);
-    hipLaunchKernelGGL(k_xmatch_drop, dim3(g), dim3(NF_XM_THREADS), 0, s, u, n, lo2, hi2, count, best, drop);
+    hipLaunchKernelGGL(k_xmatch_best_part, dim3(g, NF_XM_SLICES), dim3(NF_XM_THREADS), 0, s, u, snr, n, lo2, hi2, (XmPart*)work, nearFlag);
+    hipLaunchKernelGGL(k_xmatch_merge, dim3(nf_div_up(n, 256)), dim3(256), 0, s, (const XmPart*)work, n, count, best);
+    hipLaunchKernelGGL(k_xmatch_drop, dim3(g, NF_XM_SLICES), dim3(NF_XM_THREADS), 0, s, u, n, lo2, hi2, count, best, drop);
     NF_CHECK_LAUNCH("k_xmatch");
     return NF_OK;
 }

@@ -67,12 +67,15 @@ def xmatch_self(RADeg, decDeg, SNR, radiusDeg):
     ints = t.empty(2 * n + 1, dtype=t.int32, device=dev)
     drop = t.empty(n, dtype=t.uint8, device=dev)
     lib = _lib.load()
+    wbytes = lib.nf_xmatch_workspace_bytes(n)
+    work = t.empty(wbytes // 8 + 1, dtype=t.float64, device=dev)
     check(lib.nf_xmatch_self(ptr(u_d), ptr(s_d), n, float(radiusDeg), ptr(ints[:n]), ptr(ints[n:2 * n]), ptr(drop),
-                             ptr(ints[2 * n:]), stream_ptr()), "nf_xmatch_self")
-    h = ints.cpu().numpy()
+                             ptr(ints[2 * n:]), ptr(work), work.numel() * 8, stream_ptr()), "nf_xmatch_self")
+    # one transfer: the ints, then the drop bytes widened
+    h = t.cat([ints, drop.to(t.int32)]).cpu().numpy()
     if h[2 * n] != 0:
         return None
-    return h[:n].astype(np.int64), h[n:2 * n].astype(np.int64), drop.cpu().numpy().astype(bool)
+    return h[:n].astype(np.int64), h[n:2 * n].astype(np.int64), h[2 * n + 1:] != 0
 
 
 def stream_ptr():

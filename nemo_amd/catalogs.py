@@ -69,8 +69,10 @@ class Table(object):
     def _materialiseNames(self):
         if self._nameSpec is not None and 'RADeg' in self._cols:
             prefix, longNames = self._nameSpec
-            fn = makeLongName if longNames else makeName
-            names = [fn(r, d, prefix=prefix) for r, d in zip(self._cols['RADeg'].tolist(), self._cols['decDeg'].tolist())]
+            if longNames:
+                names = [makeLongName(r, d, prefix=prefix) for r, d in zip(self._cols['RADeg'].tolist(), self._cols['decDeg'].tolist())]
+            else:
+                names = makeNames(self._cols['RADeg'], self._cols['decDeg'], prefix=prefix)
             col = np.array(names, dtype='U30') if len(names) > 0 else np.zeros(0, dtype='U30')
             # keep 'name' as the first column, where catalogListToTab puts it
             self._cols = dict([('name', col)] + [(k, v) for k, v in self._cols.items() if k != 'name'])
@@ -217,6 +219,27 @@ def _longDecField(decDeg):
 def makeName(RADeg, decDeg, prefix='ACT-CL'):
     """``prefix JHHMM.m+DDMM`` (nemo/catalogs.py:436-451,472-524)."""
     return prefix + " J" + _raField(float(RADeg)) + _decField(float(decDeg))
+
+
+def makeNames(RADeg, decDeg, prefix='ACT-CL'):
+    """makeName for arrays: the same string route, written out in one loop (no helper calls per object)."""
+    out = []
+    head = prefix + " J"
+    for ra, dec in zip(np.asarray(RADeg, dtype=np.float64).tolist(), np.asarray(decDeg, dtype=np.float64).tolist()):
+        hours = (ra / 360) * 24
+        sh = "%.10f" % (hours)
+        mins = float(sh[sh.index("."):]) * 60
+        sm = "%.10f" % (mins)
+        raPart = ("0" + sh[:1] if hours < 10 else sh[:2]) + ("0" + sm[:3] if mins < 10 else sm[:4])
+        s = str(dec)
+        if dec > 0:
+            sDeg = "+" + ("0" + s[:1] if dec < 10 else s[:2])
+        else:
+            sDeg = "-0" + s[1] if dec > -10 else s[:3]
+        dm = float(s[s.index("."):]) * 60
+        sdm = str(dm)
+        out.append(head + raPart + sDeg + ("0" + sdm[:1] if dm < 10 else sdm[:2]))
+    return out
 
 
 def makeLongName(RADeg, decDeg, prefix="ACT-CL"):

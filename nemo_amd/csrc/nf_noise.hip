@@ -627,8 +627,24 @@ struct BlockWs {
     double* rec;                   // [maxBy][maxBx][NF_BREC]
     double* tails;
     long long tailCap;             // room in `tails`
+    // heavy blocks (more than NF_HEAVY tails - bright objects): their tails re-ordered by magnitude class in `tails2` (same
+    // offsets as `tails`), per class (count, sum v, sum v^2, offset inside the list) in `cls`
+    double* tails2;
+    double* cls;                   // [maxHeavy][NF_NCLS][4]
+    int* heavyIds;                 // [maxHeavy] block index by * maxBx + bx; hdr[4] = how many
+    int maxHeavy;
     int maxBy, maxBx;
 };
+
+#define NF_HEAVY 256
+#define NF_NCLS 16
+// lower bound of magnitude class c of a block with core threshold T: half-octave classes [T 2^(c/2), T 2^((c+1)/2)), the last
+// one open above.  One function for the kernel that sorts and the kernel that sums: the bounds are bitwise the same.
+__device__ __forceinline__ double cls_bound(double T, int c) {
+    // 2^(c/2) without a library call (a folded constant and a run-time exp2 may differ in the last bit)
+    const double f = __longlong_as_double((long long)(1023 + (c >> 1)) << 52);
+    return T * ((c & 1) ? f * 1.4142135623730951 : f);
+}
 
 static inline int blocks_max_breaks(int ncell, int len) { return 2 * ncell + len / NF_BLK + 5; }
 
@@ -783,6 +799,7 @@ __global__ void __launch_bounds__(256) k_noise_breaks(NoiseGrid g, int H, int W,
             ws.hdr[1] = nOut[1];
             ws.hdr[2] = 0;
             ws.hdr[3] = 0;
+            ws.hdr[4] = 0;
         }
         bY = outL[0];
         bX = outL[1];
@@ -795,6 +812,7 @@ __global__ void __launch_bounds__(256) k_noise_breaks(NoiseGrid g, int H, int W,
             ws.hdr[1] = nOut[1];
             ws.hdr[2] = 0;
             ws.hdr[3] = 0;
+            ws.hdr[4] = 0;
         }
     }
     const int nBy = nOut[0], nBx = nOut[1];
@@ -903,6 +921,7 @@ __global__ void __launch_bounds__(64) k_noise_block_stats(const VT* __restrict__
         rec[8] = 0.0;
         rec[10] = wminAll;
         rec[11] = wmaxAll;
+        rec[15] = -1.0;        // heavy slot (k_noise_block_core)
         rec[12] = sv;          // sum (v - v0) over the valid pixels
         rec[13] = sv2;         // sum (v - v0)^2
         rec[14] = v0;
@@ -1057,6 +1076,11 @@ __global__ void __launch_bounds__(64) k_noise_block_core(const VT* __restrict__ 
         total = 0;
     }
     if (lane == 0) {
+        int slot = -1;
+        if (total > NF_HEAVY) {
+            slot = atomicAdd(&ws.hdr[4], 1);
+            if (slot < ws.maxHeavy) ws.heavyIds[slot] = by * ws.maxBx + bx; else slot = -1;
+        }
         rec[3] = T;
         rec[4] = nc;
         rec[5] = mu;
@@ -1064,6 +1088,94 @@ __global__ void __launch_bounds__(64) k_noise_block_core(const VT* __restrict__ 
         rec[7] = s2;
         rec[8] = (double)total;
         rec[9] = (double)tailOff;
+        rec[15] = (double)slot;
+    }
+}
+
+// Heavy blocks: tails grouped by magnitude class (a counting sort by one wavefront, order inside a class = list order) with
+// the class sums, so that a clipping iteration takes whole classes from their sums and tests the elements of one class only.
+__global__ void __launch_bounds__(64) k_noise_block_classes(BlockWs ws) {
+    const int lane = threadIdx.x;
+    const int nHeavy = min(ws.hdr[4], ws.maxHeavy);
+    for (int h = blockIdx.x; h < nHeavy; h += gridDim.x) {
+        const double* __restrict__ rec = ws.rec + (long long)ws.heavyIds[h] * NF_BREC;
+        const double T = rec[3];
+        const int tc = (int)rec[8];
+        const long long off = (long long)rec[9];
+        const double* __restrict__ src = ws.tails + off;
+        double* __restrict__ dst = ws.tails2 + off;
+        double bound[NF_NCLS];
+#pragma unroll
+        for (int c = 0; c < NF_NCLS; ++c) bound[c] = cls_bound(T, c);
+        // pass 1: counts and sums per class
+        double cn[NF_NCLS], c1[NF_NCLS], c2[NF_NCLS];
+#pragma unroll
+        for (int c = 0; c < NF_NCLS; ++c) {
+            cn[c] = 0.0;
+            c1[c] = 0.0;
+            c2[c] = 0.0;
+        }
+        for (int e = lane; e < tc; e += 64) {
+            const double t = src[e], a = fabs(t);
+            int k = 0;
+#pragma unroll
+            for (int c = 1; c < NF_NCLS; ++c) k += a >= bound[c] ? 1 : 0;
+#pragma unroll
+            for (int c = 0; c < NF_NCLS; ++c)
+                if (c == k) {
+                    cn[c] += 1.0;
+                    c1[c] += t;
+                    c2[c] += t * t;
+                }
+        }
+        int start[NF_NCLS];
+        int acc = 0;
+#pragma unroll
+        for (int c = 0; c < NF_NCLS; ++c) {
+            cn[c] = wave_total(cn[c]);
+            c1[c] = wave_total(c1[c]);
+            c2[c] = wave_total(c2[c]);
+            start[c] = acc;
+            acc += (int)cn[c];
+        }
+        if (lane < NF_NCLS) {
+            double* __restrict__ ce = ws.cls + ((long long)h * NF_NCLS + lane) * 4;
+            double vn = 0.0, v1 = 0.0, v2 = 0.0;
+            int vs = 0;
+#pragma unroll
+            for (int c = 0; c < NF_NCLS; ++c)
+                if (c == lane) {
+                    vn = cn[c];
+                    v1 = c1[c];
+                    v2 = c2[c];
+                    vs = start[c];
+                }
+            ce[0] = vn;
+            ce[1] = v1;
+            ce[2] = v2;
+            ce[3] = (double)vs;
+        }
+        // pass 2: placement, chunk by chunk; inside a class the list order is kept
+        int run[NF_NCLS];
+#pragma unroll
+        for (int c = 0; c < NF_NCLS; ++c) run[c] = start[c];
+        for (int e0 = 0; e0 < tc; e0 += 64) {
+            const int e = e0 + lane;
+            const bool in = e < tc;
+            const double t = in ? src[e] : 0.0, a = fabs(t);
+            int k = -1;
+            if (in) {
+                k = 0;
+#pragma unroll
+                for (int c = 1; c < NF_NCLS; ++c) k += a >= bound[c] ? 1 : 0;
+            }
+#pragma unroll
+            for (int c = 0; c < NF_NCLS; ++c) {
+                const unsigned long long m = __ballot(k == c);
+                if (k == c) dst[run[c] + __popcll(m & ((1ULL << lane) - 1ULL))] = t;
+                run[c] += __popcll(m);
+            }
+        }
     }
 }
 
@@ -1116,7 +1228,7 @@ __device__ __forceinline__ void scan_block(const VT* __restrict__ v, int W, cons
 struct WinLds {
     double T[NF_WIN_MAXBLK], nc[NF_WIN_MAXBLK], mu[NF_WIN_MAXBLK], S1[NF_WIN_MAXBLK], S2[NF_WIN_MAXBLK];
     double nAll[NF_WIN_MAXBLK], v0[NF_WIN_MAXBLK], A1[NF_WIN_MAXBLK], A2[NF_WIN_MAXBLK];   // all valid pixels, about v0
-    int tailBase[NF_WIN_MAXBLK], tailCnt[NF_WIN_MAXBLK];
+    int tailBase[NF_WIN_MAXBLK], tailCnt[NF_WIN_MAXBLK], heavy[NF_WIN_MAXBLK];   // heavy: class-table slot or -1
     long long tailOff[NF_WIN_MAXBLK];
     double tail[NF_WIN_MAXTAIL];
     unsigned char tailBlk[NF_WIN_MAXTAIL];
@@ -1234,6 +1346,56 @@ __device__ __forceinline__ void window_sums(const VT* __restrict__ v, int W, con
             st.thrW = thr;
             __syncthreads();
         }
+        if (thr != INFINITY) {
+            // heavy blocks in core mode: lane c takes magnitude class c - whole classes below thr from their sums, the one
+            // class that straddles thr element by element (by the whole wavefront)
+            unsigned long long hm = __ballot(core && L.heavy[lane < nblk ? lane : 0] >= 0);
+            while (hm) {
+                const int b = __ffsll((long long)hm) - 1;
+                hm &= hm - 1;
+                const double Tb = L.T[b];
+                double cn = 0.0, c1 = 0.0, c2 = 0.0, lo = INFINITY, hi = INFINITY;
+                int coff = 0;
+                if (lane < NF_NCLS) {
+                    const double* __restrict__ ce = ws.cls + ((long long)L.heavy[b] * NF_NCLS + lane) * 4;
+                    cn = ce[0];
+                    c1 = ce[1];
+                    c2 = ce[2];
+                    coff = (int)ce[3];
+                    lo = cls_bound(Tb, lane);
+                    hi = lane == NF_NCLS - 1 ? INFINITY : cls_bound(Tb, lane + 1);
+                }
+                if (cn > 0.0 && hi <= thr) {
+                    s += c1 - cn * c0;
+                    ss += c2 - 2.0 * c0 * c1 + cn * c0 * c0;
+                    nn += cn;
+                }
+                const unsigned long long pm = __ballot(cn > 0.0 && lo < thr && thr < hi);
+                if (pm) {
+                    const int srcLane = __ffsll((long long)pm) - 1;
+                    const int n_ = __shfl((int)cn, srcLane, 64), o_ = __shfl(coff, srcLane, 64);
+                    const double* __restrict__ tp = ws.tails2 + L.tailOff[b] + o_;
+                    for (int e0 = 0; e0 < n_; e0 += 512) {
+                        double tv[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int e = e0 + u * 64 + lane;
+                            tv[u] = tp[e < n_ ? e : 0];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int e = e0 + u * 64 + lane;
+                            if (e < n_ && fabs(tv[u]) < thr) {
+                                const double d = tv[u] - c0;
+                                s += d;
+                                ss += d * d;
+                                nn += 1.0;
+                            }
+                        }
+                    }
+                }
+            }
+        }
         unsigned long long todo = __ballot(scan);
         if (todo && lane == 0) atomicAdd(&ws.hdr[2], __popcll(todo));    // diagnostics: direct block scans
         while (todo) {
@@ -1337,7 +1499,7 @@ __global__ void __launch_bounds__(64) k_noise_windows(const VT* __restrict__ v, 
             cnt += nv;
             wmin = fmin(wmin, rb[1]);
             wmax = fmax(wmax, rb[2]);
-            tcSum += (int)rb[8];
+            if (rb[15] < 0.0) tcSum += (int)rb[8];
         }
     }
     for (int off = 32; off > 0; off >>= 1) {
@@ -1365,6 +1527,9 @@ __global__ void __launch_bounds__(64) k_noise_windows(const VT* __restrict__ v, 
             L.S1[lane] = rb[6];
             L.S2[lane] = rb[7];
             tc = live ? (int)rb[8] : 0;
+            const int slot = live ? (int)rb[15] : -1;
+            L.heavy[lane] = slot;
+            if (slot >= 0) tc = 0;           // a heavy block's tails are served from its class table, not from the LDS set
             L.tailOff[lane] = (long long)rb[9];
             L.tailCnt[lane] = tc;
             L.nAll[lane] = rb[0];
@@ -1602,6 +1767,7 @@ int median_stack(int rtype, const void* in, void* out, int N, long long n, hipSt
 }
 
 static size_t align8(size_t b) { return (b + 7) & ~(size_t)7; }
+static size_t noise_max_heavy(size_t maxBy, size_t maxBx) { return maxBy * maxBx < 16384 ? maxBy * maxBx : 16384; }
 // sum of tail_cap over any block decomposition of an H x W map with at most maxBy x maxBx blocks
 static size_t noise_tail_cap(int H, int W, int maxBy, int maxBx) {
     (void)maxBy;
@@ -1617,7 +1783,8 @@ size_t noise_workspace_bytes(const NoiseGrid& g, int H, int W) {
     size_t ints = align8((8 + maxBy + maxBx + 2 * (size_t)g.ny + 2 * (size_t)g.nx) * sizeof(int));
     size_t recs = maxBy * maxBx * NF_BREC * sizeof(double);
     size_t tails = noise_tail_cap(H, W, (int)maxBy, (int)maxBx) * sizeof(double);
-    return cells + ints + recs + tails;
+    size_t heavy = align8(noise_max_heavy(maxBy, maxBx) * sizeof(int)) + noise_max_heavy(maxBy, maxBx) * NF_NCLS * 4 * sizeof(double);
+    return cells + ints + recs + 2 * tails + heavy;
 }
 
 int noise_map(int vtype, const void* filtered, const void* weights, int wtype, float* rms, int H, int W, const NoiseGrid& g,
@@ -1652,6 +1819,10 @@ int noise_map(int vtype, const void* filtered, const void* weights, int wtype, f
         p += align8((8 + (size_t)ws.maxBy + (size_t)ws.maxBx + 2 * (size_t)g.ny + 2 * (size_t)g.nx) * sizeof(int));
         ws.rec = (double*)p;
         ws.tails = ws.rec + (size_t)ws.maxBy * ws.maxBx * NF_BREC;
+        ws.tails2 = ws.tails + noise_tail_cap(H, W, ws.maxBy, ws.maxBx);
+        ws.maxHeavy = (int)noise_max_heavy(ws.maxBy, ws.maxBx);
+        ws.cls = ws.tails2 + noise_tail_cap(H, W, ws.maxBy, ws.maxBx);
+        ws.heavyIds = (int*)(ws.cls + (size_t)ws.maxHeavy * NF_NCLS * 4);
         if ((long long)H * W >= (1LL << 31)) {
             nf_set_error("noise_map: map too large for the 32-bit pixel offsets of the block kernels");
             return NF_ERR_SIZE;
@@ -1664,6 +1835,7 @@ int noise_map(int vtype, const void* filtered, const void* weights, int wtype, f
         hipLaunchKernelGGL((k_noise_block_stats<VT, WT>), gb, dim3(64), 0, s, (const VT*)filtered, (const WT*)weights, W, ws); \
         hipLaunchKernelGGL(k_noise_window_rms0, gw, dim3(64), 0, s, g, ws, stats);                                         \
         hipLaunchKernelGGL((k_noise_block_core<VT>), gb, dim3(64), 0, s, (const VT*)filtered, W, g, ws, stats);            \
+        hipLaunchKernelGGL(k_noise_block_classes, dim3(1024), dim3(64), 0, s, ws);                                         \
         hipLaunchKernelGGL((k_noise_windows<VT>), gw, dim3(64), 0, s, (const VT*)filtered, W, g, ws, stats);               \
     } while (0)
         if (vtype == NF_F64 && wtype == NF_F64) NF_NB(double, double);

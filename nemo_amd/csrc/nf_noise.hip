@@ -638,13 +638,12 @@ struct BlockWs {
 
 #define NF_HEAVY 256
 #define NF_NCLS 16
-// lower bound of magnitude class c of a block with core threshold T: half-octave classes [T 2^(c/2), T 2^((c+1)/2)), the last
-// one open above.  One function for the kernel that sorts and the kernel that sums: the bounds are bitwise the same.
-__device__ __forceinline__ double cls_bound(double T, int c) {
-    // 2^(c/2) without a library call (a folded constant and a run-time exp2 may differ in the last bit)
-    const double f = __longlong_as_double((long long)(1023 + (c >> 1)) << 52);
-    return T * ((c & 1) ? f * 1.4142135623730951 : f);
-}
+// lower bound of magnitude class c of a block with core threshold T: [T m_c, T m_(c+1)), the last class open above.  The
+// final clipping threshold of a window lies between T and 2 T (T = 2.25 x the smallest typical block rms, threshold = 3 x
+// the window's rms), so the classes are fine there (twelfth-octaves) and coarse (half-octaves) above.  One table for the
+// kernel that sorts and the kernel that sums: the bounds are bitwise the same.
+__device__ const double kClsMul[NF_NCLS + 1] = {1.0, 1.0594630943592953, 1.122462048309373, 1.189207115002721, 1.2599210498948732, 1.3348398541700344, 1.4142135623730951, 1.4983070768766815, 1.5874010519681994, 1.681792830507429, 1.7817974362806785, 1.8877486253633868, 2.0, 2.8284271247461903, 4.0, 5.656854249492381, INFINITY};
+__device__ __forceinline__ double cls_bound(double T, int c) { return T * kClsMul[c]; }
 
 static inline int blocks_max_breaks(int ncell, int len) { return 2 * ncell + len / NF_BLK + 5; }
 
@@ -1092,10 +1091,21 @@ __global__ void __launch_bounds__(64) k_noise_block_core(const VT* __restrict__ 
     }
 }
 
-// Heavy blocks: tails grouped by magnitude class (a counting sort by one wavefront, order inside a class = list order) with
-// the class sums, so that a clipping iteration takes whole classes from their sums and tests the elements of one class only.
-__global__ void __launch_bounds__(64) k_noise_block_classes(BlockWs ws) {
-    const int lane = threadIdx.x;
+// Heavy blocks: tails grouped by magnitude class (a counting sort by the 16 wavefronts of a workgroup; the order inside a
+// class is fixed by the chunk -> wavefront assignment, so the result is the same in every run) with the class sums, so that
+// a clipping iteration takes whole classes from their sums and tests the elements of one class only.
+#define NF_CLS_WAVES 16
+__device__ __forceinline__ int tail_class(bool in, double a, const double (&bound)[NF_NCLS]) {
+    int k = in ? 0 : -1;
+#pragma unroll
+    for (int c = 1; c < NF_NCLS; ++c) k += (in && a >= bound[c]) ? 1 : 0;
+    return k;
+}
+
+__global__ void __launch_bounds__(64 * NF_CLS_WAVES) k_noise_block_classes(BlockWs ws) {
+    __shared__ int cntW[NF_CLS_WAVES][NF_NCLS];      // per wavefront and class: count, then first position
+    __shared__ int clsStart[NF_NCLS + 1];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int nHeavy = min(ws.hdr[4], ws.maxHeavy);
     for (int h = blockIdx.x; h < nHeavy; h += gridDim.x) {
         const double* __restrict__ rec = ws.rec + (long long)ws.heavyIds[h] * NF_BREC;
@@ -1103,72 +1113,61 @@ __global__ void __launch_bounds__(64) k_noise_block_classes(BlockWs ws) {
         const int tc = (int)rec[8];
         const long long off = (long long)rec[9];
         const double* __restrict__ src = ws.tails + off;
-        double* __restrict__ dst = ws.tails2 + off;
+        double* dst = ws.tails2 + off;
         double bound[NF_NCLS];
 #pragma unroll
         for (int c = 0; c < NF_NCLS; ++c) bound[c] = cls_bound(T, c);
-        // pass 1: counts and sums per class
-        double cn[NF_NCLS], c1[NF_NCLS], c2[NF_NCLS];
+        // counts per wavefront and class (chunk i of 64 list entries belongs to wavefront i mod 16)
+        int cnt[NF_NCLS];
 #pragma unroll
-        for (int c = 0; c < NF_NCLS; ++c) {
-            cn[c] = 0.0;
-            c1[c] = 0.0;
-            c2[c] = 0.0;
-        }
-        for (int e = lane; e < tc; e += 64) {
-            const double t = src[e], a = fabs(t);
-            int k = 0;
-#pragma unroll
-            for (int c = 1; c < NF_NCLS; ++c) k += a >= bound[c] ? 1 : 0;
-#pragma unroll
-            for (int c = 0; c < NF_NCLS; ++c)
-                if (c == k) {
-                    cn[c] += 1.0;
-                    c1[c] += t;
-                    c2[c] += t * t;
-                }
-        }
-        int start[NF_NCLS];
-        int acc = 0;
-#pragma unroll
-        for (int c = 0; c < NF_NCLS; ++c) {
-            cn[c] = wave_total(cn[c]);
-            c1[c] = wave_total(c1[c]);
-            c2[c] = wave_total(c2[c]);
-            start[c] = acc;
-            acc += (int)cn[c];
-        }
-        if (lane < NF_NCLS) {
-            double* __restrict__ ce = ws.cls + ((long long)h * NF_NCLS + lane) * 4;
-            double vn = 0.0, v1 = 0.0, v2 = 0.0;
-            int vs = 0;
-#pragma unroll
-            for (int c = 0; c < NF_NCLS; ++c)
-                if (c == lane) {
-                    vn = cn[c];
-                    v1 = c1[c];
-                    v2 = c2[c];
-                    vs = start[c];
-                }
-            ce[0] = vn;
-            ce[1] = v1;
-            ce[2] = v2;
-            ce[3] = (double)vs;
-        }
-        // pass 2: placement, chunk by chunk; inside a class the list order is kept
-        int run[NF_NCLS];
-#pragma unroll
-        for (int c = 0; c < NF_NCLS; ++c) run[c] = start[c];
-        for (int e0 = 0; e0 < tc; e0 += 64) {
+        for (int c = 0; c < NF_NCLS; ++c) cnt[c] = 0;
+        for (int e0 = w * 64; e0 < tc; e0 += 64 * NF_CLS_WAVES) {
             const int e = e0 + lane;
             const bool in = e < tc;
-            const double t = in ? src[e] : 0.0, a = fabs(t);
-            int k = -1;
-            if (in) {
-                k = 0;
+            const double t = src[in ? e : 0];
+            const int k = tail_class(in, fabs(t), bound);
 #pragma unroll
-                for (int c = 1; c < NF_NCLS; ++c) k += a >= bound[c] ? 1 : 0;
+            for (int c = 0; c < NF_NCLS; ++c) cnt[c] += __popcll(__ballot(k == c));
+        }
+        if (lane < NF_NCLS) {
+            int v = 0;
+#pragma unroll
+            for (int c = 0; c < NF_NCLS; ++c)
+                if (c == lane) v = cnt[c];
+            cntW[w][lane] = v;
+        }
+        __syncthreads();
+        // first positions: classes one after the other, inside a class wavefront after wavefront
+        if (threadIdx.x < 64) {
+            int tot = 0;
+            if (lane < NF_NCLS)
+                for (int q = 0; q < NF_CLS_WAVES; ++q) tot += cntW[q][lane];
+            int incl = tot;
+            for (int o = 1; o < NF_NCLS; o <<= 1) {
+                const int up = __shfl_up(incl, o, 64);
+                if (lane >= o) incl += up;
             }
+            if (lane < NF_NCLS) {
+                int run = incl - tot;
+                clsStart[lane] = run;
+                if (lane == NF_NCLS - 1) clsStart[NF_NCLS] = incl;
+                for (int q = 0; q < NF_CLS_WAVES; ++q) {
+                    const int n = cntW[q][lane];
+                    cntW[q][lane] = run;
+                    run += n;
+                }
+            }
+        }
+        __syncthreads();
+        // placement
+        int run[NF_NCLS];
+#pragma unroll
+        for (int c = 0; c < NF_NCLS; ++c) run[c] = cntW[w][c];
+        for (int e0 = w * 64; e0 < tc; e0 += 64 * NF_CLS_WAVES) {
+            const int e = e0 + lane;
+            const bool in = e < tc;
+            const double t = src[in ? e : 0];
+            const int k = tail_class(in, fabs(t), bound);
 #pragma unroll
             for (int c = 0; c < NF_NCLS; ++c) {
                 const unsigned long long m = __ballot(k == c);
@@ -1176,10 +1175,40 @@ __global__ void __launch_bounds__(64) k_noise_block_classes(BlockWs ws) {
                 run[c] += __popcll(m);
             }
         }
+        __threadfence_block();
+        __syncthreads();
+        // class sums: one wavefront per class over its (now contiguous) segment
+        for (int c = w; c < NF_NCLS; c += NF_CLS_WAVES) {
+            const int s0 = clsStart[c], n = clsStart[c + 1] - s0;
+            const double* seg = dst + s0;
+            double s1 = 0.0, s2 = 0.0;
+            for (int e0 = 0; e0 < n; e0 += 512) {
+                double tv[8];                       // 8 loads per lane in flight
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int e = e0 + u * 64 + lane;
+                    tv[u] = seg[e < n ? e : 0];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (e0 + u * 64 + lane < n) {
+                        s1 += tv[u];
+                        s2 += tv[u] * tv[u];
+                    }
+            }
+            s1 = wave_total(s1);
+            s2 = wave_total(s2);
+            if (lane == 0) {
+                double* __restrict__ ce = ws.cls + ((long long)h * NF_NCLS + c) * 4;
+                ce[0] = (double)n;
+                ce[1] = s1;
+                ce[2] = s2;
+                ce[3] = (double)s0;
+            }
+        }
+        __syncthreads();
     }
 }
-
-
 
 // ---- k_noise_windows: ONE WAVEFRONT per cell (no barriers; reductions on the vector ALU) ----
 #define NF_WIN_MAXBLK 64      // blocks of a window whose records are staged in LDS (more: everything from global memory)
@@ -1226,8 +1255,6 @@ __device__ __forceinline__ void scan_block(const VT* __restrict__ v, int W, cons
 }
 
 struct WinLds {
-    double T[NF_WIN_MAXBLK], nc[NF_WIN_MAXBLK], mu[NF_WIN_MAXBLK], S1[NF_WIN_MAXBLK], S2[NF_WIN_MAXBLK];
-    double nAll[NF_WIN_MAXBLK], v0[NF_WIN_MAXBLK], A1[NF_WIN_MAXBLK], A2[NF_WIN_MAXBLK];   // all valid pixels, about v0
     int tailBase[NF_WIN_MAXBLK], tailCnt[NF_WIN_MAXBLK], heavy[NF_WIN_MAXBLK];   // heavy: class-table slot or -1
     long long tailOff[NF_WIN_MAXBLK];
     double tail[NF_WIN_MAXTAIL];
@@ -1247,6 +1274,9 @@ __device__ __forceinline__ int tail_block(const WinLds& L, int nblk, int e) {
 // The tail values the LDS currently holds (the "working set"): all tails with |v| < thrW if `complete`.  Thresholds fall
 // from one clipping iteration to the next, so after one pass over a long list the following iterations stay in LDS.
 struct WinState {
+    // lane = block: the block record (core threshold, core count/mean/sums about the mean; all valid pixels: count, sums
+    // about v0) - registers, not LDS, which keeps ten windows resident per CU
+    double T, nc, mu, S1, S2, nAll, v0, A1, A2;
     int nW;
     double thrW;
     bool complete;
@@ -1264,10 +1294,10 @@ __device__ __forceinline__ void window_sums(const VT* __restrict__ v, int W, con
     if (LDS) {
         // lane = block: core sums, or (rarely) a direct scan, which the whole wavefront does block after block
         bool scan = false, core = false;
-        if (lane < nblk && L.nc[lane] >= 0.0) {
-            core = thr >= L.T[lane];
+        if (lane < nblk && st.nc >= 0.0) {
+            core = thr >= st.T;
             if (core) {
-                const double nc = L.nc[lane], dmu = L.mu[lane] - c0, S1 = L.S1[lane], S2 = L.S2[lane];
+                const double nc = st.nc, dmu = st.mu - c0, S1 = st.S1, S2 = st.S2;
                 s = S1 + nc * dmu;
                 ss = S2 + 2.0 * dmu * S1 + nc * dmu * dmu;
                 nn = nc;
@@ -1281,8 +1311,8 @@ __device__ __forceinline__ void window_sums(const VT* __restrict__ v, int W, con
             s = 0.0;
             ss = 0.0;
             nn = 0.0;
-            if (lane < nblk && L.nc[lane] >= 0.0) {
-                const double na = L.nAll[lane], dv = L.v0[lane] - c0, A1 = L.A1[lane], A2 = L.A2[lane];
+            if (lane < nblk && st.nc >= 0.0) {
+                const double na = st.nAll, dv = st.v0 - c0, A1 = st.A1, A2 = st.A2;
                 s = A1 + na * dv;
                 ss = A2 + 2.0 * dv * A1 + na * dv * dv;
                 nn = na;
@@ -1353,7 +1383,7 @@ __device__ __forceinline__ void window_sums(const VT* __restrict__ v, int W, con
             while (hm) {
                 const int b = __ffsll((long long)hm) - 1;
                 hm &= hm - 1;
-                const double Tb = L.T[b];
+                const double Tb = __shfl(st.T, b, 64);
                 double cn = 0.0, c1 = 0.0, c2 = 0.0, lo = INFINITY, hi = INFINITY;
                 int coff = 0;
                 if (lane < NF_NCLS) {
@@ -1516,26 +1546,29 @@ __global__ void __launch_bounds__(64) k_noise_windows(const VT* __restrict__ v, 
     if (nblk <= NF_WIN_MAXBLK) {
         // stage the block records (lane = block) and, through a prefix of the tail counts, the first NF_WIN_MAXTAIL tail
         // values (a window with more - bright objects - reads the rest from global memory in every iteration)
+        WinState st;
+        st.T = st.mu = st.S1 = st.S2 = st.nAll = st.A1 = st.A2 = st.v0 = 0.0;
+        st.nc = -1.0;
         int tc = 0;
         if (lane < nblk) {
             const int byo = lane / nbx;
             const double* __restrict__ rb = ws.rec + ((long long)(BY0 + byo) * ws.maxBx + BX0 + (lane - byo * nbx)) * NF_BREC;
             const bool live = rb[0] > 0.0;
-            L.T[lane] = rb[3];
-            L.nc[lane] = live ? rb[4] : -1.0;     // -1: block without valid pixels
-            L.mu[lane] = rb[5];
-            L.S1[lane] = rb[6];
-            L.S2[lane] = rb[7];
+            st.T = rb[3];
+            st.nc = live ? rb[4] : -1.0;     // -1: block without valid pixels
+            st.mu = rb[5];
+            st.S1 = rb[6];
+            st.S2 = rb[7];
             tc = live ? (int)rb[8] : 0;
             const int slot = live ? (int)rb[15] : -1;
             L.heavy[lane] = slot;
             if (slot >= 0) tc = 0;           // a heavy block's tails are served from its class table, not from the LDS set
             L.tailOff[lane] = (long long)rb[9];
             L.tailCnt[lane] = tc;
-            L.nAll[lane] = rb[0];
-            L.A1[lane] = rb[12];
-            L.A2[lane] = rb[13];
-            L.v0[lane] = rb[14];
+            st.nAll = rb[0];
+            st.A1 = rb[12];
+            st.A2 = rb[13];
+            st.v0 = rb[14];
         }
         int incl = tc;
         for (int off = 1; off < 64; off <<= 1) {
@@ -1545,7 +1578,6 @@ __global__ void __launch_bounds__(64) k_noise_windows(const VT* __restrict__ v, 
         if (lane < nblk) L.tailBase[lane] = incl - tc;
         __syncthreads();
         // the block of flat tail index e by binary search in the prefix (LDS only), then the loads, all independent
-        WinState st;
         st.complete = tcSum <= NF_WIN_MAXTAIL;
         st.nW = st.complete ? tcSum : 0;
         st.thrW = st.complete ? INFINITY : 0.0;
@@ -1563,6 +1595,8 @@ __global__ void __launch_bounds__(64) k_noise_windows(const VT* __restrict__ v, 
         rms = window_clip<VT, true>(v, W, ws, L, st, BY0, BX0, nbx, nblk, tcSum);
     } else {
         WinState st;
+        st.T = st.mu = st.S1 = st.S2 = st.nAll = st.A1 = st.A2 = st.v0 = 0.0;
+        st.nc = -1.0;
         st.complete = false;
         st.nW = 0;
         st.thrW = 0.0;
@@ -1835,7 +1869,7 @@ int noise_map(int vtype, const void* filtered, const void* weights, int wtype, f
         hipLaunchKernelGGL((k_noise_block_stats<VT, WT>), gb, dim3(64), 0, s, (const VT*)filtered, (const WT*)weights, W, ws); \
         hipLaunchKernelGGL(k_noise_window_rms0, gw, dim3(64), 0, s, g, ws, stats);                                         \
         hipLaunchKernelGGL((k_noise_block_core<VT>), gb, dim3(64), 0, s, (const VT*)filtered, W, g, ws, stats);            \
-        hipLaunchKernelGGL(k_noise_block_classes, dim3(1024), dim3(64), 0, s, ws);                                         \
+        hipLaunchKernelGGL(k_noise_block_classes, dim3(512), dim3(64 * NF_CLS_WAVES), 0, s, ws);                                    \
         hipLaunchKernelGGL((k_noise_windows<VT>), gw, dim3(64), 0, s, (const VT*)filtered, W, g, ws, stats);               \
     } while (0)
         if (vtype == NF_F64 && wtype == NF_F64) NF_NB(double, double);

@@ -407,6 +407,33 @@ __device__ __forceinline__ void fft_stage(cpx<T>* __restrict__ buf, const nf::Li
                     //   epiZeroRef  pixels that are zero in the reference map stay zero (nemo/filters.py:99-101)
                     const bool doScale = a.epiScale != nullptr;
                     const double es = doScale ? *a.epiScale : 1.0;
+                    const bool useMask = doScale && a.epiMask != nullptr, useRef = a.epiZeroRef != nullptr;
+                    // the epilogue operands of all R outputs first (one batch of loads, not one round trip per output):
+                    // bits 0-7 mask of row A, 8-15 mask of row B, 16 / 17 "reference is zero" for row A / B
+                    unsigned ep[R];
+                    if (useMask || useRef) {
+#pragma unroll
+                        for (int k = 0; k < R; ++k) {
+                            const unsigned e = base + (unsigned)k * L;
+                            const unsigned ec = (!BLUE || e < (unsigned)p.n) ? e : 0u;
+                            const unsigned oa = rowA * (unsigned)a.realW + ec, ob = haveB ? oa + (unsigned)a.realW : oa;
+                            unsigned v = 0x0101u;
+                            if (useMask) v = (unsigned)a.epiMask[oa] | ((unsigned)a.epiMask[ob] << 8);
+                            if (useRef) {
+                                if (a.outType == 1) {
+                                    v |= ((const double*)a.epiZeroRef)[oa] == 0.0 ? 0x10000u : 0u;
+                                    v |= ((const double*)a.epiZeroRef)[ob] == 0.0 ? 0x20000u : 0u;
+                                } else {
+                                    v |= ((const float*)a.epiZeroRef)[oa] == 0.0f ? 0x10000u : 0u;
+                                    v |= ((const float*)a.epiZeroRef)[ob] == 0.0f ? 0x20000u : 0u;
+                                }
+                            }
+                            ep[k] = v;
+                        }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < R; ++k) ep[k] = 0x0101u;
+                    }
 #pragma unroll
                     for (int k = 0; k < R; ++k) {
                         const unsigned e = base + (unsigned)k * L;
@@ -420,15 +447,13 @@ __device__ __forceinline__ void fft_stage(cpx<T>* __restrict__ buf, const nf::Li
                                 if (doScale) {
                                     wa = (double)(float)va * es;
                                     wb = (double)(float)vb * es;
-                                    if (a.epiMask != nullptr) {
-                                        wa = wa * (double)a.epiMask[oa];
-                                        if (haveB) wb = wb * (double)a.epiMask[ob];
+                                    if (useMask) {
+                                        wa = wa * (double)(ep[k] & 0xffu);
+                                        wb = wb * (double)((ep[k] >> 8) & 0xffu);
                                     }
                                 }
-                                if (a.epiZeroRef != nullptr) {
-                                    if (((const double*)a.epiZeroRef)[oa] == 0.0) wa = 0.0;
-                                    if (haveB && ((const double*)a.epiZeroRef)[ob] == 0.0) wb = 0.0;
-                                }
+                                if (ep[k] & 0x10000u) wa = 0.0;
+                                if (ep[k] & 0x20000u) wb = 0.0;
                                 ((double*)G.outP)[oa] = wa;
                                 if (haveB) ((double*)G.outP)[ob] = wb;
                             } else {
@@ -436,15 +461,13 @@ __device__ __forceinline__ void fft_stage(cpx<T>* __restrict__ buf, const nf::Li
                                 if (doScale) {
                                     wa = wa * (float)es;
                                     wb = wb * (float)es;
-                                    if (a.epiMask != nullptr) {
-                                        wa = wa * (float)a.epiMask[oa];
-                                        if (haveB) wb = wb * (float)a.epiMask[ob];
+                                    if (useMask) {
+                                        wa = wa * (float)(ep[k] & 0xffu);
+                                        wb = wb * (float)((ep[k] >> 8) & 0xffu);
                                     }
                                 }
-                                if (a.epiZeroRef != nullptr) {
-                                    if (((const float*)a.epiZeroRef)[oa] == 0.0f) wa = 0.0f;
-                                    if (haveB && ((const float*)a.epiZeroRef)[ob] == 0.0f) wb = 0.0f;
-                                }
+                                if (ep[k] & 0x10000u) wa = 0.0f;
+                                if (ep[k] & 0x20000u) wb = 0.0f;
                                 ((float*)G.outP)[oa] = wa;
                                 if (haveB) ((float*)G.outP)[ob] = wb;
                             }
@@ -641,6 +664,48 @@ __device__ __forceinline__ void stage_in_pairs_inv(cpx<T>* __restrict__ buf, con
         const cpx<T>* inA = (const cpx<T>*)G.inP + (unsigned)rowA * (unsigned)a.realW;
         const cpx<T>* inB = inA + (haveB ? (unsigned)a.realW : 0u);
         cpx<T>* __restrict__ lb = buf + line * p.mPad;
+        if (!BLUE) {
+            // each stored mode k <= n/2 is loaded once and feeds both line elements k and n - k (the conjugate)
+            const int nh = n >> 1;
+            for (int k0 = G.tb; k0 <= nh; k0 += NF_STAGE_IN * G.TB) {
+                cpx<T> va[NF_STAGE_IN], vb[NF_STAGE_IN];
+                int p1[NF_STAGE_IN], p2[NF_STAGE_IN];
+#pragma unroll
+                for (int j = 0; j < NF_STAGE_IN; ++j) {
+                    const int k = min(k0 + j * G.TB, nh);
+                    va[j] = inA[k];
+                    vb[j] = inB[k];
+                    p1[j] = p.rev[k];
+                    p2[j] = p.rev[k == 0 ? 0 : n - k];
+                }
+#pragma unroll
+                for (int j = 0; j < NF_STAGE_IN; ++j) {
+                    const int k = k0 + j * G.TB;
+                    if (k <= nh) {
+                        cpx<T> A = va[j], B = vb[j];
+                        const bool self = k == 0 || 2 * k == n;      // self-conjugate modes are real
+                        if (self) {
+                            A.y = 0;
+                            B.y = 0;
+                        }
+                        if (!haveB) {
+                            B.x = 0;
+                            B.y = 0;
+                        }
+                        cpx<T> t;
+                        t.x = A.x - B.y;
+                        t.y = (A.y + B.x) * sgn;
+                        lb[swz(p1[j])] = t;
+                        if (!self) {
+                            t.x = A.x + B.y;
+                            t.y = (B.x - A.y) * sgn;
+                            lb[swz(p2[j])] = t;
+                        }
+                    }
+                }
+            }
+            continue;
+        }
         for (int i0 = G.tb; i0 < nIn; i0 += NF_STAGE_IN * G.TB) {
             cpx<T> va[NF_STAGE_IN], vb[NF_STAGE_IN], ch[BLUE ? NF_STAGE_IN : 1];
             int pos[NF_STAGE_IN];
@@ -693,8 +758,10 @@ __device__ __forceinline__ void stage_in_pairs_inv(cpx<T>* __restrict__ buf, con
 }
 
 // Rows: lines are contiguous in memory (elemStride 1).  LDS layout [line][swz(e)].
+// (the plain-radix variants are held to 128 VGPRs - four wavefronts per SIMD - so that two 512-thread workgroups share a
+// CU and one's butterflies overlap the other's HBM traffic; the big-radix and Bluestein variants keep their registers)
 template <typename T, int MODE, int PAIR>
-__global__ void __launch_bounds__(512) k_fft_rows(nf::LineArgs<T> a) {
+__global__ void __launch_bounds__(512, (MODE == 0 ? 4 : 2)) k_fft_rows(nf::LineArgs<T> a) {
     extern __shared__ __align__(16) unsigned char nf_smem[];
     cpx<T>* buf = (cpx<T>*)nf_smem;
     const nf::LinePlan<T>& p = a.plan;

@@ -7,7 +7,7 @@ import csv, glob, json, sys, collections
 
 TAGS = [('fft_cols_f64', ['k_fft_cols<double'], None), ('fft_rows_f64', ['k_fft_rows<double'], None),
         ('fft_cols_f32', ['k_fft_cols<float'], None), ('fft_rows_f32', ['k_fft_rows<float'], None),
-        # one nf_noise_map call = breaks + block_stats + window_rms0 + block_core + windows + paint_blocks
+        # one nf_noise_map call = breaks + block_stats + window_rms0 + block_core + block_classes + windows + paint_blocks
         ('noise_map', ['k_noise_'], 'k_noise_breaks')]
 
 

@@ -21,7 +21,7 @@ def wrapped(filtered, medWeights, noiseParams, pixSizeDeg):
     hdr = raw[hdrOff:hdrOff + 8].cpu().numpy()
     stats = work[:ncy * ncx * 4].reshape(ncy * ncx, 4).cpu().numpy()
     f = filtered.cpu().numpy()
-    print("heavy blocks", hdr[4], "max per window", hdr[5], "max straddle elements", hdr[6], "slowest window %.1f us" % (hdr[7] / 100.0))
+    print("heavy blocks (magnitude-class tables)", hdr[4])
     print("breaks", hdr[0], hdr[1], "scans", hdr[2], "nonLDS windows", hdr[3], "| map std %.3e  kurtosis %.2f  cell rms min/med/max %.3e %.3e %.3e"
           % (f.std(), ((f - f.mean()) ** 4).mean() / f.var() ** 2, stats[:, 3].min(), np.median(stats[:, 3]), stats[:, 3].max()), flush=True)
     import time

@@ -813,7 +813,7 @@ __global__ void __launch_bounds__(512, (MODE == 0 ? 4 : 2)) k_fft_rows(nf::LineA
 
 // Columns: a tile of TL = linesPerWG adjacent lines (elemStride = row pitch, lineStride 1).  LDS layout [swz(e)][line].
 template <typename T, int MODE, int SPEC>
-__global__ void __launch_bounds__(NF_FFT_MAXTHREADS) k_fft_cols(nf::LineArgs<T> a) {
+__global__ void __launch_bounds__((MODE == 0 && SPEC == 3 && sizeof(T) == 8) ? 512 : NF_FFT_MAXTHREADS) k_fft_cols(nf::LineArgs<T> a) {
     extern __shared__ __align__(16) unsigned char nf_smem[];
     cpx<T>* buf = (cpx<T>*)nf_smem;
     const nf::LinePlan<T>& p = a.plan;
@@ -1134,6 +1134,7 @@ int launch_lines(const LineArgs<T>& a, bool cols, int batch, int threads, hipStr
         else if (spec == 1) NF_LAUNCH2(K, M, 1); \
         else NF_LAUNCH2(K, M, 2);                \
     } while (0)
+    if (cols && spec == 3 && mode == 0 && sizeof(T) == 8 && threads > 512) threads = 512;   // that variant trades threads for registers
     if (cols && spec == 3) {
         if (mode == 0) NF_LAUNCH2(k_fft_cols, 0, 3);
         else if (mode == 1) NF_LAUNCH2(k_fft_cols, 1, 3);

@@ -487,38 +487,56 @@ __device__ __forceinline__ void spline_eval_interior(const VT* __restrict__ map,
 }
 
 // ---------------------------------------------------------------------------------------------------
-// 1-D not-a-knot cubic spline through n >= 4 unit-spaced samples y[0..n-1] (stride `st`), evaluated at
-// position u in [0, n-1].  Second derivatives M: M_1 = d_1/6 and M_{n-2} = d_{n-2}/6 follow directly from the
-// not-a-knot conditions on a uniform grid; the interior is a constant (1,4,1) tridiagonal system.
-__device__ double nak_spline_eval(const double* y, int st, int n, double u, double* work /* n doubles */, const double* cp) {
-    // d_i = 6 (y_{i-1} - 2 y_i + y_{i+1})
-    auto d = [&](int i) { return 6.0 * (y[(i - 1) * st] - 2.0 * y[i * st] + y[(i + 1) * st]); };
-    double* M = work;
-    M[1] = d(1) / 6.0;
-    M[n - 2] = d(n - 2) / 6.0;
-    if (n > 4) {
-        // forward sweep over i = 2 .. n-3, cp[k] = modified super-diagonal for the k-th interior row
-        double prev = 0.0;
-        for (int i = 2; i <= n - 3; ++i) {
-            double rhs = d(i);
-            if (i == 2) rhs -= M[1];
-            if (i == n - 3) rhs -= M[n - 2];
-            int k = i - 2;
-            // 1 / (4 - cp[k-1]) is cp[k] itself (cp[0] = 1/4): a multiplication instead of an IEEE division in the chain
-            double val = (k == 0) ? rhs * cp[0] : (rhs - prev) * cp[k];
-            M[i] = val;
-            prev = val;
-        }
-        for (int i = n - 4; i >= 2; --i) M[i] -= cp[i - 2] * M[i + 1];
-    }
-    M[0] = 2.0 * M[1] - M[2];
-    M[n - 1] = 2.0 * M[n - 2] - M[n - 3];
+// 1-D not-a-knot cubic spline through n >= 4 unit-spaced samples y[0..n-1], evaluated at position u in [0, n-1].
+// Second derivatives M: M_1 = d_1/6 and M_{n-2} = d_{n-2}/6 follow directly from the not-a-knot conditions on a uniform
+// grid (d_i = 6 (y_{i-1} - 2 y_i + y_{i+1})); between them the constant (1, 4, 1) system M_{i-1} + 4 M_i + M_{i+1} = d_i,
+// i = 2 .. n-3, is a Dirichlet problem.  Instead of a sequential elimination (two dependent sweeps of n steps) it is
+// solved in closed form: the particular solution P_i = sum_j G(i - j) d_j with the Green's function of the infinite
+// system (G(k) = rho^|k| / (2 sqrt 3), rho = sqrt 3 - 2) plus the two homogeneous solutions rho^(i-1), rho^(n-2-i) fitted
+// to the two known end values.  Only the two M the evaluation interval needs are formed: four independent dot products
+// of length n - 4, no dependent chain.  rw[k] = rho^k, k < NF_SPL_MAXN.
+__device__ double nak_spline_eval(const double* y, int n, double u, const double* rw) {
+    const double A = 0.28867513459481288225457439025098;       // 1 / (2 sqrt(3))
     int i = (int)floor(u);
     if (i < 0) i = 0;
     if (i > n - 2) i = n - 2;
-    double t = u - (double)i, t1 = 1.0 - t;
-    double y0 = y[i * st], y1 = y[(i + 1) * st];
-    return M[i] * t1 * t1 * t1 / 6.0 + M[i + 1] * t * t * t / 6.0 + (y0 - M[i] / 6.0) * t1 + (y1 - M[i + 1] / 6.0) * t;
+    // the two interior second derivatives to form: those of the interval, or the end pair an extrapolated end value needs
+    const int qa = i == 0 ? 1 : (i + 1 == n - 1 ? n - 3 : i), qb = qa + 1;
+    double p1 = 0.0, pn = 0.0, pa = 0.0, pb = 0.0;
+    double ym = y[1], yc = y[2];
+    for (int j = 2; j <= n - 3; ++j) {
+        const double yp = y[j + 1];
+        const double dj = 6.0 * (ym - 2.0 * yc + yp);
+        p1 += rw[j - 1] * dj;
+        pn += rw[n - 2 - j] * dj;
+        pa += rw[abs(qa - j)] * dj;
+        pb += rw[abs(qb - j)] * dj;
+        ym = yc;
+        yc = yp;
+    }
+    p1 *= A;
+    pn *= A;
+    pa *= A;
+    pb *= A;
+    const double r1 = (y[0] - 2.0 * y[1] + y[2]) - p1, rn = (y[n - 3] - 2.0 * y[n - 2] + y[n - 1]) - pn;   // d/6 - P
+    const double e = rw[n - 3], det = 1.0 - e * e;
+    const double alpha = (r1 - e * rn) / det, beta = (rn - e * r1) / det;
+    const double Ma = pa + alpha * rw[qa - 1] + beta * rw[n - 2 - qa];
+    const double Mb = pb + alpha * rw[qb - 1] + beta * rw[n - 2 - qb];
+    double Mi, Mi1;
+    if (i == 0) {                       // M_0 = 2 M_1 - M_2
+        Mi = 2.0 * Ma - Mb;
+        Mi1 = Ma;
+    } else if (i + 1 == n - 1) {        // M_{n-1} = 2 M_{n-2} - M_{n-3}
+        Mi = Mb;
+        Mi1 = 2.0 * Mb - Ma;
+    } else {
+        Mi = Ma;
+        Mi1 = Mb;
+    }
+    const double t = u - (double)i, t1 = 1.0 - t;
+    const double y0 = y[i], y1 = y[i + 1];
+    return Mi * t1 * t1 * t1 / 6.0 + Mi1 * t * t * t / 6.0 + (y0 - Mi / 6.0) * t1 + (y1 - Mi1 / 6.0) * t;
 }
 
 // interior points: small static LDS, so many workgroups share a CU (the windowed-solve kernel below needs 85 KB each)
@@ -545,32 +563,24 @@ __global__ void k_spline_eval(const VT* __restrict__ map, int negate, int H, int
     int x0 = max(0, ix - halfWin), x1 = min(W - 1, ix + 1 + halfWin);
     const int ny = y1 - y0 + 1, nx = x1 - x0 + 1;
     const int nxp = nx + 1;
-    double* mwork = win + NF_SPL_MAXN * (NF_SPL_MAXN + 1);   // [ny][nxp] second-derivative scratch
-    double* colv = mwork + NF_SPL_MAXN * (NF_SPL_MAXN + 1);  // [ny]
-    double* cp = colv + NF_SPL_MAXN;                         // [NF_SPL_MAXN]
+    double* colv = win + NF_SPL_MAXN * (NF_SPL_MAXN + 1);    // [ny]
+    double* rw = colv + NF_SPL_MAXN;                         // [NF_SPL_MAXN] rho^k
     if (!(py >= 0.0 && py <= (double)(H - 1) && px >= 0.0 && px <= (double)(W - 1)) || ny < 4 || nx < 4) {
         if (threadIdx.x == 0) out[pt] = nan("");
         return;
     }
     if (spline_interior(iy, ix, H, W, halfWin)) return;      // k_spline_eval_interior wrote this point
+#pragma unroll 8
     for (int i = threadIdx.x; i < ny * nx; i += blockDim.x) {
         int r = i / nx, c = i % nx;
         double v = (double)map[(long long)(y0 + r) * W + x0 + c];
         win[r * nxp + c] = negate ? -v : v;
     }
-    if (threadIdx.x == 0) {
-        double c = 0.25;
-        cp[0] = c;
-        for (int k = 1; k < NF_SPL_MAXN; ++k) {
-            c = 1.0 / (4.0 - c);
-            cp[k] = c;
-        }
-    }
+    if (threadIdx.x < NF_SPL_MAXN) rw[threadIdx.x] = ipow(-0.26794919243112270647255365849413, (int)threadIdx.x);
     __syncthreads();
-    for (int r = threadIdx.x; r < ny; r += blockDim.x)
-        colv[r] = nak_spline_eval(win + r * nxp, 1, nx, px - (double)x0, mwork + r * nxp, cp);
+    for (int r = threadIdx.x; r < ny; r += blockDim.x) colv[r] = nak_spline_eval(win + r * nxp, nx, px - (double)x0, rw);
     __syncthreads();
-    if (threadIdx.x == 0) out[pt] = nak_spline_eval(colv, 1, ny, py - (double)y0, mwork, cp);
+    if (threadIdx.x == 0) out[pt] = nak_spline_eval(colv, ny, py - (double)y0, rw);
 }
 
 int spline_eval(int vtype, const void* map, int negate, int H, int W, const double* yx, int nPts, int halfWin, int pointsClass,
@@ -580,7 +590,7 @@ int spline_eval(int vtype, const void* map, int negate, int H, int W, const doub
         nf_set_error("spline_eval: window too large");
         return NF_ERR_ARG;
     }
-    size_t lds = (size_t)(2 * NF_SPL_MAXN * (NF_SPL_MAXN + 1) + 2 * NF_SPL_MAXN) * sizeof(double);
+    size_t lds = (size_t)(NF_SPL_MAXN * (NF_SPL_MAXN + 1) + 2 * NF_SPL_MAXN) * sizeof(double);
     static bool attr[2] = {false, false};
     if (vtype == NF_F64) {
         if (!attr[1]) {

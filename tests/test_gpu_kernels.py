@@ -287,6 +287,35 @@ def test_noise_map(vdtype, numBins):
 
 
 @pytest.mark.parametrize("vdtype", [np.float64, np.float32])
+def test_noise_map_heavy_tails(vdtype):
+    """Blocks under bright extended objects (more than 256 values beyond the core threshold) take the magnitude-class
+    route of the block path (k_noise_block_classes): same clipped RMS as the oracle's
+    per-window evaluation (nemo/filters.py:407-478), and the route is really taken (workspace header counter)."""
+    shape = (420, 530)
+    rng = np.random.default_rng(77)
+    m = rng.standard_normal(shape)
+    yy, xx = np.mgrid[0:shape[0], 0:shape[1]]
+    for (cy, cx, amp, sig) in [(100, 120, 60.0, 14.0), (101, 300, -35.0, 20.0), (300, 260, 400.0, 9.0), (330, 60, 25.0, 30.0),
+                               (210, 500, 80.0, 12.0)]:
+        m += amp * np.exp(-0.5 * ((yy - cy) ** 2 + (xx - cx) ** 2) / sig ** 2)
+    m[:, :5] = 0
+    m = m.astype(vdtype)
+    w = (1.0 + 0.2 * np.sin(xx / 40.0) * np.cos(yy / 55.0)).astype(vdtype)
+    eng = _eng(shape)
+    pix = 0.5 / 60.0
+    for grid in (40.0, 20.0):
+        params = {'noiseGridArcmin': grid, 'numNoiseBins': 1}
+        ref = ofilt.make_noise_map(m, [w], params, pix)
+        got = _np(eng.noise_map(engine.to_dev(m), engine.to_dev(w), params, pix))
+        work, ncy, ncx, nb = eng._lastNoiseWork
+        hdr = work.view(torch.int32)[ncy * ncx * 4 * 2:ncy * ncx * 4 * 2 + 8].cpu().numpy()
+        assert hdr[4] > 0, "no heavy block in this case: the test does not exercise the class route"
+        assert np.array_equal(got > 0, ref > 0)
+        assert np.abs(got - ref).max() <= 1.2e-7 * ref.max()
+        assert (got != ref).mean() < (0.02 if vdtype == np.float64 else 0.6)
+
+
+@pytest.mark.parametrize("vdtype", [np.float64, np.float32])
 def test_edge_check_and_finalize(vdtype):
     shape = (129, 86)
     rng = np.random.default_rng(31)

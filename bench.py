@@ -161,8 +161,8 @@ def pmc_traffic(tag, shape, numScales, dtype):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", type=int, default=4096, help="tile side in pixels (headline: 4096)")
     ap.add_argument("--scales", type=int, default=15)
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])

@@ -286,8 +286,8 @@ __device__ __forceinline__ cpx<T> fused_ops_herm(const nf::LineArgs<T>& a, const
 // outputs.  srcG: operands come from global memory (columns kernel, first DIT stage: row src[e]); dstG: results go
 // to global memory (last DIT stage: natural index e).
 // SPEC (compile time, so that the common kernels do not carry the registers of the special paths): columns kernel
-// 1 = mirrored second store (forward transform of a real map), 2 = pointwise / symmetrised load (fused inverse);
-// rows kernel 2 = two real output rows per line (inverse, real output).
+// 1 = mirrored second store (forward transform of a real map), 2 = pointwise / symmetrised load (fused inverse),
+// 3 = one half-stored plane times a real factor (batched form of 2); the rows kernel always passes 0.
 template <typename T, int R, bool COLS, bool BLUE, int SPEC>
 __device__ __forceinline__ void fft_stage(cpx<T>* __restrict__ buf, const nf::LineArgs<T>& a, const nf::StageInfo st,
                                           const bool dif, const bool srcG, const bool dstG, const Geo& G) {
@@ -393,83 +393,6 @@ __device__ __forceinline__ void fft_stage(cpx<T>* __restrict__ buf, const nf::Li
                                 v.y *= -(r * (T)a.conjOutSign);
                                 const unsigned rowM = e == 0u ? 0u : (unsigned)a.realH - e;
                                 ((cpx<T>*)G.outP)[rowM * (unsigned)a.outElemStride + ((unsigned)a.realW - col)] = v;
-                            }
-                        }
-                    }
-                } else if (!COLS && SPEC == 2) {
-                    // two real output rows from one complex line: row 2p = Re, row 2p+1 = Im (of the conjugated transform)
-                    const unsigned rowA = 2u * (unsigned)(G.line0 + line);
-                    const bool haveB = rowA + 1u < (unsigned)a.realH;
-                    const T r = (T)a.scale, rb = r * (T)a.conjOutSign;
-                    // optional epilogues of the matched-filter path, applied to the real value on its way out:
-                    //   epiScale  float32 map * signalNorm * psMask (nemo/filters.py:847,853,714: the filtered map is cast to
-                    //             float32, then multiplied by the scalar and the mask in the output type)
-                    //   epiZeroRef  pixels that are zero in the reference map stay zero (nemo/filters.py:99-101)
-                    const bool doScale = a.epiScale != nullptr;
-                    const double es = doScale ? *a.epiScale : 1.0;
-                    const bool useMask = doScale && a.epiMask != nullptr, useRef = a.epiZeroRef != nullptr;
-                    // the epilogue operands of all R outputs first (one batch of loads, not one round trip per output):
-                    // bits 0-7 mask of row A, 8-15 mask of row B, 16 / 17 "reference is zero" for row A / B
-                    unsigned ep[R];
-                    if (useMask || useRef) {
-#pragma unroll
-                        for (int k = 0; k < R; ++k) {
-                            const unsigned e = base + (unsigned)k * L;
-                            const unsigned ec = (!BLUE || e < (unsigned)p.n) ? e : 0u;
-                            const unsigned oa = rowA * (unsigned)a.realW + ec, ob = haveB ? oa + (unsigned)a.realW : oa;
-                            unsigned v = 0x0101u;
-                            if (useMask) v = (unsigned)a.epiMask[oa] | ((unsigned)a.epiMask[ob] << 8);
-                            if (useRef) {
-                                if (a.outType == 1) {
-                                    v |= ((const double*)a.epiZeroRef)[oa] == 0.0 ? 0x10000u : 0u;
-                                    v |= ((const double*)a.epiZeroRef)[ob] == 0.0 ? 0x20000u : 0u;
-                                } else {
-                                    v |= ((const float*)a.epiZeroRef)[oa] == 0.0f ? 0x10000u : 0u;
-                                    v |= ((const float*)a.epiZeroRef)[ob] == 0.0f ? 0x20000u : 0u;
-                                }
-                            }
-                            ep[k] = v;
-                        }
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < R; ++k) ep[k] = 0x0101u;
-                    }
-#pragma unroll
-                    for (int k = 0; k < R; ++k) {
-                        const unsigned e = base + (unsigned)k * L;
-                        if (!BLUE || e < (unsigned)p.n) {
-                            cpx<T> v = x[k];
-                            if (BLUE) v = cmul(cconj(v), p.chirp[e]);
-                            const unsigned oa = rowA * (unsigned)a.realW + e, ob = oa + (unsigned)a.realW;
-                            T va = v.x * r, vb = v.y * rb;
-                            if (a.outType == 1) {
-                                double wa = (double)va, wb = (double)vb;
-                                if (doScale) {
-                                    wa = (double)(float)va * es;
-                                    wb = (double)(float)vb * es;
-                                    if (useMask) {
-                                        wa = wa * (double)(ep[k] & 0xffu);
-                                        wb = wb * (double)((ep[k] >> 8) & 0xffu);
-                                    }
-                                }
-                                if (ep[k] & 0x10000u) wa = 0.0;
-                                if (ep[k] & 0x20000u) wb = 0.0;
-                                ((double*)G.outP)[oa] = wa;
-                                if (haveB) ((double*)G.outP)[ob] = wb;
-                            } else {
-                                float wa = (float)va, wb = (float)vb;
-                                if (doScale) {
-                                    wa = wa * (float)es;
-                                    wb = wb * (float)es;
-                                    if (useMask) {
-                                        wa = wa * (float)(ep[k] & 0xffu);
-                                        wb = wb * (float)((ep[k] >> 8) & 0xffu);
-                                    }
-                                }
-                                if (ep[k] & 0x10000u) wa = 0.0f;
-                                if (ep[k] & 0x20000u) wb = 0.0f;
-                                ((float*)G.outP)[oa] = wa;
-                                if (haveB) ((float*)G.outP)[ob] = wb;
                             }
                         }
                     }
@@ -757,6 +680,94 @@ __device__ __forceinline__ void stage_in_pairs_inv(cpx<T>* __restrict__ buf, con
     }
 }
 
+// Inverse of a real map's half-stored rows, last step: the complex line in LDS holds row 2p in its real and row 2p+1 in its
+// imaginary part (of the conjugated transform).  Consecutive threads take consecutive pixels: coalesced stores, and the
+// optional epilogues of the matched-filter path applied to the real value on its way out:
+//   epiScale    float32 map * signalNorm * psMask (nemo/filters.py:847,853,714: the filtered map is cast to float32, then
+//               multiplied by the scalar and the mask in the output type)
+//   epiZeroRef  pixels that are zero in the reference map stay zero (nemo/filters.py:99-101)
+template <typename T, bool BLUE>
+__device__ __forceinline__ void store_pairs_inv(const cpx<T>* __restrict__ buf, const nf::LineArgs<T>& a, const Geo& G) {
+    const nf::LinePlan<T>& p = a.plan;
+    const int n = p.n;
+    const T r = (T)a.scale, rb = r * (T)a.conjOutSign;
+    const bool doScale = a.epiScale != nullptr;
+    const double es = doScale ? *a.epiScale : 1.0;
+    const bool useMask = doScale && a.epiMask != nullptr, useRef = a.epiZeroRef != nullptr;
+    constexpr int NB = 4;
+    for (int line = G.tl; line < G.nl; line += G.TL) {
+        const unsigned rowA = 2u * (unsigned)(G.line0 + line);
+        const bool haveB = rowA + 1u < (unsigned)a.realH;
+        const cpx<T>* __restrict__ lb = buf + line * p.mPad;
+        const unsigned oa0 = rowA * (unsigned)a.realW;
+        for (int e0 = G.tb; e0 < n; e0 += NB * G.TB) {
+            // operands of NB pixels first (one batch of loads): bits 0-7 mask of row A, 8-15 mask of row B, 16 / 17
+            // "reference is zero" for row A / B
+            cpx<T> z[NB];
+            unsigned ep[NB];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int ec = min(e0 + j * G.TB, n - 1);
+                z[j] = lb[swz(ec)];
+                unsigned v = 0x0101u;
+                if (useMask || useRef) {
+                    const unsigned oa = oa0 + (unsigned)ec, ob = haveB ? oa + (unsigned)a.realW : oa;
+                    if (useMask) v = (unsigned)a.epiMask[oa] | ((unsigned)a.epiMask[ob] << 8);
+                    if (useRef) {
+                        if (a.outType == 1) {
+                            v |= ((const double*)a.epiZeroRef)[oa] == 0.0 ? 0x10000u : 0u;
+                            v |= ((const double*)a.epiZeroRef)[ob] == 0.0 ? 0x20000u : 0u;
+                        } else {
+                            v |= ((const float*)a.epiZeroRef)[oa] == 0.0f ? 0x10000u : 0u;
+                            v |= ((const float*)a.epiZeroRef)[ob] == 0.0f ? 0x20000u : 0u;
+                        }
+                    }
+                }
+                ep[j] = v;
+            }
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int e = e0 + j * G.TB;
+                if (e < n) {
+                    cpx<T> v = z[j];
+                    if (BLUE) v = cmul(cconj(v), p.chirp[e]);
+                    const unsigned oa = oa0 + (unsigned)e, ob = oa + (unsigned)a.realW;
+                    T va = v.x * r, vb = v.y * rb;
+                    if (a.outType == 1) {
+                        double wa = (double)va, wb = (double)vb;
+                        if (doScale) {
+                            wa = (double)(float)va * es;
+                            wb = (double)(float)vb * es;
+                            if (useMask) {
+                                wa = wa * (double)(ep[j] & 0xffu);
+                                wb = wb * (double)((ep[j] >> 8) & 0xffu);
+                            }
+                        }
+                        if (ep[j] & 0x10000u) wa = 0.0;
+                        if (ep[j] & 0x20000u) wb = 0.0;
+                        ((double*)G.outP)[oa] = wa;
+                        if (haveB) ((double*)G.outP)[ob] = wb;
+                    } else {
+                        float wa = (float)va, wb = (float)vb;
+                        if (doScale) {
+                            wa = wa * (float)es;
+                            wb = wb * (float)es;
+                            if (useMask) {
+                                wa = wa * (float)(ep[j] & 0xffu);
+                                wb = wb * (float)((ep[j] >> 8) & 0xffu);
+                            }
+                        }
+                        if (ep[j] & 0x10000u) wa = 0.0f;
+                        if (ep[j] & 0x20000u) wb = 0.0f;
+                        ((float*)G.outP)[oa] = wa;
+                        if (haveB) ((float*)G.outP)[ob] = wb;
+                    }
+                }
+            }
+        }
+    }
+}
+
 // Rows: lines are contiguous in memory (elemStride 1).  LDS layout [line][swz(e)].
 // (the plain-radix variants are held to 128 VGPRs - four wavefronts per SIMD - so that two 512-thread workgroups share a
 // CU and one's butterflies overlap the other's HBM traffic; the big-radix and Bluestein variants keep their registers)
@@ -808,7 +819,13 @@ __global__ void __launch_bounds__(512, (MODE == 0 ? 4 : 2)) k_fft_rows(nf::LineA
         unpack_pairs_fwd<T, MODE == 2>(buf, a, G);
         return;
     }
-    for (int s = 0; s < p.nst; ++s) fft_stage_dispatch<T, false, MODE, PAIR == 2 ? 2 : 0>(buf, a, s, false, false, s == p.nst - 1, G);
+    if (PAIR == 2) {
+        // real output rows: the last stage stays in LDS too, the rows leave through a coalesced store pass
+        for (int s = 0; s < p.nst; ++s) fft_stage_dispatch<T, false, MODE, 0>(buf, a, s, false, false, false, G);
+        store_pairs_inv<T, MODE == 2>(buf, a, G);
+        return;
+    }
+    for (int s = 0; s < p.nst; ++s) fft_stage_dispatch<T, false, MODE, 0>(buf, a, s, false, false, s == p.nst - 1, G);
 }
 
 // Columns: a tile of TL = linesPerWG adjacent lines (elemStride = row pitch, lineStride 1).  LDS layout [swz(e)][line].

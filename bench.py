@@ -192,7 +192,9 @@ def main():
     shape = (args.size, args.size)
     mapsList, wcs, truth = make_workload(shape, 1234 + rank, args.dtype)
     config = make_config(mapsList, args.scales)
-    config.rank, config.size = rank, world      # tiles are already one per rank (weak scaling): only the gather uses these
+    # tiles are already one per rank (weak scaling).  A step is the per-tile work; the end-of-run catalogue all-gather
+    # (pipelines._gatherCatalogs, once per run after a rank's last tile) is not part of it: config.MPIEnabled stays False
+    config.rank, config.size = rank, world
     N, S = 1, len(config.parDict['mapFilters'])
 
     def barrier():

@@ -98,9 +98,9 @@ def _gatherCatalogs(optimalCatalog, config):
         tab[k] = col
     tab['template'] = np.array([labels[int(i)] if i >= 0 else '' for i in allRows[:, len(cols)]], dtype='U30')
     tab['tileName'] = np.array([config.allTileNames[int(i)] for i in allRows[:, len(cols) + 1]], dtype='U30')
-    ident = config.parDict['objIdent']
-    namer = catalogs.makeLongName if config.parDict['longNames'] else catalogs.makeName
-    tab['name'] = np.array([namer(r, d, prefix=ident) for r, d in zip(tab['RADeg'], tab['decDeg'])], dtype='U30')
+    # names are a function of the coordinates: formatted when first read (every rank holds the rows of all ranks here, and a
+    # rank that only filters more tiles next never looks at them)
+    tab.setLazyNames(config.parDict['objIdent'], config.parDict['longNames'])
     return tab
 
 

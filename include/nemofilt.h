@@ -156,8 +156,8 @@ int nf_scale_mask_dev(int vtype, const float* in_d, void* out_d, const double* s
  * np.linspace(..., dtype=int), device int arrays of ny+1 / nx+1 entries), each widened by `overlap` pixels,
  * with `numBins` weight-percentile bins per cell (quantiles: numBins host doubles = percentiles/100).
  * weights_d: the median weight map (float32/float64).  work_d: nf_noise_workspace_bytes() bytes of device scratch (for the
- * default estimator with one bin this includes the per-block sums and tail lists of the single-read evaluation, about
- * 8 bytes per pixel).
+ * default estimator with one bin this includes the per-block sums, the tail lists in list and in magnitude-class
+ * order and the class tables of the single-read evaluation, about 16 bytes per pixel).
  * estimator: 0 = 3-sigma clipped standard deviation (10 iterations, the default), 1 = RMSEstimator 'percentile'
  * (np.percentile(abs(values), 68.3), nemo/filters.py:459-460).  'biweight' needs astropy.stats and is not provided. */
 size_t nf_noise_workspace_bytes(int H, int W, int ny, int nx, int numBins);

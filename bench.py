@@ -192,8 +192,8 @@ def main():
     shape = (args.size, args.size)
     mapsList, wcs, truth = make_workload(shape, 1234 + rank, args.dtype)
     config = make_config(mapsList, args.scales)
-    # tiles are already one per rank (weak scaling).  A step is the per-tile work; the end-of-run catalogue all-gather
-    # (pipelines._gatherCatalogs, once per run after a rank's last tile) is not part of it: config.MPIEnabled stays False
+    # tiles are already one per rank (weak scaling): config.MPIEnabled stays False (no tile division inside the pipeline);
+    # run_step() does the catalogue all-gather of the path itself when there are several ranks
     config.rank, config.size = rank, world
     N, S = 1, len(config.parDict['mapFilters'])
 

@@ -50,10 +50,14 @@ def initDistributed():
     return dist.get_rank(), dist.get_world_size()
 
 
+_NAME_CHARS = 30      # width of the name column (catalogs.catalogListToTab: minStrLength = 30)
+
+
 def _gatherCatalogs(optimalCatalog, config):
     """All ranks end up with the rows of all ranks: all-gather of the row counts, then of the rows padded to the largest
     count.  Rows are [len(_GATHER_COLS) + 2] float64: the listed columns, the index of the template in the filter list and
-    the index of the tile in ``config.allTileNames``.  Extra (photometry) columns travel too when present on every rank."""
+    the index of the tile in ``config.allTileNames``.  Extra (photometry) columns travel too when present on every rank,
+    and so do the names (each rank formats those of its own rows; a second all-gather of fixed-width bytes)."""
     import torch
     import torch.distributed as dist
     dev = torch.device('cuda', torch.cuda.current_device()) if dist.get_backend() == 'nccl' else torch.device('cpu')
@@ -63,12 +67,13 @@ def _gatherCatalogs(optimalCatalog, config):
         extra = [k for k in optimalCatalog.keys() if k not in _GATHER_COLS + ['name', 'template', 'tileName']
                  and np.asarray(optimalCatalog[k]).dtype.kind in 'fiub']
     # agree on the extra columns (a rank with no detections has none to offer): keep those every non-empty rank has
-    names = [None] * config.size
-    dist.all_gather_object(names, extra if len(optimalCatalog) > 0 else None)
-    common = None
-    for n in names:
-        if n is not None:
-            common = list(n) if common is None else [k for k in common if k in n]
+    offers = [None] * config.size
+    dist.all_gather_object(offers, (extra, 'name' in optimalCatalog.keys()) if len(optimalCatalog) > 0 else None)
+    common, carryNames = None, True
+    for o in offers:
+        if o is not None:
+            common = list(o[0]) if common is None else [k for k in common if k in o[0]]
+            carryNames = carryNames and o[1]
     extra = common or []
     cols = _GATHER_COLS + extra
     n = len(optimalCatalog)
@@ -91,6 +96,16 @@ def _gatherCatalogs(optimalCatalog, config):
     dist.all_gather(gathered, padded)
     allRows = np.concatenate([g[:c].cpu().numpy() for g, c in zip(gathered, counts)], axis=0)
     tab = catalogs.Table()
+    if carryNames:
+        # every rank formats the names of its own rows only; they travel as fixed-width UTF-32 (numpy 'U30') bytes
+        nameBytes = torch.zeros((nmax, _NAME_CHARS * 4), dtype=torch.uint8, device=dev)
+        if n > 0:
+            own = np.ascontiguousarray(np.asarray(optimalCatalog['name'], dtype='U%d' % _NAME_CHARS))
+            nameBytes[:n] = torch.from_numpy(own.view(np.uint8).reshape(n, _NAME_CHARS * 4)).to(dev)
+        gatheredNames = [torch.empty_like(nameBytes) for _ in range(config.size)]
+        dist.all_gather(gatheredNames, nameBytes)
+        allNames = np.concatenate([g[:c].cpu().numpy() for g, c in zip(gatheredNames, counts)], axis=0)
+        tab['name'] = np.ascontiguousarray(allNames).view('U%d' % _NAME_CHARS).reshape(-1)
     for j, k in enumerate(cols):
         col = allRows[:, j]
         if k == 'ringFlag':
@@ -98,9 +113,9 @@ def _gatherCatalogs(optimalCatalog, config):
         tab[k] = col
     tab['template'] = np.array([labels[int(i)] if i >= 0 else '' for i in allRows[:, len(cols)]], dtype='U30')
     tab['tileName'] = np.array([config.allTileNames[int(i)] for i in allRows[:, len(cols) + 1]], dtype='U30')
-    # names are a function of the coordinates: formatted when first read (every rank holds the rows of all ranks here, and a
-    # rank that only filters more tiles next never looks at them)
-    tab.setLazyNames(config.parDict['objIdent'], config.parDict['longNames'])
+    if not carryNames:
+        # names are a function of the coordinates: formatted when first read
+        tab.setLazyNames(config.parDict['objIdent'], config.parDict['longNames'])
     return tab
 
 

@@ -171,6 +171,7 @@ assert list(allTab['template']) == ['fa', 'fb', 'fa', 'fb', 'fb']
 assert list(allTab['tileName']) == ['T0', 'T0', 'T1', 'T2', 'T2']
 assert 'y_c' in allTab.keys() and allTab['y_c'][3] == 1.0
 assert allTab['name'][0] == catalogs.makeName(10.0, 0.1)
+assert list(allTab['name']) == [catalogs.makeName(r, d) for r, d in zip(allTab['RADeg'], allTab['decDeg'])]
 dedup, nDup, names = catalogs.removeDuplicates(allTab)
 assert len(dedup) == 4 and nDup == 2 and 9.0 in list(dedup['SNR']) and 7.0 not in list(dedup['SNR'])
 # an empty rank still takes part in the exchange

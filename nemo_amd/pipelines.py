@@ -81,11 +81,13 @@ def _gatherCatalogs(optimalCatalog, config):
     if n > 0:
         for j, k in enumerate(cols):
             rows[:, j] = np.asarray(optimalCatalog[k], dtype=np.float64) if k in optimalCatalog.keys() else -99
-        rows[:, len(cols)] = [labels.index(str(t)) if str(t) in labels else -1 for t in optimalCatalog['template']]
-        rows[:, len(cols) + 1] = [config.allTileNames.index(str(t)) for t in optimalCatalog['tileName']]
+        labelIndex = {l: i for i, l in enumerate(labels)}
+        tileIndex = {l: i for i, l in enumerate(config.allTileNames)}
+        rows[:, len(cols)] = [labelIndex.get(t, -1) for t in np.asarray(optimalCatalog['template']).astype(str).tolist()]
+        rows[:, len(cols) + 1] = [tileIndex[t] for t in np.asarray(optimalCatalog['tileName']).astype(str).tolist()]
     counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(config.size)]
     dist.all_gather(counts, torch.tensor([n], dtype=torch.int64, device=dev))
-    counts = [int(c.item()) for c in counts]
+    counts = [int(c) for c in torch.cat(counts).cpu().tolist()]          # one transfer, one synchronisation
     nmax = max(counts)
     if nmax == 0:
         return catalogs.Table(names=('SNR', 'RADeg', 'decDeg'))
@@ -94,7 +96,8 @@ def _gatherCatalogs(optimalCatalog, config):
         padded[:n] = torch.from_numpy(rows).to(dev)
     gathered = [torch.empty_like(padded) for _ in range(config.size)]
     dist.all_gather(gathered, padded)
-    allRows = np.concatenate([g[:c].cpu().numpy() for g, c in zip(gathered, counts)], axis=0)
+    gatheredHost = torch.stack(gathered).cpu().numpy()                    # [rank][nmax][cols] in one transfer
+    allRows = np.concatenate([gatheredHost[r, :c] for r, c in enumerate(counts)], axis=0)
     tab = catalogs.Table()
     if carryNames:
         # every rank formats the names of its own rows only; they travel as fixed-width UTF-32 (numpy 'U30') bytes
@@ -104,15 +107,16 @@ def _gatherCatalogs(optimalCatalog, config):
             nameBytes[:n] = torch.from_numpy(own.view(np.uint8).reshape(n, _NAME_CHARS * 4)).to(dev)
         gatheredNames = [torch.empty_like(nameBytes) for _ in range(config.size)]
         dist.all_gather(gatheredNames, nameBytes)
-        allNames = np.concatenate([g[:c].cpu().numpy() for g, c in zip(gatheredNames, counts)], axis=0)
+        namesHost = torch.stack(gatheredNames).cpu().numpy()
+        allNames = np.concatenate([namesHost[r, :c] for r, c in enumerate(counts)], axis=0)
         tab['name'] = np.ascontiguousarray(allNames).view('U%d' % _NAME_CHARS).reshape(-1)
     for j, k in enumerate(cols):
         col = allRows[:, j]
         if k == 'ringFlag':
             col = col > 0
         tab[k] = col
-    tab['template'] = np.array([labels[int(i)] if i >= 0 else '' for i in allRows[:, len(cols)]], dtype='U30')
-    tab['tileName'] = np.array([config.allTileNames[int(i)] for i in allRows[:, len(cols) + 1]], dtype='U30')
+    tab['template'] = np.array(labels + [''], dtype='U30')[allRows[:, len(cols)].astype(np.int64)]     # -1 -> ''
+    tab['tileName'] = np.array(config.allTileNames, dtype='U30')[allRows[:, len(cols) + 1].astype(np.int64)]
     if not carryNames:
         # names are a function of the coordinates: formatted when first read
         tab.setLazyNames(config.parDict['objIdent'], config.parDict['longNames'])

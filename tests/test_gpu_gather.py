@@ -40,6 +40,22 @@ assert list(out['template']) == ['fa', 'fb', 'fa'] and list(out['tileName']) == 
 assert list(out['name']) == [catalogs.makeName(r, d) for r, d in zip(tab['RADeg'], tab['decDeg'])]
 empty = pipelines._gatherCatalogs(catalogs.Table(names=('SNR', 'RADeg', 'decDeg')), cfg)
 assert len(empty) == 0
+# the multi-rank branch of bench.run_step on a real pipeline catalogue (small tile, 6 scales)
+sys.path.insert(0, %(root)r)
+import bench
+mapsList, wcs, truth = bench.make_workload((1024, 1024), 5, 'f64')
+config = bench.make_config(mapsList, 6)
+config.rank, config.size = 0, 1
+cat = pipelines.filterMapsAndMakeCatalogs(config, verbose=False)
+assert len(cat) > 0
+allCat = pipelines._gatherCatalogs(cat, config)
+assert len(allCat) == len(cat)
+for k in ['RADeg', 'decDeg', 'SNR']:
+    assert np.array_equal(np.asarray(allCat[k]), np.asarray(cat[k])), k
+assert list(allCat['name']) == list(cat['name']) and list(allCat['template']) == list(cat['template'])
+assert list(allCat['tileName']) == list(cat['tileName'])
+dedup, nDup, names = catalogs.removeDuplicates(allCat)
+assert len(dedup) <= len(allCat)
 dist.destroy_process_group()
 print("gather ok")
 '''

@@ -203,7 +203,7 @@ int nf_convolve2d(const float* in_d, float* out_d, int H, int W, const double* k
 
 /* photometry.getObjectPositions, nemo/photometry.py:235-241: labels_d[H*W] int32 = scipy.ndimage.label numbering
  * of (map > threshold) (negate != 0: of (-map > threshold), nemo/photometry.py:54-55); work_d: int32 scratch of
- * H*W + H*W/1024 + 2 entries.  Synchronises the stream and returns the number of objects in *numObjects. */
+ * H*W + 2*(H*W/1024) + 4 entries.  Synchronises the stream and returns the number of objects in *numObjects. */
 int nf_label_components(int vtype, const void* sn_d, double threshold, int negate, int* labels_d, int H, int W,
                         int* work_d, int* numObjects, void* stream);
 

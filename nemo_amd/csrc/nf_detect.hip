@@ -32,10 +32,28 @@ __device__ __forceinline__ bool is_fg(const VT* sn, long long p, VT thr, int neg
     return v > thr;
 }
 
+#define NF_SCAN_CHUNK 1024   // pixels per workgroup (256 threads x 4) in every labelling pass
+
+// At a detection threshold of a few sigma almost every 1024-pixel chunk of the map holds no pixel above it.  The first
+// pass records that per chunk (chunkFG), and every later pass leaves such a chunk after reading one flag: the union-find
+// passes then cost what the foreground costs, and only the first pass (read the map, write parent) and the last (write
+// the labels) touch the whole map.
 template <typename VT>
-__global__ void k_ccl_init(const VT* __restrict__ sn, VT thr, int negate, int* __restrict__ parent, long long n) {
-    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x)
-        parent[p] = is_fg<VT>(sn, p, thr, negate) ? (int)p : -1;
+__global__ void __launch_bounds__(256) k_ccl_init(const VT* __restrict__ sn, VT thr, int negate, int* __restrict__ parent,
+                                                  long long n, int* __restrict__ chunkFG) {
+    const long long base = (long long)blockIdx.x * NF_SCAN_CHUNK;
+    int any = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const long long p = base + j * 256 + threadIdx.x;
+        if (p < n) {
+            const bool fg = is_fg<VT>(sn, p, thr, negate);
+            parent[p] = fg ? (int)p : -1;
+            any |= fg ? 1 : 0;
+        }
+    }
+    any = __syncthreads_or(any);
+    if (threadIdx.x == 0) chunkFG[blockIdx.x] = any;
 }
 
 __device__ __forceinline__ int uf_find(const int* parent, int x) {
@@ -63,30 +81,35 @@ __device__ __forceinline__ void uf_union(int* parent, int a, int b) {
     }
 }
 
-__global__ void k_ccl_merge(int* __restrict__ parent, int H, int W) {
-    const long long n = (long long)H * W;
-    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x) {
-        if (parent[p] < 0) continue;
+__global__ void __launch_bounds__(256) k_ccl_merge(int* __restrict__ parent, int H, int W, const int* __restrict__ chunkFG) {
+    if (!chunkFG[blockIdx.x]) return;
+    const long long n = (long long)H * W, base = (long long)blockIdx.x * NF_SCAN_CHUNK;
+    for (int j = 0; j < 4; ++j) {
+        const long long p = base + j * 256 + threadIdx.x;
+        if (p >= n || parent[p] < 0) continue;
         int x = (int)(p % W);
         if (x > 0 && parent[p - 1] >= 0) uf_union(parent, (int)p, (int)(p - 1));
         if (p >= W && parent[p - W] >= 0) uf_union(parent, (int)p, (int)(p - W));
     }
 }
 
-__global__ void k_ccl_flatten(int* __restrict__ parent, long long n) {
-    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x)
-        if (parent[p] >= 0) parent[p] = uf_find(parent, (int)p);
-}
-
-#define NF_SCAN_CHUNK 1024   // pixels per workgroup in the root-numbering passes (256 threads x 4)
-
-__global__ void k_count_roots(const int* __restrict__ parent, long long n, int* __restrict__ blockCounts) {
+// every foreground pixel points at its root; the roots of the chunk are counted on the way
+__global__ void __launch_bounds__(256) k_ccl_flatten_count(int* __restrict__ parent, long long n, const int* __restrict__ chunkFG,
+                                                           int* __restrict__ blockCounts) {
     __shared__ int red[4];
-    long long base = (long long)blockIdx.x * NF_SCAN_CHUNK;
+    if (!chunkFG[blockIdx.x]) {
+        if (threadIdx.x == 0) blockCounts[blockIdx.x] = 0;
+        return;
+    }
+    const long long base = (long long)blockIdx.x * NF_SCAN_CHUNK;
     int c = 0;
     for (int j = 0; j < 4; ++j) {
-        long long p = base + threadIdx.x * 4 + j;
-        if (p < n && parent[p] == (int)p) ++c;
+        const long long p = base + j * 256 + threadIdx.x;
+        if (p < n && parent[p] >= 0) {
+            const int r = uf_find(parent, (int)p);
+            parent[p] = r;
+            c += r == (int)p ? 1 : 0;
+        }
     }
     for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
@@ -94,35 +117,40 @@ __global__ void k_count_roots(const int* __restrict__ parent, long long n, int* 
     if (threadIdx.x == 0) blockCounts[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
-// exclusive scan of blockCounts (single workgroup, chunked); total written to blockCounts[nblocks]
-__global__ void k_scan_counts(int* __restrict__ blockCounts, int nblocks) {
-    __shared__ int tmp[1024];
-    __shared__ int carry;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (int base = 0; base < nblocks; base += 1024) {
-        int i = base + threadIdx.x;
-        int v = (i < nblocks) ? blockCounts[i] : 0;
-        tmp[threadIdx.x] = v;
-        __syncthreads();
-        for (int off = 1; off < 1024; off <<= 1) {
-            int t = (threadIdx.x >= off) ? tmp[threadIdx.x - off] : 0;
-            __syncthreads();
-            tmp[threadIdx.x] += t;
-            __syncthreads();
-        }
-        int incl = tmp[threadIdx.x];
-        if (i < nblocks) blockCounts[i] = carry + incl - v;
-        __syncthreads();
-        if (threadIdx.x == 1023) carry += incl;
-        __syncthreads();
+// exclusive scan of blockCounts (single workgroup: a run of consecutive entries per thread, then one scan over the
+// threads' sums); total written to blockCounts[nblocks]
+__global__ void __launch_bounds__(1024) k_scan_counts(int* __restrict__ blockCounts, int nblocks) {
+    __shared__ int waveTot[16];
+    const int per = (nblocks + 1023) / 1024, start = threadIdx.x * per;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int sum = 0;
+    for (int i = 0; i < per; ++i)
+        if (start + i < nblocks) sum += blockCounts[start + i];
+    int incl = sum;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
     }
-    if (threadIdx.x == 0) blockCounts[nblocks] = carry;
+    if (lane == 63) waveTot[wave] = incl;
+    __syncthreads();
+    int run = incl - sum, total = 0;
+    for (int w = 0; w < 16; ++w) {
+        if (w < wave) run += waveTot[w];
+        total += waveTot[w];
+    }
+    for (int i = 0; i < per; ++i)
+        if (start + i < nblocks) {
+            const int v = blockCounts[start + i];
+            blockCounts[start + i] = run;
+            run += v;
+        }
+    if (threadIdx.x == 0) blockCounts[nblocks] = total;
 }
 
-__global__ void k_number_roots(const int* __restrict__ parent, long long n, const int* __restrict__ blockOffsets,
-                               int* __restrict__ labels) {
+__global__ void __launch_bounds__(256) k_number_roots(const int* __restrict__ parent, long long n, const int* __restrict__ blockOffsets,
+                                                      const int* __restrict__ chunkFG, int* __restrict__ labels) {
     __shared__ int waveTot[4];
+    if (!chunkFG[blockIdx.x]) return;
     long long base = (long long)blockIdx.x * NF_SCAN_CHUNK;
     int flags[4], c = 0;
     for (int j = 0; j < 4; ++j) {
@@ -148,8 +176,20 @@ __global__ void k_number_roots(const int* __restrict__ parent, long long n, cons
     }
 }
 
-__global__ void k_relabel(const int* __restrict__ parent, int* __restrict__ labels, long long n) {
-    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x) {
+__global__ void __launch_bounds__(256) k_relabel(const int* __restrict__ parent, int* __restrict__ labels, long long n,
+                                                 const int* __restrict__ chunkFG) {
+    const long long base = (long long)blockIdx.x * NF_SCAN_CHUNK;
+    if (!chunkFG[blockIdx.x]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const long long p = base + j * 256 + threadIdx.x;
+            if (p < n) labels[p] = 0;
+        }
+        return;
+    }
+    for (int j = 0; j < 4; ++j) {
+        const long long p = base + j * 256 + threadIdx.x;
+        if (p >= n) continue;
         int r = parent[p];
         if (r < 0)
             labels[p] = 0;
@@ -167,18 +207,18 @@ int label_components(int vtype, const void* sn, double threshold, int negate, in
     }
     int* parent = work;
     const int nblocks = nf_div_up(n, NF_SCAN_CHUNK);
-    int* blockCounts = work + n;
-    dim3 g(grid_for(n, 256)), b(256);
+    int* blockCounts = work + n;                 // nblocks + 1
+    int* chunkFG = blockCounts + nblocks + 1;    // nblocks
+    dim3 g(nblocks), b(256);
     if (vtype == NF_F64)
-        hipLaunchKernelGGL(k_ccl_init<double>, g, b, 0, s, (const double*)sn, threshold, negate, parent, n);
+        hipLaunchKernelGGL(k_ccl_init<double>, g, b, 0, s, (const double*)sn, threshold, negate, parent, n, chunkFG);
     else  // a Python-float threshold compared against a float32 map is cast to float32 by numpy
-        hipLaunchKernelGGL(k_ccl_init<float>, g, b, 0, s, (const float*)sn, (float)threshold, negate, parent, n);
-    hipLaunchKernelGGL(k_ccl_merge, g, b, 0, s, parent, H, W);
-    hipLaunchKernelGGL(k_ccl_flatten, g, b, 0, s, parent, n);
-    hipLaunchKernelGGL(k_count_roots, dim3(nblocks), dim3(256), 0, s, parent, n, blockCounts);
+        hipLaunchKernelGGL(k_ccl_init<float>, g, b, 0, s, (const float*)sn, (float)threshold, negate, parent, n, chunkFG);
+    hipLaunchKernelGGL(k_ccl_merge, g, b, 0, s, parent, H, W, chunkFG);
+    hipLaunchKernelGGL(k_ccl_flatten_count, g, b, 0, s, parent, n, chunkFG, blockCounts);
     hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, s, blockCounts, nblocks);
-    hipLaunchKernelGGL(k_number_roots, dim3(nblocks), dim3(256), 0, s, parent, n, blockCounts, labels);
-    hipLaunchKernelGGL(k_relabel, g, b, 0, s, parent, labels, n);
+    hipLaunchKernelGGL(k_number_roots, g, b, 0, s, parent, n, blockCounts, chunkFG, labels);
+    hipLaunchKernelGGL(k_relabel, g, b, 0, s, parent, labels, n, chunkFG);
     NF_CHECK_LAUNCH("label_components");
     NF_HIP(hipMemcpyAsync(numObjects, blockCounts + nblocks, sizeof(int), hipMemcpyDeviceToHost, s));
     NF_HIP(hipStreamSynchronize(s));

@@ -586,7 +586,7 @@ class TileEngine(object):
     def label(self, sn, threshold, negate=False):
         t = self.t
         labels = t.empty((self.H, self.W), dtype=t.int32, device=self.dev)
-        work = t.empty(self.npix + self.npix // 1024 + 8, dtype=t.int32, device=self.dev)
+        work = t.empty(self.npix + 2 * (self.npix // 1024) + 16, dtype=t.int32, device=self.dev)
         n = ctypes.c_int(0)
         check(self.lib.nf_label_components(prec_of(sn), ptr(sn), float(threshold), 1 if negate else 0, ptr(labels), self.H,
                                            self.W, ptr(work), ctypes.byref(n), stream_ptr()), "nf_label_components")

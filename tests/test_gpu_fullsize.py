@@ -88,3 +88,51 @@ def test_injected_clusters_are_recovered(c2):
         y = cat['y_c'][k] * 1e-4
         assert cat['SNR'][k] > 8
         assert abs(y - src['amplitude']) < 5.0 * cat['err_y_c'][k] * 1e-4 + 0.04 * src['amplitude']
+
+
+_PER_WINDOW_WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+from nemo_amd import engine
+m = np.load(%(mpath)r); w = np.load(%(wpath)r)
+eng = engine.TileEngine.get(m.shape)
+rms = eng.noise_map(engine.to_dev(m), engine.to_dev(w), {'noiseGridArcmin': 40.0, 'numNoiseBins': 1}, 0.5 / 60.0)
+np.save(%(opath)r, rms.cpu().numpy())
+print("per-window ok")
+'''
+
+
+def test_noise_block_path_equals_per_window_path(c2, tmp_path):
+    """The single-read block evaluation of makeNoiseMap (DESIGN.md section 3, incl. the magnitude-class route under the bright
+    sources) against the library's other, independent evaluation of nemo/filters.py:407-478 - one workgroup per widened cell
+    window, the window clipped directly (NF_NOISE_BLOCKS=0, read once per process, hence the child process) - on a
+    4096 x 4096 filtered map with heavy tails: float64 sums in another order, so equal as float32 up to rare 1-ulp flips."""
+    import os, subprocess, sys
+    mapsL, wcs, truth, got, fobj = c2
+    rng = np.random.default_rng(23)
+    m = np.asarray(got['data'], dtype=np.float64).copy()
+    yy, xx = np.mgrid[0:SHAPE[0], 0:SHAPE[1]]
+    for k in range(12):        # bright extended objects on top of the filtered noise: blocks with > 256 tail values
+        cy, cx = rng.uniform(100, SHAPE[0] - 100), rng.uniform(100, SHAPE[1] - 100)
+        sl = (slice(int(cy) - 90, int(cy) + 90), slice(int(cx) - 90, int(cx) + 90))
+        m[sl] += 60.0 * m.std() * np.exp(-0.5 * ((yy[sl] - cy) ** 2 + (xx[sl] - cx) ** 2) / rng.uniform(8, 25) ** 2)
+    w = (1.0 + 0.3 * np.sin(xx / 300.0) * np.cos(yy / 170.0))
+    eng = fobj.engine
+    params = {'noiseGridArcmin': 40.0, 'numNoiseBins': 1}
+    blockRMS = eng.noise_map(engine.to_dev(m), engine.to_dev(w), params, 0.5 / 60.0).cpu().numpy()
+    work, ncy, ncx, nb = eng._lastNoiseWork
+    hdr = work.view(torch.int32)[ncy * ncx * 4 * 2:ncy * ncx * 4 * 2 + 8].cpu().numpy()
+    assert hdr[4] > 0, "no heavy block: the class route is not exercised"
+    mpath, wpath, opath = str(tmp_path / "m.npy"), str(tmp_path / "w.npy"), str(tmp_path / "rms.npy")
+    np.save(mpath, m)
+    np.save(wpath, w)
+    script = tmp_path / "worker.py"
+    script.write_text(_PER_WINDOW_WORKER % {'root': os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'mpath': mpath, 'wpath': wpath, 'opath': opath})
+    r = subprocess.run([sys.executable, str(script)], env=dict(os.environ, NF_NOISE_BLOCKS="0"), capture_output=True, text=True,
+                       timeout=240)
+    assert r.returncode == 0 and "per-window ok" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
+    cellRMS = np.load(opath)
+    assert np.array_equal(blockRMS > 0, cellRMS > 0)
+    assert np.abs(blockRMS - cellRMS).max() <= 1.2e-7 * cellRMS.max()
+    assert (blockRMS != cellRMS).mean() < 0.02

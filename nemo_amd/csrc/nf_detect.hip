@@ -124,8 +124,16 @@ __global__ void __launch_bounds__(1024) k_scan_counts(int* __restrict__ blockCou
     const int per = (nblocks + 1023) / 1024, start = threadIdx.x * per;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int sum = 0;
-    for (int i = 0; i < per; ++i)
-        if (start + i < nblocks) sum += blockCounts[start + i];
+    int v16[16];                   // the usual case (up to 16 entries per thread: maps up to 16.8 Mpx) in one batch of loads
+    if (per <= 16) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v16[i] = (i < per && start + i < nblocks) ? blockCounts[start + i] : 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sum += v16[i];
+    } else {
+        for (int i = 0; i < per; ++i)
+            if (start + i < nblocks) sum += blockCounts[start + i];
+    }
     int incl = sum;
     for (int off = 1; off < 64; off <<= 1) {
         const int t = __shfl_up(incl, off, 64);
@@ -138,12 +146,21 @@ __global__ void __launch_bounds__(1024) k_scan_counts(int* __restrict__ blockCou
         if (w < wave) run += waveTot[w];
         total += waveTot[w];
     }
-    for (int i = 0; i < per; ++i)
-        if (start + i < nblocks) {
-            const int v = blockCounts[start + i];
-            blockCounts[start + i] = run;
-            run += v;
-        }
+    if (per <= 16) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (i < per && start + i < nblocks) {
+                blockCounts[start + i] = run;
+                run += v16[i];
+            }
+    } else {
+        for (int i = 0; i < per; ++i)
+            if (start + i < nblocks) {
+                const int v = blockCounts[start + i];
+                blockCounts[start + i] = run;
+                run += v;
+            }
+    }
     if (threadIdx.x == 0) blockCounts[nblocks] = total;
 }
 

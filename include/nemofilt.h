@@ -200,6 +200,10 @@ int nf_subtract(int rtype, const void* a_d, const void* b_d, void* out_d, long l
  * kernel already flipped on both axes (float64, kh x kw, odd sizes). */
 int nf_convolve2d(const float* in_d, float* out_d, int H, int W, const double* kernFlipped_d, int kh, int kw,
                   void* stream);
+/* The same for a float64 map (nemo/filters.py:1189-1193 with bckSub False: the float32 zeros + a float64 cube promote to
+ * float64, so ndimage.convolve runs and returns in float64). */
+int nf_convolve2d_f64(const double* in_d, double* out_d, int H, int W, const double* kernFlipped_d, int kh, int kw,
+                      void* stream);
 
 /* photometry.getObjectPositions, nemo/photometry.py:235-241: labels_d[H*W] int32 = scipy.ndimage.label numbering
  * of (map > threshold) (negate != 0: of (-map > threshold), nemo/photometry.py:54-55); work_d: int32 scratch of

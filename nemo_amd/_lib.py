@@ -71,6 +71,7 @@ SIGNATURES = {
     'nf_restore_zeros': (c_int, [c_int, c_void_p, c_void_p, c_ll, c_void_p]),
     'nf_subtract': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_ll, c_void_p]),
     'nf_convolve2d': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
+    'nf_convolve2d_f64': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
     'nf_label_components': (c_int, [c_int, c_void_p, c_double, c_int, c_void_p, c_int, c_int, c_void_p,
                                     ctypes.POINTER(c_int), c_void_p]),
     'nf_object_stats': (c_int, [c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),

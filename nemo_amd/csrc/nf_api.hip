@@ -520,7 +520,16 @@ int nf_convolve2d(const float* in, float* out, int H, int W, const double* kernF
         return NF_ERR_ARG;
     }
     nf::ProfScope ps(nf::PT_CONVOLVE2D, S(stream), (double)H * W * 8.0);
-    return nf::convolve2d(in, out, H, W, kernFlipped, kh, kw, S(stream));
+    return nf::convolve2d(NF_F32, in, out, H, W, kernFlipped, kh, kw, S(stream));
+}
+
+int nf_convolve2d_f64(const double* in, double* out, int H, int W, const double* kernFlipped, int kh, int kw, void* stream) {
+    if (!in || !out || !kernFlipped || H < 1 || W < 1 || kh < 1 || kw < 1 || in == out) {
+        nf_set_error("nf_convolve2d_f64: bad arguments");
+        return NF_ERR_ARG;
+    }
+    nf::ProfScope ps(nf::PT_CONVOLVE2D, S(stream), (double)H * W * 16.0);
+    return nf::convolve2d(NF_F64, in, out, H, W, kernFlipped, kh, kw, S(stream));
 }
 
 int nf_label_components(int vtype, const void* sn, double threshold, int negate, int* labels, int H, int W, int* work,

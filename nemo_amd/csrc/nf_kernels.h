@@ -39,7 +39,7 @@ int restore_zeros(int vtype, void* data, const void* ref, long long n, hipStream
 int gaussian_filter(int rtype, const void* in, void* tmp, void* out, int H, int W, int batch, const double* wY, int radY,
                     const double* wX, int radX, hipStream_t s);
 int subtract(int rtype, const void* a, const void* b, void* out, long long n, hipStream_t s);
-int convolve2d(const float* in, float* out, int H, int W, const double* kernFlipped, int kh, int kw, hipStream_t s);
+int convolve2d(int rtype, const void* in, void* out, int H, int W, const double* kernFlipped, int kh, int kw, hipStream_t s);
 int edge_check(int vtype, const void* filtered, const unsigned char* psMask, unsigned char* tmp, unsigned char* out, int H, int W,
                int size, hipStream_t s);
 

@@ -5,7 +5,7 @@
 //                         (centre tap, then pairs from the outermost inwards), intermediate stored in the
 //                         map dtype between the two passes.
 //  k_convolve2d   K13     ndimage.convolve (nemo/filters.py:1193): odd kernel, float64 accumulation over the
-//                         flipped kernel in raster order, taps with |w| <= DBL_EPSILON skipped, float32 out.
+//                         flipped kernel in raster order, taps with |w| <= DBL_EPSILON skipped, output in the map dtype.
 //  k_edge_*       K12     ndimage.rank_filter(abs(m + (1 - psMask)), 0, size=(t,t)) > 0 (nemo/filters.py:735,
 //                         1139): a moving-window minimum > 0 is an AND of "pixel != 0" over the window
 //                         [i - t//2, i + t - t//2 - 1]; separable, exact.
@@ -94,11 +94,12 @@ int subtract(int rtype, const void* a, const void* b, void* out, long long n, hi
 
 // ---------------------------------------------------------------------------------------------------
 #define NF_CONV_TILE 32
-__global__ void k_convolve2d(const float* __restrict__ in, float* __restrict__ out, int H, int W, const double* __restrict__ kf,
+template <typename T>
+__global__ void k_convolve2d(const T* __restrict__ in, T* __restrict__ out, int H, int W, const double* __restrict__ kf,
                              int kh, int kw) {
-    // LDS tile of the input (float32) with halo; one output pixel per thread
+    // LDS tile of the input (map dtype) with halo; one output pixel per thread
     extern __shared__ __align__(16) unsigned char nf_smem[];
-    float* tile = (float*)nf_smem;
+    T* tile = (T*)nf_smem;
     const int hy = kh / 2, hx = kw / 2;
     const int tw = NF_CONV_TILE + kw - 1, th = NF_CONV_TILE + kh - 1;
     const int x0 = blockIdx.x * NF_CONV_TILE, y0 = blockIdx.y * NF_CONV_TILE;
@@ -113,28 +114,31 @@ __global__ void k_convolve2d(const float* __restrict__ in, float* __restrict__ o
     if (x >= W || y >= H) return;
     double acc = 0.0;
     for (int fy = 0; fy < kh; ++fy) {
-        const float* trow = tile + (threadIdx.y + fy) * tw + threadIdx.x;
+        const T* trow = tile + (threadIdx.y + fy) * tw + threadIdx.x;
         const double* krow = kf + fy * kw;
         for (int fx = 0; fx < kw; ++fx) {
             double wv = krow[fx];
             if (fabs(wv) > DBL_EPSILON) acc = __dadd_rn(acc, __dmul_rn((double)trow[fx], wv));
         }
     }
-    out[(long long)y * W + x] = (float)acc;
+    out[(long long)y * W + x] = (T)acc;
 }
 
-int convolve2d(const float* in, float* out, int H, int W, const double* kernFlipped, int kh, int kw, hipStream_t s) {
+int convolve2d(int rtype, const void* in, void* out, int H, int W, const double* kernFlipped, int kh, int kw, hipStream_t s) {
     if ((kh % 2) == 0 || (kw % 2) == 0) {
         nf_set_error("convolve2d: kernel dimensions must be odd");
         return NF_ERR_ARG;
     }
-    size_t lds = (size_t)(NF_CONV_TILE + kw - 1) * (NF_CONV_TILE + kh - 1) * sizeof(float);
+    size_t lds = (size_t)(NF_CONV_TILE + kw - 1) * (NF_CONV_TILE + kh - 1) * (rtype == NF_F64 ? sizeof(double) : sizeof(float));
     if (lds > 64 * 1024) {
         nf_set_error("convolve2d: kernel too large for the LDS tile");
         return NF_ERR_SIZE;
     }
     dim3 g(nf_div_up(W, NF_CONV_TILE), nf_div_up(H, NF_CONV_TILE)), b(NF_CONV_TILE, NF_CONV_TILE);
-    hipLaunchKernelGGL(k_convolve2d, g, b, lds, s, in, out, H, W, kernFlipped, kh, kw);
+    if (rtype == NF_F64)
+        hipLaunchKernelGGL(k_convolve2d<double>, g, b, lds, s, (const double*)in, (double*)out, H, W, kernFlipped, kh, kw);
+    else
+        hipLaunchKernelGGL(k_convolve2d<float>, g, b, lds, s, (const float*)in, (float*)out, H, W, kernFlipped, kh, kw);
     NF_CHECK_LAUNCH("k_convolve2d");
     return NF_OK;
 }

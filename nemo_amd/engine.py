@@ -573,13 +573,14 @@ class TileEngine(object):
         check(self.lib.nf_subtract(prec_of(data), ptr(data), ptr(sm), ptr(out), data.numel(), stream_ptr()), "nf_subtract")
         return out
 
-    def convolve(self, m32, kern2d):
-        """scipy.ndimage.convolve(float32 map, float64 kernel), reflect (nemo/filters.py:1193)."""
+    def convolve(self, m, kern2d):
+        """scipy.ndimage.convolve(float32 or float64 map, float64 kernel), reflect, output in the map dtype
+        (nemo/filters.py:1193)."""
         t = self.t
         kf = to_dev(np.array(np.asarray(kern2d, dtype=np.float64)[::-1, ::-1], order='C', copy=True))
-        out = t.empty_like(m32)
-        check(self.lib.nf_convolve2d(ptr(m32), ptr(out), self.H, self.W, ptr(kf), kern2d.shape[0], kern2d.shape[1],
-                                     stream_ptr()), "nf_convolve2d")
+        out = t.empty_like(m)
+        fn = self.lib.nf_convolve2d_f64 if m.dtype == t.float64 else self.lib.nf_convolve2d
+        check(fn(ptr(m), ptr(out), self.H, self.W, ptr(kf), kern2d.shape[0], kern2d.shape[1], stream_ptr()), "nf_convolve2d")
         return out
 
     # ---- detection -----------------------------------------------------------------------------------------

@@ -731,10 +731,7 @@ class RealSpaceMatchedFilter(MapFilter):
                 p = maps.subtractBackground(cube[i], self.wcs, RADeg=self.applyRACentre, decDeg=self.applyDecCentre,
                                             smoothScaleDeg=self.bckSubScaleArcmin / 60.).to(t.float32)
             else:
-                p = cube[i]
-                if p.dtype != t.float32:
-                    raise NotImplementedError("float64 maps with bckSub: False are convolved in float64 by the reference; "
-                                              "not part of this build yet")
+                p = cube[i]       # float32 zeros + cube (:1189): a float64 cube is convolved, and summed, in float64
             planes.append(eng.convolve(p.contiguous(), np.asarray(self.kern2d[i])))         # :1192-1193  K13
         total = planes[0]
         for p in planes[1:]:
@@ -743,7 +740,10 @@ class RealSpaceMatchedFilter(MapFilter):
             self.fRelWeights = {}
             maxValue, maxIndex = eng.map_max(total)
             for plane, mapDict in zip(planes, self.unfilteredMapsDictList):
-                self.fRelWeights[mapDict['obsFreqGHz']] = np.float32(plane.reshape(-1)[maxIndex].item()) / np.float32(maxValue)
+                ft = np.float64 if plane.dtype == t.float64 else np.float32
+                self.fRelWeights[mapDict['obsFreqGHz']] = ft(plane.reshape(-1)[maxIndex].item()) / ft(maxValue)
+        if total.dtype != t.float32:
+            total = total.to(t.float32)                                           # :1205 .astype(np.float32)
         if scale:
             total = total * float(np.float32(self.signalNorm))
         return total

@@ -87,6 +87,18 @@ def _section_slice(wcs, shape, RADecSection):
     return (slice(ya, yb), slice(xa, xb)), type(wcs)(hdr)
 
 
+def radians_map(wcs, shape):
+    """MapFilter.makeRadiansMap (nemo/filters.py:211-236): (degPerPixX, degPerPixY, radiansMap)."""
+    x0, y0 = int(shape[1] / 2), int(shape[0] / 2)
+    ra0, dec0 = wcs.pix2wcs(x0, y0)
+    ra1, dec1 = wcs.pix2wcs(x0 + 1, y0 + 1)
+    degPerPixX = calcAngSepDeg(ra0, dec0, ra1, dec0)
+    degPerPixY = calcAngSepDeg(ra0, dec0, ra0, dec1)
+    xRad = np.arange(int(np.floor(-shape[1] / 2)), int(shape[1] / 2), dtype=np.float64) * np.radians(degPerPixX)
+    yRad = np.arange(int(np.floor(-shape[0] / 2)), int(shape[0] / 2), dtype=np.float64) * np.radians(degPerPixY)
+    return degPerPixX, degPerPixY, np.sqrt(xRad[None, :] ** 2 + yRad[:, None] ** 2)
+
+
 def oracle_realspace(mapsL, wcs, params, kind):
     """Oracle statement of RealSpaceMatchedFilter.buildAndApply (nemo/filters.py:888-1161) on one tile.
     Returns (result dict, dict with kern2d, signalNorm, bckSubScaleArcmin)."""
@@ -100,14 +112,7 @@ def oracle_realspace(mapsL, wcs, params, kind):
         subMaps.append(d)
     _, inner = oracle_matched(subMaps, subWCS, params, kind)
     subShape = subMaps[0]['mapData'].shape
-    x0, y0 = int(subShape[1] / 2), int(subShape[0] / 2)
-    ra0, dec0 = subWCS.pix2wcs(x0, y0)
-    ra1, dec1 = subWCS.pix2wcs(x0 + 1, y0 + 1)
-    degPerPixX = calcAngSepDeg(ra0, dec0, ra1, dec0)
-    degPerPixY = calcAngSepDeg(ra0, dec0, ra0, dec1)
-    xRad = np.arange(int(np.floor(-subShape[1] / 2)), int(subShape[1] / 2), dtype=np.float64) * np.radians(degPerPixX)
-    yRad = np.arange(int(np.floor(-subShape[0] / 2)), int(subShape[0] / 2), dtype=np.float64) * np.radians(degPerPixY)
-    radiansMap = np.sqrt(xRad[None, :] ** 2 + yRad[:, None] ** 2)
+    degPerPixX, degPerPixY, radiansMap = radians_map(subWCS, subShape)
     kern2d, prof, arcminRange = ofilt.crop_kernel(inner.filt, radiansMap, degPerPixX, params['noiseParams']['kernelMaxArcmin'],
                                                   symmetrize=params['noiseParams'].get('symmetrize', False))
     if 'bckSubScaleArcmin' in params:
@@ -138,3 +143,22 @@ def oracle_realspace(mapsL, wcs, params, kind):
                                   wcs.getPixelSizeDeg())
     return res, {'kern2d': kern2d, 'signalNorm': signalNorm, 'bckSubScaleArcmin': bckScale, 'fRelWeights': fRel,
                  'bckSigma': sig}
+
+
+# ---- fixtures made by the reference's own filter classes (tests/golden/make_golden_filters.py) -----------------------
+def load_reference_case(g, k):
+    """Case k of matched_filter.npz / realspace_build.npz -> (mapsL as make_tile returns them, wcs, meta dict)."""
+    import json
+    from nemo_amd.wcs import CARWCS
+    p = 'c%d_' % k
+    meta = json.loads(str(g[p + 'meta']))
+    hdr = json.loads(str(g[p + 'header']))
+    for key in ('NAXIS', 'NAXIS1', 'NAXIS2'):
+        hdr[key] = int(hdr[key])
+    wcs = CARWCS(hdr)
+    mapsL = []
+    for i, (freq, fwhm) in enumerate(zip(meta['freqs'], meta['fwhm'])):
+        mapsL.append({'mapData': g[p + 'data'][i], 'weightsData': g[p + 'weights'][i], 'obsFreqGHz': freq, 'units': 'uK',
+                      'beamFileName': signals.BeamProfile(FWHMArcmin=fwhm), 'label': 'f%03d' % (int(round(freq))), 'wcs': wcs,
+                      'surveyMask': g[p + 'surveyMask'], 'pointSourceMask': g[p + 'psMask']})
+    return mapsL, wcs, meta

@@ -1,0 +1,106 @@
+"""GPU parity against fixtures produced by the reference's OWN filter classes (tests/golden/make_golden_filters.py:
+filters.filterMaps, MatchedFilter.buildAndApply / applyFilter, RealSpaceMatchedFilter.buildKernel / buildAndApply /
+applyFilter of simonsobs/nemo run unmodified, with pixell.enmap served by oracle/nemo_oracle/pixell_restated.py).
+
+Tolerances are those of tests/test_gpu_filters.py (same reasons): float64 maps 5e-6 of the map maximum end to end (the
+template transforms are complex64 and the filter cube a float32 store in the reference itself), float32 maps 2e-3; staged
+with the REFERENCE's filter cube and normalisation in the product object the apply path holds to 1.3e-7 (one float32
+rounding).  Masks and zero patterns are exact."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+import helpers  # noqa: E402
+from nemo_amd import filters  # noqa: E402
+
+GOLDEN = helpers.GOLDEN
+
+
+def _rel(a, b):
+    return np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64)).max() / max(np.abs(b).max(), 1e-300)
+
+
+def _check(got, g, p, tol, what):
+    for key in ('data', 'SNMap', 'RMSMap'):
+        ref = g[p + 'out_' + key]
+        assert got[key].dtype == ref.dtype, (what, key, got[key].dtype, ref.dtype)
+        assert np.array_equal(got[key] != 0, ref != 0) or key != 'RMSMap', (what, key)
+        assert _rel(got[key], ref) < tol, (what, key, _rel(got[key], ref))
+    assert np.array_equal(got['surveyMask'] > 0, g[p + 'out_surveyMask'] > 0), what
+    assert got['surveyMask'].dtype == g[p + 'out_surveyMask'].dtype, what
+
+
+@pytest.mark.parametrize("k", range(12))
+def test_matched_filter_vs_reference_class_code(k):
+    g = np.load(os.path.join(GOLDEN, "matched_filter.npz"))
+    mapsL, wcs, meta = helpers.load_reference_case(g, k)
+    p = 'c%d_' % k
+    f64 = meta['dtype'] == 'float64'
+    tol = 5e-6 if f64 else 2e-3
+    f = {'label': 'ref%d' % k, 'class': meta['class'], 'params': meta['params']}
+    got, fobj = filters.filterMaps(helpers.product_maps(mapsL), dict(f, params=dict(meta['params'])), 'PRIMARY', diagnosticsDir=None,
+                                   selFnDir=None, verbose=False, undoPixelWindow=False, returnFilter=True)
+    what = "case %d %s" % (k, meta)
+    # the product paints its own templates on the GPU: they must be the fixture's (same painter definition)
+    N = len(mapsL)
+    for i, m in enumerate(mapsL):
+        t = fobj.makeSignalTemplateMap(m['beamFileName'])
+        assert np.abs(t - g[p + 'tmplUnit'][i]).max() <= 1e-7 * np.abs(g[p + 'tmplUnit'][i]).max(), what
+    assert fobj.filt.dtype == np.float32 and fobj.filt.shape == g[p + 'filt'].shape
+    assert _rel(fobj.filt, g[p + 'filt']) < tol, (what, _rel(fobj.filt, g[p + 'filt']))
+    assert abs(float(fobj.signalNorm) / float(g[p + 'signalNorm']) - 1) < tol, what
+    assert isinstance(fobj.signalNorm, np.float64) == bool(g[p + 'signalNormIsF64']), what
+    if meta['params']['outputUnits'] == 'yc':
+        rw = np.array([float(fobj.fRelWeights[m['obsFreqGHz']]) for m in mapsL])
+        assert np.abs(rw - g[p + 'fRelWeights']).max() < tol, what
+    _check(got, g, p, tol, what)
+    # pixel-window undo of filterMaps (nemo/filters.py:98-101)
+    got2 = filters.filterMaps(helpers.product_maps(mapsL), dict(f, params=dict(meta['params'])), 'PRIMARY', diagnosticsDir=None,
+                              selFnDir=None, verbose=False, undoPixelWindow=True)
+    ref2 = g[p + 'out_dataUndone']
+    assert got2['data'].dtype == ref2.dtype, what
+    assert _rel(got2['data'], ref2) < tol, what
+    assert np.array_equal(got2['data'] == 0, ref2 == 0), what
+    # staged: the reference's own filter cube and normalisation in the product object (useCachedFilter branch)
+    fobj.filt = g[p + 'filt']
+    sn = g[p + 'signalNorm']
+    fobj.signalNorm = np.float64(sn) if bool(g[p + 'signalNormIsF64']) else np.float32(sn)
+    staged = fobj.buildAndApply(useCachedFilter=True)
+    if f64:
+        _check(staged, g, p, 1.3e-7, what + " staged")
+
+
+@pytest.mark.parametrize("k", range(5))
+def test_realspace_filter_vs_reference_class_code(k, tmp_path):
+    g = np.load(os.path.join(GOLDEN, "realspace_build.npz"))
+    mapsL, wcs, meta = helpers.load_reference_case(g, k)
+    p = 'c%d_' % k
+    f64 = meta['dtype'] == 'float64'
+    what = "case %d %s" % (k, meta)
+    got, fobj = filters.filterMaps(helpers.product_maps(mapsL), {'label': 'rs%d' % k, 'class': meta['class'],
+                                                                'params': dict(meta['params'])},
+                                   'PRIMARY', diagnosticsDir=str(tmp_path), selFnDir=str(tmp_path), verbose=False,
+                                   undoPixelWindow=False, returnFilter=True)
+    kref = g[p + 'kern2d']
+    assert np.asarray(fobj.kern2d).shape == kref.shape, what
+    tol = 5e-5 if f64 else 3e-3
+    assert _rel(fobj.kern2d, kref) < (2e-5 if f64 else 3e-3), (what, _rel(fobj.kern2d, kref))
+    assert abs(fobj.bckSubScaleArcmin - float(g[p + 'bckSubScaleArcmin'])) < 1e-9, what
+    assert abs(float(fobj.signalNorm) / float(g[p + 'signalNorm']) - 1) < (2e-5 if f64 else 3e-3), what
+    rw = np.array([float(fobj.fRelWeights[m['obsFreqGHz']]) for m in mapsL])
+    assert np.abs(rw - g[p + 'fRelWeights']).max() < tol, what
+    _check(got, g, p, tol, what)
+    # with the REFERENCE's kernel and normalisation: convolution + tail bit for bit
+    fobj.kern2d = kref
+    fobj.signalNorm = np.float32(g[p + 'signalNorm'])
+    out = fobj.applyFilter(np.array([m['mapData'] for m in mapsL]))
+    psMask = g[p + 'psMask']
+    refData = g[p + 'out_data']
+    inside = g[p + 'out_surveyMask'] > 0
+    assert out.dtype == np.float32
+    assert np.array_equal((out * psMask)[inside], refData[inside].astype(np.float32)), what

@@ -23,19 +23,34 @@ def torch():
     return _torch
 
 
-_device = None       # (torch.device, index) once a HIP device and the library have been found: one process drives one GPU
+_device = None       # (torch.device, index): the GPU this PROCESS drives (one process per GPU), fixed by the first caller
+
+
+def bind_device(index):
+    """Make HIP device ``index`` the device of this process (pipelines.initDistributed: LOCAL_RANK).  Every thread that
+    later goes through :func:`require_gpu` is switched to it."""
+    global _device
+    t = torch()
+    if not t.cuda.is_available():
+        raise NemoFiltError("no HIP device visible: nemo_amd runs on MI355X (gfx950) only and has no CPU fallback")
+    _lib.load()
+    index = int(index)
+    t.cuda.set_device(index)
+    _device = (t.device('cuda', index), index)
+    return _device[0]
 
 
 def require_gpu():
-    """The HIP device of this process; raises when there is none (no CPU fallback).  Checked once, then cached: this is
-    called from every tensor hand-over, and the availability probe alone costs microseconds of interpreter time."""
+    """The HIP device of this process; raises when there is none (no CPU fallback).  The device is chosen once - the
+    current device of the first caller, or :func:`bind_device` - and never follows per-thread state afterwards: HIP's
+    current device belongs to the host thread and starts at 0 in every new thread, so a worker thread (the detection pool
+    of pipelines.py) that arrives here on another device is switched to the process's device instead of dragging the
+    library over to device 0.  Called from every tensor hand-over: the check is one raw call (~0.1 us)."""
     global _device
     t = torch()
     if _device is not None:
-        if t._C._cuda_getDevice() == _device[1]:      # (a raw call: ~0.1 us; follows a later torch.cuda.set_device)
-            return _device[0]
-        idx = t._C._cuda_getDevice()
-        _device = (t.device('cuda', idx), idx)
+        if t._C._cuda_getDevice() != _device[1]:
+            t.cuda.set_device(_device[1])
         return _device[0]
     if not t.cuda.is_available():
         raise NemoFiltError("no HIP device visible: nemo_amd runs on MI355X (gfx950) only and has no CPU fallback")
@@ -81,8 +96,8 @@ def xmatch_self(RADeg, decDeg, SNR, radiusDeg):
 def stream_ptr():
     """The current HIP stream of the calling thread as a void* (raw handle: no Stream object is built)."""
     t = torch()
-    require_gpu()
-    return ctypes.c_void_p(t._C._cuda_getCurrentRawStream(_device[1]))
+    dev = require_gpu()
+    return ctypes.c_void_p(t._C._cuda_getCurrentRawStream(dev.index))
 
 
 def ptr(t):

@@ -289,11 +289,15 @@ class MapFilter(object):
         return prof, arcminRange
 
     def _realSpaceFilter(self):
-        """fftshift(ifft2(filt).real), float32 [N, H, W] (ifft2 of a real cube = conj(fft2)/n)."""
+        """fftshift(ifft2(filt).real), float32 [N, H, W] (ifft2 of a real cube = conj(fft2)/n).
+
+        The reference calls ``fft.fftshift`` without ``axes`` (nemo/filters.py:288,958), which also rolls the FREQUENCY axis
+        by N // 2: with two maps the planes of the real-space cube - and so of ``kern2d`` and of the 1-D profile - come out
+        swapped.  Kept as it is (found by the fixtures made from the reference's own class code)."""
         F = self.engine.fft(self._dFilt, prec=NF_F32, unitary=False)
         n = np.float32(self.shape[0] * self.shape[1])
         real = _asnumpy(F.real.contiguous()) / n
-        return np.fft.fftshift(real, axes=(-2, -1))
+        return np.fft.fftshift(real)
 
     def loadFRelWeights(self):
         """nemo/filters.py:483-495."""

@@ -40,10 +40,10 @@ def initDistributed():
     local = int(os.environ.get('LOCAL_RANK', '0'))
     backend = os.environ.get('NEMO_AMD_DIST_BACKEND', 'nccl')      # 'gloo' to rehearse several ranks on one GPU
     if torch.cuda.is_available() and backend == 'nccl':
-        torch.cuda.set_device(local % torch.cuda.device_count())
-        dist.init_process_group('nccl', device_id=torch.device('cuda', torch.cuda.current_device()))
+        dev = engine.bind_device(local % torch.cuda.device_count())
+        dist.init_process_group('nccl', device_id=dev)
     elif torch.cuda.is_available():
-        torch.cuda.set_device(local % torch.cuda.device_count())
+        engine.bind_device(local % torch.cuda.device_count())
         dist.init_process_group('gloo')
     else:
         dist.init_process_group('gloo')
@@ -145,7 +145,8 @@ def _detectionWorkers(numWorkers):
     strand the device memory cached for the old one (the allocator keeps one pool per stream), and costs device
     allocations on every call."""
     if numWorkers not in _workers:
-        _workers[numWorkers] = (concurrent.futures.ThreadPoolExecutor(max_workers=numWorkers,
+        # every worker starts by binding itself to the GPU of this process (a new host thread starts on HIP device 0)
+        _workers[numWorkers] = (concurrent.futures.ThreadPoolExecutor(max_workers=numWorkers, initializer=engine.require_gpu,
                                                                       thread_name_prefix="nemo-amd-detect"), _WorkerStreams())
     return _workers[numWorkers]
 
@@ -159,7 +160,7 @@ class _WorkerStreams(object):
     def get(self):
         s = getattr(self._local, 'stream', None)
         if s is None:
-            s = self._local.stream = engine.torch().cuda.Stream()
+            s = self._local.stream = engine.torch().cuda.Stream(device=engine.require_gpu())
         return s
 
 
@@ -168,6 +169,7 @@ def _detectAndMeasure(config, job, stream, invertMap, measureFluxes, photFilter,
     work is enqueued on that HIP stream (called from the detection worker thread) after the filtered maps are complete."""
     label, f, filteredMapDict, photFilteredMapDict, ready = job
     t = engine.torch()
+    engine.require_gpu()        # (this may be a worker thread: same GPU as the thread that filtered the maps)
     if isinstance(stream, _WorkerStreams):
         stream = stream.get()
     ctx = t.cuda.stream(stream) if stream is not None else contextlib.nullcontext()

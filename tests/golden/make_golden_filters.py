@@ -295,8 +295,12 @@ def run_realspace(filters, maps, tmpDir):
                 for key in ('mapData', 'weightsData'):
                     d[key] = np.ascontiguousarray(m[key][sl])
                 sub.append(d)
-            o = reference_filter(filters, innerName, kind, sub, subWCS, np.ascontiguousarray(surveyMask[sl]),
-                                 np.ascontiguousarray(psMask[sl]), p, tmpDir, label=label)
+            # buildKernel strips the mask keys (nemo/filters.py:916-922): the inner filter sees the defaults of
+            # MapDict.preprocess - survey mask = where the weights are non-zero, no point-source mask
+            innerSurvey = np.ones(sub[0]['mapData'].shape, dtype=np.uint8)
+            innerSurvey[sub[0]['weightsData'] == 0] = 0
+            o = reference_filter(filters, innerName, kind, sub, subWCS, innerSurvey,
+                                 np.ones(innerSurvey.shape, dtype=np.uint8), p, tmpDir, label=label)
             inner['obj'] = o
             inner['slice'] = [sl[0].start, sl[0].stop, sl[1].start, sl[1].stop]
             return o

@@ -196,3 +196,48 @@ def test_catalogue_allgather_gloo_world_size_2(tmp_path):
                          timeout=300)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert "rank 0 ok" in out.stdout and "rank 1 ok" in out.stdout
+
+
+def test_worker_threads_are_bound_to_the_process_device(monkeypatch):
+    """HIP's current device is per host thread and starts at 0: a detection worker thread must be switched to the GPU of
+    the process (LOCAL_RANK), never the other way round.  A fake torch.cuda with per-thread device state
+    stands in for the GPU here."""
+    import threading
+    import types
+    from concurrent.futures import ThreadPoolExecutor
+    from nemo_amd import engine, _lib
+
+    tls = threading.local()
+
+    def cur():
+        return getattr(tls, 'dev', 0)
+
+    def set_device(i):
+        tls.dev = int(i)
+    fake = types.SimpleNamespace(
+        cuda=types.SimpleNamespace(is_available=lambda: True, current_device=cur, set_device=set_device, device_count=lambda: 8),
+        _C=types.SimpleNamespace(_cuda_getDevice=cur),
+        device=lambda kind, idx: types.SimpleNamespace(type=kind, index=idx))
+    monkeypatch.setattr(engine, '_torch', fake)
+    monkeypatch.setattr(engine, '_device', None)
+    monkeypatch.setattr(_lib, 'load', lambda: None)
+    assert engine.bind_device(5).index == 5
+    assert cur() == 5
+    seen = {}
+
+    def work():
+        seen['before'] = cur()
+        seen['dev'] = engine.require_gpu().index
+        seen['after'] = cur()
+    with ThreadPoolExecutor(max_workers=1) as pool:
+        pool.submit(work).result()
+    assert seen == {'before': 0, 'dev': 5, 'after': 5}
+    assert engine.require_gpu().index == 5 and cur() == 5      # the main thread was not dragged to device 0
+    # the pool the pipeline uses binds its workers the same way
+    from nemo_amd import pipelines
+    monkeypatch.setattr(pipelines, '_workers', {})
+    pool, streams = pipelines._detectionWorkers(1)
+    try:
+        assert pool.submit(cur).result() == 5
+    finally:
+        pool.shutdown()

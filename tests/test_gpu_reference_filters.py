@@ -52,7 +52,10 @@ def test_matched_filter_vs_reference_class_code(k):
         t = fobj.makeSignalTemplateMap(m['beamFileName'])
         assert np.abs(t - g[p + 'tmplUnit'][i]).max() <= 1e-7 * np.abs(g[p + 'tmplUnit'][i]).max(), what
     assert fobj.filt.dtype == np.float32 and fobj.filt.shape == g[p + 'filt'].shape
-    assert _rel(fobj.filt, g[p + 'filt']) < tol, (what, _rel(fobj.filt, g[p + 'filt']))
+    # filter cube: the template spectra are complex64 in both paths (different FFT algorithms, ~1e-7 apart); the 3 x 3
+    # covariance inverse amplifies that by its condition number, so three frequencies get 2e-5 (measured 5.4e-6)
+    filtTol = tol if (N < 3 or not f64) else 2e-5
+    assert _rel(fobj.filt, g[p + 'filt']) < filtTol, (what, _rel(fobj.filt, g[p + 'filt']))
     assert abs(float(fobj.signalNorm) / float(g[p + 'signalNorm']) - 1) < tol, what
     assert isinstance(fobj.signalNorm, np.float64) == bool(g[p + 'signalNormIsF64']), what
     if meta['params']['outputUnits'] == 'yc':

@@ -374,9 +374,12 @@ class MatchedFilter(MapFilter):
                 self._dFilt, self._signalNorm, self.fRelWeights = cached._dFilt, cached._signalNorm, dict(cached.fRelWeights)
         if haveFile == False and useCachedFilter == False:
             method = self.params['noiseParams']['method']
-            if method not in ['dataMap', 'max(dataMap,CMB)']:
+            if method != 'dataMap':
                 if method == 'model':
                     raise NotImplementedError("noise method 'model' (simulated CMB + white noise) is not part of this build yet")
+                # 'max(dataMap,CMB)' included: the reference's branch for it (nemo/filters.py:574-577) is unreachable, its
+                # loop over the maps raises this for every method but 'dataMap' and 'model' (:539-561; pinned by
+                # tests/golden/matched_filter.npz 'maxDataMapCMB_raises')
                 raise Exception("'%s' is not a valid filter noise method name - fix the .yml config file" % (method))
             if self.params.get('noiseModelCatalog', None) is not None:
                 raise NotImplementedError("noiseModelCatalog needs maps.makeModelImage (scope table row f1)")
@@ -385,9 +388,6 @@ class MatchedFilter(MapFilter):
             else:
                 fMapsForNoise = fMapsToFilter                                     # identical to :548 without a catalog
                 NP = eng.cross_power(fMapsForNoise, half=True)                            # :573  K4
-                if method == 'max(dataMap,CMB)':
-                    NPCMB = engine.to_dev(self.makeForegroundsPower().astype(_asnumpy(NP[0, 0, :1, :1]).dtype))
-                    NP = t.maximum(NP, NPCMB)
                 noiseCov = eng.gaussian_filter(NP, (3, 3))                        # :580  K5
                 del NP
                 if shared is not None:
@@ -506,7 +506,8 @@ class MatchedFilter(MapFilter):
         return np.array(w)
 
     def makeForegroundsPower(self):
-        """nemo/filters.py:261-276: CMB power on the 2-D Fourier grid (flat-sky |l| of the tile)."""
+        """nemo/filters.py:261-276: CMB power on the 2-D Fourier grid (flat-sky |l| of the tile).  Not used on the path: its
+        only caller in the reference is the unreachable 'max(dataMap,CMB)' branch.  |l| convention (enmap.modlmap) unpinned."""
         tab = np.loadtxt(os.path.join(os.path.dirname(__file__), "data", "planck_lensedCls.dat"))
         L, TT = tab[:, 0], tab[:, 1]
         TT = (TT * 2 * np.pi) / (L * (L + 1))

@@ -247,19 +247,21 @@ def findObjects(filteredMapDict, threshold=3.0, minObjPix=3, rejectBorder=10, fi
     return tab
 
 
-def _valuesAt(catalog, mapData, wcs, useInterpolator, negate=False):
+def _valuesAt(catalog, mapData, wcs, useInterpolator, negate=False, allRows=False):
     """_splineAt at the catalogue's positions, or what findObjects already fetched for this map (``_prefetch``)."""
     pre = getattr(catalog, '_prefetched', None)
     if pre is not None:
         hit = pre.get((id(mapData), bool(negate)), None)
-        if hit is not None and hit[2] == len(catalog):
+        if hit is not None and hit[2] == len(catalog) and (not allRows or hit[1].all()):
             return hit[0].copy(), hit[1]
-    return _splineAt(mapData, wcs, catalog['RADeg'], catalog['decDeg'], useInterpolator, negate=negate)
+    return _splineAt(mapData, wcs, catalog['RADeg'], catalog['decDeg'], useInterpolator, negate=negate, allRows=allRows)
 
 
-def _splineAt(mapData, wcs, RADeg, decDeg, useInterpolator, negate=False):
+def _splineAt(mapData, wcs, RADeg, decDeg, useInterpolator, negate=False, allRows=False):
     """Map values at sky positions: RectBivariateSpline(y, x) or nearest pixel (nemo/photometry.py:276-281,354-361).
-    Returns (values, inside) where ``inside`` follows the reference's int(x) > 0 ... bounds test."""
+    Returns (values, inside) where ``inside`` follows getSNRValues' int(x) > 0 ... bounds test (:277); rows outside get 0
+    unless ``allRows`` (measureFluxes evaluates every row, :353-361: the spline clamps positions to the map, the nearest
+    pixel lookup takes Python's negative indices)."""
     d = engine.to_dev(mapData)
     eng = engine.TileEngine.get(d.shape)
     H, W = d.shape
@@ -267,17 +269,23 @@ def _splineAt(mapData, wcs, RADeg, decDeg, useInterpolator, negate=False):
     x, y = np.atleast_1d(x), np.atleast_1d(y)
     inside = (x.astype(np.int64) > 0) & (x.astype(np.int64) < W) & (y.astype(np.int64) > 0) & (y.astype(np.int64) < H)
     vals = np.zeros(len(x), dtype=np.float64)
-    if inside.sum() == 0:
+    use = np.ones(len(x), dtype=bool) if allRows else inside
+    if use.sum() == 0:
         return vals, inside
     if useInterpolator:
-        # the spline is only defined on [0, H-1] x [0, W-1]; FITPACK clamps outside (positions there are masked anyway)
-        yy = np.clip(y[inside], 0.0, H - 1.0)
-        xx = np.clip(x[inside], 0.0, W - 1.0)
-        vals[inside] = eng.spline_eval(d, np.stack([yy, xx], axis=1), negate=negate)
+        # the spline is only defined on [0, H-1] x [0, W-1]; FITPACK clamps outside
+        yy = np.clip(y[use], 0.0, H - 1.0)
+        xx = np.clip(x[use], 0.0, W - 1.0)
+        vals[use] = eng.spline_eval(d, np.stack([yy, xx], axis=1), negate=negate)
     else:
-        iy = np.clip(np.round(y[inside]).astype(np.int64), 0, H - 1)
-        ix = np.clip(np.round(x[inside]).astype(np.int64), 0, W - 1)
-        vals[inside] = _lookup(d, iy, ix).astype(np.float64) * (-1.0 if negate else 1.0)
+        iy, ix = np.round(y[use]).astype(np.int64), np.round(x[use]).astype(np.int64)
+        if allRows:
+            if (iy >= H).any() or (ix >= W).any() or (iy < -H).any() or (ix < -W).any():
+                raise IndexError("measureFluxes: catalogue position outside the map (useInterpolator False)")
+            iy, ix = iy % H, ix % W
+        else:
+            iy, ix = np.clip(iy, 0, H - 1), np.clip(ix, 0, W - 1)
+        vals[use] = _lookup(d, iy, ix).astype(np.float64) * (-1.0 if negate else 1.0)
     return vals, inside
 
 
@@ -334,7 +342,7 @@ def measureFluxes(catalog, filteredMapDict, diagnosticsDir, photFilteredMapDict=
         for k in keysToAdd:
             catalog[prefix + k] = np.zeros(n)
     for data, prefix in zip(mapDataList, prefixList):
-        mapValue, inside = _valuesAt(catalog, data, wcs, useInterpolator)
+        mapValue, inside = _valuesAt(catalog, data, wcs, useInterpolator, allRows=True)
         with np.errstate(divide='ignore', invalid='ignore'):
             if mapUnits == 'yc':
                 catalog[prefix + 'y_c'] = mapValue / 1e-4

@@ -193,8 +193,12 @@ class MatchedFilter(object):
         for the noise term (the reference subtracts ``noiseModelCatalog`` models first, :540-547)."""
         n = len(self.maps)
         self.signalNorm = 1.0                                                     # fresh object state (:207)
-        if self.params['noiseParams']['method'] != 'dataMap':
-            raise NotImplementedError("oracle restates the 'dataMap' noise method only")
+        method = self.params['noiseParams']['method']
+        if method == 'model':
+            raise NotImplementedError("oracle restates the 'dataMap' noise method only ('model' needs pixell's rand_map)")
+        if method != 'dataMap':
+            # including 'max(dataMap,CMB)': its branch at nemo/filters.py:574-577 is dead code, the loop above it raises
+            raise Exception("'%s' is not a valid filter noise method name - fix the .yml config file" % (method))   # :561
         fNoise = np.array([enmap.fft(enmap.apod(m['data'] if noiseData is None else noiseData[i], APOD_PIX))
                            for i, m in enumerate(self.maps)])
         noiseCov = []

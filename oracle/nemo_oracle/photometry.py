@@ -90,3 +90,68 @@ def find_objects(SNMap, flagMask, pix2wcs, threshold=3.0, minObjPix=3, findCente
         for o in catalog:
             o['flags'] = o['flags'] + o['ringFlag']
     return catalog
+
+
+def _whole_map_spline(data):
+    return interpolate.RectBivariateSpline(np.arange(data.shape[0]), np.arange(data.shape[1]), data, kx=3, ky=3)
+
+
+def get_snr_values(catalog, SNMap, wcs2pix, useInterpolator=True, invertMap=False, prefix=''):
+    """photometry.getSNRValues (nemo/photometry.py:251-281) on a list of dict rows, in place."""
+    if invertMap:
+        SNMap = SNMap * -1
+    if useInterpolator:
+        spline = _whole_map_spline(SNMap)
+    for obj in catalog:
+        obj[prefix + 'SNR'] = 0.0
+    for obj in catalog:
+        x, y = wcs2pix(obj['RADeg'], obj['decDeg'])
+        if int(x) > 0 and int(x) < SNMap.shape[1] and int(y) > 0 and int(y) < SNMap.shape[0]:
+            if useInterpolator:
+                obj[prefix + 'SNR'] = spline(y, x)[0][0]
+            else:
+                obj[prefix + 'SNR'] = SNMap[int(round(y)), int(round(x))]
+
+
+def measure_fluxes(catalog, data, wcs2pix, mapUnits, convertToDeltaT, deltaTToJyPerSr=None, photSNMap=None, photData=None,
+                   useInterpolator=True, ycObsFreqGHz=148.0, beamSolidAngle_nsr=None, obsFreqGHz=None):
+    """photometry.measureFluxes (nemo/photometry.py:284-377) on a list of dict rows, in place.  ``mapUnits`` is the
+    BUNIT of the filtered map, ``beamSolidAngle_nsr`` / ``obsFreqGHz`` its BEAMNSR / FREQGHZ cards (None: absent);
+    unit conversions are supplied by the caller (nemo/maps.py:679, nemo/photometry.py:488)."""
+    if photSNMap is not None:
+        get_snr_values(catalog, photSNMap, wcs2pix, prefix='fixed_', useInterpolator=useInterpolator)
+    reportJyFluxes = beamSolidAngle_nsr is not None
+    mapDataList, prefixList = [data], ['']
+    if photData is not None:
+        mapDataList.append(photData)
+        prefixList.append('fixed_')
+    splines = [_whole_map_spline(d) if useInterpolator else None for d in mapDataList]
+    keysToAdd = ['deltaT_c', 'err_deltaT_c']
+    if mapUnits == 'yc':
+        keysToAdd = keysToAdd + ['y_c', 'err_y_c']
+    elif mapUnits == 'uK':
+        keysToAdd = keysToAdd + ['fluxJy', 'err_fluxJy']
+    for obj in catalog:
+        for prefix in prefixList:
+            for k in keysToAdd:
+                obj[prefix + k] = 0.0
+    with np.errstate(divide='ignore', invalid='ignore'):
+        for obj in catalog:
+            x, y = wcs2pix(obj['RADeg'], obj['decDeg'])
+            for d, prefix, spline in zip(mapDataList, prefixList, splines):
+                if useInterpolator:
+                    mapValue = spline(y, x)[0][0]
+                else:
+                    mapValue = d[int(round(y)), int(round(x))]
+                if mapUnits == 'yc':
+                    obj[prefix + 'y_c'] = mapValue / 1e-4
+                    obj[prefix + 'err_y_c'] = obj[prefix + 'y_c'] / obj[prefix + 'SNR']
+                    deltaTc = convertToDeltaT(mapValue, obsFrequencyGHz=ycObsFreqGHz)
+                    obj[prefix + 'deltaT_c'] = deltaTc
+                    obj[prefix + 'err_deltaT_c'] = abs(deltaTc / obj[prefix + 'SNR'])
+                elif mapUnits == 'uK':
+                    obj[prefix + 'deltaT_c'] = mapValue
+                    obj[prefix + 'err_deltaT_c'] = mapValue / obj[prefix + 'SNR']
+                    if reportJyFluxes:
+                        obj[prefix + 'fluxJy'] = deltaTToJyPerSr(obj[prefix + 'deltaT_c'], obsFreqGHz) * beamSolidAngle_nsr * 1.e-9
+                        obj[prefix + 'err_fluxJy'] = deltaTToJyPerSr(obj[prefix + 'err_deltaT_c'], obsFreqGHz) * beamSolidAngle_nsr * 1.e-9

@@ -23,7 +23,11 @@ delegates to ABSENT third-party code is served as follows, and THAT is the only 
   maps.MapDict (FITS tile loader) / maps.saveFITS / the inner filter's constructor
                                                  <- in-memory stand-ins that only carry arrays (no arithmetic)
 
-Usage:  python tests/golden/make_golden_filters.py     (writes tests/golden/matched_filter.npz, realspace_build.npz)
+  photometry.getSNRValues / measureFluxes / deltaTToJyPerSr   nemo/photometry.py:251-377, 488-502  (astropy Table rows
+                                                  <- dict rows; astropy.constants <- CODATA 2018 values)
+
+Usage:  python tests/golden/make_golden_filters.py     (writes tests/golden/matched_filter.npz, realspace_build.npz,
+                                                        measure_fluxes.npz)
 """
 import json
 import os
@@ -68,6 +72,7 @@ def install_reference():
     signals.constants = types.SimpleNamespace(h=_V(psignals._h_planck), k_B=_V(psignals._k_B), sigma_T=_V(6.6524587321e-29),
                                               m_e=_V(9.1093837015e-31), c=_V(299792458.0))
     maps.saveFITS = lambda *a, **k: None
+
     return filters, maps, signals
 
 
@@ -235,6 +240,21 @@ def run_matched(filters, tmpDir):
         assert np.array_equal(np.asarray(res['SNMap']), np.asarray(pre['SNMap']))
         print("matched case %d: %s N=%d %s %s shape=%s signalNorm=%r" % (k, c['clsName'], c['N'], np.dtype(c['dtype']).name,
                                                                          c['params']['outputUnits'], c['shape'], obj.signalNorm))
+    # noise method 'max(dataMap,CMB)': the branch at nemo/filters.py:574-577 cannot be reached - the loop that builds
+    # fMapsForNoise (:539-561) raises for every method other than 'dataMap' and 'model'.  Record what the reference does.
+    c = cases[0]
+    mapsL, wcs, surveyMask, psMask = make_inputs(c['shape'], c['freqs'], c['fwhm'], c['noise'], c['seed'], c['kind'], c['dtype'],
+                                                 c['holes'])
+    params = json.loads(json.dumps(c['params']))
+    params['noiseParams']['method'] = 'max(dataMap,CMB)'
+    obj = reference_filter(filters, c['clsName'], c['kind'], mapsL, wcs, surveyMask, psMask, params, tmpDir, label='goldenMax')
+    try:
+        obj.buildAndApply()
+        message = ''
+    except Exception as e:
+        message = str(e)
+    assert message != ''
+    out['maxDataMapCMB_raises'] = np.array(message)
     out['ncases'] = np.int64(len(cases))
     np.savez_compressed(os.path.join(HERE, 'matched_filter.npz'), **out)
 
@@ -333,11 +353,82 @@ def run_realspace(filters, maps, tmpDir):
     np.savez_compressed(os.path.join(HERE, 'realspace_build.npz'), **out)
 
 
+class RowTable(object):
+    """Stands where the astropy Table stands in photometry.getSNRValues / measureFluxes: rows are dicts."""
+
+    def __init__(self, RADeg, decDeg, SNR):
+        self.rows = [{'RADeg': float(r), 'decDeg': float(d), 'SNR': float(s)} for r, d, s in zip(RADeg, decDeg, SNR)]
+
+    def __len__(self):
+        return len(self.rows)
+
+    def __iter__(self):
+        return iter(self.rows)
+
+    def add_column(self, col):
+        data, name = col
+        for row, v in zip(self.rows, data):
+            row[name] = float(v)
+
+
+def run_fluxes():
+    """photometry.getSNRValues / measureFluxes (nemo/photometry.py:251-377) and deltaTToJyPerSr (:488-502) as they are."""
+    from nemo import photometry
+    photometry.atpy = types.SimpleNamespace(Column=lambda data, name: (data, name))
+    cgs = lambda v: types.SimpleNamespace(cgs=_V(v))    # noqa: E731
+    photometry.constants = types.SimpleNamespace(k_B=cgs(psignals._k_B * 1e7), h=cgs(psignals._h_planck * 1e7),
+                                                 c=cgs(psignals.CLight * 100.0))
+    shape = (90, 110)
+    wcs = CARWCS.make(shape, RADeg=40.0, decDeg=-3.0)
+    out = {'header': np.array(header_json(wcs)), 'ncases': np.int64(4)}
+    rng = np.random.default_rng(77)
+    x = np.concatenate([rng.uniform(1.0, shape[1] - 2.0, 40), [0.3, 0.9, 5.2, shape[1] - 1.4, 55.5]])
+    y = np.concatenate([rng.uniform(1.0, shape[0] - 2.0, 40), [10.0, 0.4, 0.95, 30.0, shape[0] - 1.2]])
+    RADeg, decDeg = wcs.pix2wcs(x, y)
+    out['RADeg'], out['decDeg'] = RADeg, decDeg
+    for k, (units, dtype, usePhot, useInterp, jy) in enumerate([('yc', np.float64, True, True, False),
+                                                                 ('uK', np.float32, True, True, True),
+                                                                 ('uK', np.float64, False, True, False),
+                                                                 ('yc', np.float64, True, False, False)]):
+        scale = 1e-4 if units == 'yc' else 300.0
+        data = (MG.correlated_map(shape, 700 + k, sigmaPix=2.5) * scale).astype(dtype)
+        sn = (MG.correlated_map(shape, 710 + k, sigmaPix=2.5) * 3.0).astype(dtype)
+        photData = (MG.correlated_map(shape, 720 + k, sigmaPix=3.5) * scale).astype(dtype)
+        photSN = (MG.correlated_map(shape, 730 + k, sigmaPix=3.5) * 3.0).astype(dtype)
+        w = wcs.copy()
+        w.header['BUNIT'] = units
+        if jy:
+            w.header['BEAMNSR'] = 187.3
+            w.header['FREQGHZ'] = 97.8
+        snr = 4.0 + 10.0 * rng.uniform(size=len(x))
+        snr[3] = 0.0                                    # a zero S/N row: the error columns divide by it
+        tab = RowTable(RADeg, decDeg, snr)
+        fmd = {'data': data, 'SNMap': sn, 'wcs': w}
+        phot = {'data': photData, 'SNMap': photSN} if usePhot else None
+        with np.errstate(divide='ignore', invalid='ignore'):
+            photometry.measureFluxes(tab, fmd, None, photFilteredMapDict=phot, useInterpolator=useInterp)
+        tab2 = RowTable(RADeg, decDeg, snr)
+        photometry.getSNRValues(tab2, sn, w, useInterpolator=useInterp, invertMap=True, prefix='inv_')
+        p = 'c%d_' % k
+        out[p + 'meta'] = np.array(json.dumps({'units': units, 'usePhot': usePhot, 'useInterpolator': useInterp, 'jy': jy,
+                                               'BEAMNSR': 187.3 if jy else None, 'FREQGHZ': 97.8 if jy else None}))
+        out[p + 'data'], out[p + 'SNMap'], out[p + 'photData'], out[p + 'photSNMap'] = data, sn, photData, photSN
+        out[p + 'SNR'] = snr
+        cols = sorted(k2 for k2 in tab.rows[0].keys() if k2 not in ('RADeg', 'decDeg', 'SNR'))
+        out[p + 'cols'] = np.array(json.dumps(cols))
+        for c in cols:
+            out[p + 'col_' + c] = np.array([_plain(float(r[c])) for r in tab.rows])
+        out[p + 'col_inv_SNR'] = np.array([_plain(float(r['inv_SNR'])) for r in tab2.rows])
+        print("fluxes case %d: %s cols %s" % (k, units, cols))
+    np.savez_compressed(os.path.join(HERE, 'measure_fluxes.npz'), **out)
+
+
 def main():
     filters, maps, signals = install_reference()
     with tempfile.TemporaryDirectory() as tmpDir:
         run_matched(filters, tmpDir)
         run_realspace(filters, maps, tmpDir)
+    run_fluxes()
     print("golden vectors written to", HERE)
 
 

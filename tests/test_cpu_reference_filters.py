@@ -114,3 +114,44 @@ def test_oracle_realspace_kernel_from_the_reference_inner_filter_is_bit_exact():
                                                       meta['params']['noiseParams']['kernelMaxArcmin'],
                                                       symmetrize=meta['params']['noiseParams'].get('symmetrize', False))
         assert np.array_equal(kern2d, g[p + 'kern2d']), k
+
+
+def test_oracle_measure_fluxes_equals_reference_code():
+    """photometry.getSNRValues / measureFluxes restated in the oracle vs the reference's own functions
+    (nemo/photometry.py:251-377): same scipy calls -> bit for bit, including rows on the first pixel row / column (measured
+    without a bounds test by measureFluxes, zeroed by getSNRValues) and a zero-S/N row (inf / nan error columns)."""
+    import json
+    from nemo_amd import photometry as pphot
+    from nemo_amd.wcs import CARWCS
+    from nemo_oracle import photometry as ophot
+    g = np.load(os.path.join(GOLDEN, "measure_fluxes.npz"))
+    hdr = json.loads(str(g['header']))
+    for key in ('NAXIS', 'NAXIS1', 'NAXIS2'):
+        hdr[key] = int(hdr[key])
+    wcs = CARWCS(hdr)
+    for k in range(int(g['ncases'])):
+        p = 'c%d_' % k
+        meta = json.loads(str(g[p + 'meta']))
+        cat = [{'RADeg': float(r), 'decDeg': float(d), 'SNR': float(s)} for r, d, s in zip(g['RADeg'], g['decDeg'], g[p + 'SNR'])]
+        ophot.measure_fluxes(cat, g[p + 'data'], wcs.wcs2pix, meta['units'], signals.convertToDeltaT, pphot.deltaTToJyPerSr,
+                             photSNMap=g[p + 'photSNMap'] if meta['usePhot'] else None,
+                             photData=g[p + 'photData'] if meta['usePhot'] else None, useInterpolator=meta['useInterpolator'],
+                             beamSolidAngle_nsr=meta['BEAMNSR'], obsFreqGHz=meta['FREQGHZ'])
+        for c in json.loads(str(g[p + 'cols'])):
+            assert np.array_equal(np.array([o[c] for o in cat]), g[p + 'col_' + c], equal_nan=True), (k, c)
+        cat2 = [{'RADeg': float(r), 'decDeg': float(d)} for r, d in zip(g['RADeg'], g['decDeg'])]
+        ophot.get_snr_values(cat2, g[p + 'SNMap'], wcs.wcs2pix, useInterpolator=meta['useInterpolator'], invertMap=True, prefix='inv_')
+        assert np.array_equal(np.array([o['inv_SNR'] for o in cat2]), g[p + 'col_inv_SNR']), k
+
+
+def test_noise_method_max_datamap_cmb_raises_as_the_reference_does():
+    """The reference's 'max(dataMap,CMB)' branch (nemo/filters.py:574-577) is unreachable: the loop at :539-561 raises for
+    it.  The fixture records the reference's own exception; the oracle raises the same."""
+    g = np.load(os.path.join(GOLDEN, "matched_filter.npz"))
+    message = str(g['maxDataMapCMB_raises'])
+    assert message == "'max(dataMap,CMB)' is not a valid filter noise method name - fix the .yml config file"
+    mapsL, wcs, meta = helpers.load_reference_case(g, 0)
+    params = dict(meta['params'], noiseParams=dict(meta['params']['noiseParams'], method='max(dataMap,CMB)'))
+    with pytest.raises(Exception) as e:
+        helpers.oracle_matched(mapsL, wcs, params, meta['kind'])
+    assert str(e.value) == message

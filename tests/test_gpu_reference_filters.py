@@ -107,3 +107,54 @@ def test_realspace_filter_vs_reference_class_code(k, tmp_path):
     inside = g[p + 'out_surveyMask'] > 0
     assert out.dtype == np.float32
     assert np.array_equal((out * psMask)[inside], refData[inside].astype(np.float32)), what
+
+
+@pytest.mark.parametrize("k", range(4))
+def test_measure_fluxes_vs_reference_code(k):
+    """Every flux column of photometry.measureFluxes / getSNRValues against the reference's own functions
+    (nemo/photometry.py:251-377; fixtures: tests/golden/measure_fluxes.npz).  The device spline is a +-32 pixel window of the
+    whole-map FITPACK spline (1e-16 of it): float64 maps 1e-12 relative, float32 maps 1e-6."""
+    import json
+    from nemo_amd import photometry, catalogs
+    from nemo_amd.wcs import CARWCS
+    g = np.load(os.path.join(GOLDEN, "measure_fluxes.npz"))
+    hdr = json.loads(str(g['header']))
+    for key in ('NAXIS', 'NAXIS1', 'NAXIS2'):
+        hdr[key] = int(hdr[key])
+    p = 'c%d_' % k
+    meta = json.loads(str(g[p + 'meta']))
+    wcs = CARWCS(hdr)
+    wcs.header['BUNIT'] = meta['units']
+    if meta['jy']:
+        wcs.header['BEAMNSR'] = meta['BEAMNSR']
+        wcs.header['FREQGHZ'] = meta['FREQGHZ']
+    tab = catalogs.Table(cols={'RADeg': g['RADeg'], 'decDeg': g['decDeg'], 'SNR': g[p + 'SNR']})
+    fmd = {'data': g[p + 'data'], 'SNMap': g[p + 'SNMap'], 'wcs': wcs}
+    phot = {'data': g[p + 'photData'], 'SNMap': g[p + 'photSNMap']} if meta['usePhot'] else None
+    with np.errstate(divide='ignore', invalid='ignore'):
+        photometry.measureFluxes(tab, fmd, None, photFilteredMapDict=phot, useInterpolator=meta['useInterpolator'])
+    tol = 1e-12 if g[p + 'data'].dtype == np.float64 else 1e-6
+    cols = json.loads(str(g[p + 'cols']))
+    assert sorted(c for c in tab.keys() if c not in ('RADeg', 'decDeg', 'SNR')) == cols
+    for c in cols:
+        ref, got = g[p + 'col_' + c], np.asarray(tab[c], dtype=np.float64)
+        fin = np.isfinite(ref)
+        assert np.array_equal(np.isnan(ref), np.isnan(got)) and np.array_equal(np.isinf(ref), np.isinf(got)), (k, c)
+        scale = np.abs(ref[fin]).max()
+        assert np.abs(got[fin] - ref[fin]).max() <= tol * scale, (k, c, np.abs(got[fin] - ref[fin]).max() / scale)
+    tab2 = catalogs.Table(cols={'RADeg': g['RADeg'], 'decDeg': g['decDeg']})
+    photometry.getSNRValues(tab2, g[p + 'SNMap'], wcs, useInterpolator=meta['useInterpolator'], invertMap=True, prefix='inv_')
+    ref = g[p + 'col_inv_SNR']
+    assert np.array_equal(ref == 0, tab2['inv_SNR'] == 0)
+    assert np.abs(tab2['inv_SNR'] - ref).max() <= tol * np.abs(ref).max()
+
+
+def test_noise_method_max_datamap_cmb_raises_as_the_reference_does():
+    g = np.load(os.path.join(GOLDEN, "matched_filter.npz"))
+    message = str(g['maxDataMapCMB_raises'])
+    mapsL, wcs, meta = helpers.load_reference_case(g, 0)
+    params = dict(meta['params'], noiseParams=dict(meta['params']['noiseParams'], method='max(dataMap,CMB)'))
+    with pytest.raises(Exception) as e:
+        filters.filterMaps(helpers.product_maps(mapsL), {'label': 'x', 'class': meta['class'], 'params': params}, 'PRIMARY',
+                           diagnosticsDir=None, selFnDir=None, verbose=False)
+    assert str(e.value) == message

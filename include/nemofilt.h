@@ -233,6 +233,16 @@ size_t nf_xmatch_workspace_bytes(int n);
 int nf_xmatch_self(const double* unit_d, const double* snr_d, int n, double radiusDeg, int* count_d, int* best_d,
                    unsigned char* drop_d, int* nearFlag_d, void* work_d, size_t workBytes, void* stream);
 
+/* nf_xmatch_self for callers that cannot allocate.  It has NO counterpart in the reference: it is for callers that cannot
+ * call hipMalloc - code under HIP graph capture, tight serving loops, harnesses that forbid allocation.  Same kernels and
+ * results as nf_xmatch_self, but the per-slice partial results live in a file-scope device array of the library (6 MiB on
+ * each GPU the library runs on, held until the process ends) instead of a caller workspace, so n is limited to
+ * nf_xmatch_static_max_rows() = 16384 rows; more is refused with NF_ERR_SIZE.  The call allocates nothing.  Every call on
+ * one GPU shares that GPU's array: calls that overlap on one GPU (two streams, two threads) race - serialise them. */
+int nf_xmatch_static_max_rows(void);
+int nf_xmatch_self_static(const double* unit_d, const double* snr_d, int n, double radiusDeg, int* count_d, int* best_d,
+                          unsigned char* drop_d, int* nearFlag_d, void* stream);
+
 /* nemo/photometry.py:69-73: isRing_d[id] = 1 if component id has > minRingPix pixels and its centre of mass is
  * not one of its own pixels. */
 int nf_ring_flags(const int* ringLabels_d, const double* ringStats_d, int numRing, int minRingPix, int H, int W,

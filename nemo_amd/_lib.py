@@ -78,6 +78,8 @@ SIGNATURES = {
     'nf_xmatch_workspace_bytes': (c_size_t, [c_int]),
     'nf_xmatch_self': (c_int, [c_void_p, c_void_p, c_int, c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                c_void_p]),
+    'nf_xmatch_static_max_rows': (c_int, []),
+    'nf_xmatch_self_static': (c_int, [c_void_p, c_void_p, c_int, c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'nf_map_max': (c_int, [c_int, c_void_p, c_ll, c_void_p, c_void_p]),
     'nf_ring_flags': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     'nf_profile_enable': (c_int, [c_int]),

@@ -565,6 +565,19 @@ int nf_xmatch_self(const double* unit_d, const double* snr_d, int n, double radi
     return nf::xmatch_self(unit_d, snr_d, n, lo * lo, hi * hi, count_d, best_d, drop_d, nearFlag_d, work_d, workBytes, S(stream));
 }
 
+int nf_xmatch_static_max_rows(void) { return NF_XM_STATIC_MAX_ROWS; }
+
+int nf_xmatch_self_static(const double* unit_d, const double* snr_d, int n, double radiusDeg, int* count_d, int* best_d,
+                          unsigned char* drop_d, int* nearFlag_d, void* stream) {
+    if (!unit_d || !snr_d || !count_d || !best_d || !drop_d || !nearFlag_d || n < 1 || !(radiusDeg > 0.0)) {
+        nf_set_error("nf_xmatch_self_static: bad arguments");
+        return NF_ERR_ARG;
+    }
+    const double lim = 2.0 * std::sin(radiusDeg * 3.14159265358979323846 / 180.0 / 2.0);
+    const double lo = lim * (1.0 - 1e-9), hi = lim * (1.0 + 1e-9);
+    return nf::xmatch_self_static(unit_d, snr_d, n, lo * lo, hi * hi, count_d, best_d, drop_d, nearFlag_d, S(stream));
+}
+
 int nf_map_max(int vtype, const void* map, long long n, double* out, void* stream) {
     if (!map || !out || n < 1) {
         nf_set_error("nf_map_max: bad arguments");

@@ -16,6 +16,8 @@
 #include "nf_common.h"
 #include "nf_kernels.h"
 
+#include <mutex>
+
 namespace nf {
 
 static inline int grid_for(long long n, int threads) {
@@ -822,6 +824,55 @@ int xmatch_self(const double* u, const double* snr, int n, double lo2, double hi
     hipLaunchKernelGGL(k_xmatch_drop, dim3(g, NF_XM_SLICES), dim3(NF_XM_THREADS), 0, s, u, n, lo2, hi2, count, best, drop);
     NF_CHECK_LAUNCH("k_xmatch");
     return NF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// xmatch_self for callers that cannot allocate (HIP graph capture, serving loops): the per-slice partial results live in a
+// file-scope device array instead of a caller workspace.  Each GPU the library runs on holds its own copy of the array (at
+// its own address) until the process ends; host code never uses the array's NAME as an address - it asks the runtime for the
+// address once per device (hipGetSymbolAddress, below) and passes that pointer to the kernels, as xmatch_self passes `work`.
+// Nothing in the array has to start at zero: k_xmatch_best_part writes every record (all NF_XM_SLICES slices of every row
+// i < n) before k_xmatch_merge reads it.  All calls on one GPU share the array: calls that overlap on one GPU race.
+static __device__ __align__(256) unsigned char nf_xm_scratch[(size_t)NF_XM_SLICES * NF_XM_STATIC_MAX_ROWS * sizeof(XmPart)];
+
+namespace {
+const int kMaxDevices = 64;
+void* g_xmScratchPtr[kMaxDevices];       // device address of nf_xm_scratch per HIP device, 0 until first asked for
+std::mutex g_xmScratchMu;
+}  // namespace
+
+int xmatch_static_scratch(void** ptr) {
+    int dev = -1;
+    NF_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= kMaxDevices) {
+        nf_set_error("xmatch_self_static: unexpected device index");
+        return NF_ERR_ARG;
+    }
+    std::lock_guard<std::mutex> lock(g_xmScratchMu);
+    if (!g_xmScratchPtr[dev]) {
+        void* p = nullptr;
+        hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(nf_xm_scratch));     // the address on the CURRENT device
+        if (e != hipSuccess) return nf_hip_fail(e, "hipGetSymbolAddress(nf_xm_scratch)");
+        if (!p) {
+            nf_set_error("xmatch_self_static: no device address for the scratch array");
+            return NF_ERR_HIP;
+        }
+        g_xmScratchPtr[dev] = p;
+    }
+    *ptr = g_xmScratchPtr[dev];
+    return NF_OK;
+}
+
+int xmatch_self_static(const double* u, const double* snr, int n, double lo2, double hi2, int* count, int* best, unsigned char* drop,
+                       int* nearFlag, hipStream_t s) {
+    if (n > NF_XM_STATIC_MAX_ROWS) {
+        nf_set_error("xmatch_self_static: more than NF_XMATCH_STATIC_MAX_ROWS (16384) rows - use nf_xmatch_self with a workspace");
+        return NF_ERR_SIZE;
+    }
+    void* work = nullptr;
+    int rc = xmatch_static_scratch(&work);
+    if (rc) return rc;
+    return xmatch_self(u, snr, n, lo2, hi2, count, best, drop, nearFlag, work, xmatch_workspace_bytes(n), s);
 }
 
 }  // namespace nf

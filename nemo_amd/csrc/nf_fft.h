@@ -63,6 +63,7 @@ struct LineArgs {
     int halfIn;              //   ... of a spectrum of a real map that is stored for c <= W/2 only (the mirror mode is the
                              //   conjugate of the stored one; only its filter value and window factor are fetched)
     int realH, realW;        // shape of the real map (H rows, W columns)
+    int packNyq;             // columns kernel: lane 0 of tile 0 carries columns 0 and W/2 as one complex column (nLines = W/2)
     // rows kernel, pairMode 2 (real output): optional epilogues on the value being stored (batch 1 only)
     const double* epiScale;          // device scalar: out = (float)value * scale (* epiMask), formed in the output type
     const unsigned char* epiMask;    //   mask multiplied in after the scale
@@ -77,6 +78,8 @@ struct Plan2D {
     LinePlan<T> row, col;
     int rowsPerWG, colsPerWG, threadsRow, tbRow, threadsCol;
     int useReal;    // real-data fast paths enabled (NF_FFT_REAL=0 switches them off)
+    int packNyq;    // columns 0 and W/2 of half spectra share one complex column (NF_FFT_PACK_NYQ=0 switches it off)
+    bool packOk() const;
     int init(int H, int W);
     void destroy();
     int forward(const void* in, int inType, void* out, int batch, const double* apodY, const double* apodX,

@@ -333,7 +333,25 @@ __device__ __forceinline__ void fft_stage(cpx<T>* __restrict__ buf, const nf::Li
                     for (int k = 0; k < R; ++k)
                         x[k] = fused_ops_herm<T>(a, G, x[k], lo + idx[k] * (unsigned)a.inElemStride, G.line0 + line, (int)idx[k]);
                 }
-                if (COLS && SPEC == 3) {
+                if (COLS && a.packNyq && G.line0 + line == 0) {
+                    // lane 0 of tile 0 carries columns 0 and W/2 as ONE complex column z0 + i zN (see k_fft_cols): fetch the
+                    // Nyquist column's operands the general way and fold them in.  Forward: both columns are real.
+                    const int colN = a.realW / 2;
+#pragma unroll
+                    for (int k = 0; k < R; ++k) {
+                        const unsigned offN = (unsigned)colN * (unsigned)a.inLineStride + idx[k] * (unsigned)a.inElemStride;
+                        cpx<T> zN = load_elem<T, 0>(a, G.inP, offN, 1.0, (int)idx[k]);
+                        if (SPEC >= 2) {
+                            zN = fused_ops_herm<T>(a, G, zN, offN, colN, (int)idx[k]);
+                            if (SPEC == 3) x[k] = fused_ops_herm<T>(a, G, x[k], lo + idx[k] * (unsigned)a.inElemStride, 0, (int)idx[k]);
+                        } else {
+                            x[k].y = (T)0;
+                            zN.y = (T)0;
+                        }
+                        x[k].x -= zN.y;
+                        x[k].y += zN.x;
+                    }
+                } else if (COLS && SPEC == 3) {
                     // fused_ops_herm for ONE half-stored plane (the matched filter's own case): the real factor
                     // filtSym[k] * win[k] per element, its operands fetched in one batch like the data
                     const int col = G.line0 + line;
@@ -377,7 +395,22 @@ __device__ __forceinline__ void fft_stage(cpx<T>* __restrict__ buf, const nf::Li
         const unsigned e = base + (unsigned)k * L;                                                                \
         if (!BLUE || e < (unsigned)p.n) store_elem<T, OT, BLUE>(a, G.outP, lo + e * (unsigned)a.outElemStride, (int)e, x[k]); \
     }
-                if (COLS && SPEC == 1) {
+                if (COLS && SPEC >= 2 && a.packNyq && G.line0 + line == 0) {
+                    // inverse of the packed column: the two real columns come back as real and imaginary part
+                    const T r = (T)a.scale, ri = r * (T)a.conjOutSign;
+                    const unsigned colN = (unsigned)(a.realW / 2);
+#pragma unroll
+                    for (int k = 0; k < R; ++k) {
+                        const unsigned e = base + (unsigned)k * L;
+                        cpx<T> v0, vN;
+                        v0.x = x[k].x * r;
+                        v0.y = (T)0;
+                        vN.x = x[k].y * ri;
+                        vN.y = (T)0;
+                        ((cpx<T>*)G.outP)[e * (unsigned)a.outElemStride] = v0;
+                        ((cpx<T>*)G.outP)[e * (unsigned)a.outElemStride + colN] = vN;
+                    }
+                } else if (COLS && SPEC == 1) {
                     // spectrum of a real map: F[-y][-c] = conj F[y][c]; this tile holds columns c <= W/2 and writes both
                     NF_STORE_ALL(0)
                     const unsigned col = (unsigned)(G.line0 + line);
@@ -829,6 +862,10 @@ __global__ void __launch_bounds__(512, (MODE == 0 ? 4 : 2)) k_fft_rows(nf::LineA
 }
 
 // Columns: a tile of TL = linesPerWG adjacent lines (elemStride = row pitch, lineStride 1).  LDS layout [swz(e)][line].
+// packNyq (half-plane passes of real maps, W even): lane 0 of tile 0 carries columns 0 and W/2 as one complex column
+// c0 + i cN - before the forward column pass both are real (row spectra at k = 0 and k = W/2), before the inverse one both
+// are Hermitian along y, so their transforms separate again (forward: with the mirror element; inverse: real / imaginary
+// part).  The pass then covers W/2 columns instead of W/2 + 1.
 template <typename T, int MODE, int SPEC>
 __global__ void __launch_bounds__((MODE == 0 && SPEC == 3 && sizeof(T) == 8) ? 512 : NF_FFT_MAXTHREADS) k_fft_cols(nf::LineArgs<T> a) {
     extern __shared__ __align__(16) unsigned char nf_smem[];
@@ -874,7 +911,39 @@ __global__ void __launch_bounds__((MODE == 0 && SPEC == 3 && sizeof(T) == 8) ? 5
         bluestein_middle<T, true, MODE>(buf, a, G);
         for (int s = 0; s < p.nst; ++s) fft_stage_dispatch<T, true, MODE, SPEC>(buf, a, s, false, false, s == p.nst - 1, G);
     } else {
-        for (int s = 0; s < p.nst; ++s) fft_stage_dispatch<T, true, MODE, SPEC>(buf, a, s, false, s == 0, s == p.nst - 1, G);
+        // packNyq, forward: Z = FFT(c0 + i cN) is unpacked with its mirror element, G0[k] = (Z[k] + conj Z[-k]) / 2,
+        // GN[k] = -i (Z[k] - conj Z[-k]) / 2 - tile 0 keeps its last stage in LDS and leaves through a store pass
+        const bool unpack = SPEC <= 1 && a.packNyq && tile == 0;
+        for (int s = 0; s < p.nst; ++s) fft_stage_dispatch<T, true, MODE, SPEC>(buf, a, s, false, s == 0, s == p.nst - 1 && !unpack, G);
+        if (SPEC <= 1 && unpack) {
+            const unsigned n = (unsigned)p.n, TL = (unsigned)G.TL, colN = (unsigned)(a.realW / 2);
+            const T r = (T)a.scale, ri = r * (T)a.conjOutSign, h = (T)0.5;
+            for (unsigned i = threadIdx.x; i < n * TL; i += blockDim.x) {
+                const unsigned line = i & (TL - 1), e = i / TL;
+                if ((int)line >= nvalid) continue;
+                cpx<T> v = buf[(unsigned)swz((int)e) * TL + line];
+                cpx<T>* orow = (cpx<T>*)G.outP + e * (unsigned)a.outElemStride;
+                if (line == 0) {
+                    const cpx<T> zm = buf[(unsigned)swz((int)(e == 0u ? 0u : n - e)) * TL];
+                    cpx<T> g0, gN;
+                    g0.x = h * (v.x + zm.x) * r;
+                    g0.y = h * (v.y - zm.y) * ri;
+                    gN.x = h * (v.y + zm.y) * r;
+                    gN.y = -h * (v.x - zm.x) * ri;
+                    orow[0] = g0;
+                    orow[colN] = gN;
+                } else {
+                    v.x *= r;
+                    v.y *= ri;
+                    const unsigned col = (unsigned)G.line0 + line;
+                    orow[col] = v;
+                    if (SPEC == 1 && 2u * col < (unsigned)a.realW) {      // the other half of a real map's spectrum
+                        v.y = -v.y;
+                        ((cpx<T>*)G.outP)[(e == 0u ? 0u : (unsigned)a.realH - e) * (unsigned)a.outElemStride + ((unsigned)a.realW - col)] = v;
+                    }
+                }
+            }
+        }
     }
 }
 
@@ -1120,7 +1189,7 @@ int launch_lines(const LineArgs<T>& a, bool cols, int batch, int threads, hipStr
 #undef NF_ATTR
         attrSet[which] = true;
     }
-    const double npixTotal = (double)a.nLines * a.plan.n * batch;
+    const double npixTotal = ((double)a.nLines + (cols && a.packNyq ? 1.0 : 0.0)) * a.plan.n * batch;
     const double inB = a.inType == 0 ? sizeof(cpx<T>) : (a.inType == 1 ? 8.0 : 4.0);
     const double outB = a.outType == 0 ? sizeof(cpx<T>) : (a.outType == 1 ? 8.0 : 4.0);
     const int tag = sizeof(T) == 8 ? (cols ? PT_FFT_COLS_F64 : PT_FFT_ROWS_F64) : (cols ? PT_FFT_COLS_F32 : PT_FFT_ROWS_F32);
@@ -1217,7 +1286,16 @@ int Plan2D<T>::init(int H_, int W_) {
     if (env_int("NF_FFT_COL_THREADS", 0) > 0) threadsCol = env_int("NF_FFT_COL_THREADS", 0);
     threadsCol = std::max(threadsCol, colsPerWG);
     useReal = env_int("NF_FFT_REAL", 1);
+    packNyq = env_int("NF_FFT_PACK_NYQ", 1);
     return NF_OK;
+}
+
+// Columns 0 and W/2 of a real map's half spectrum can travel through the column pass as one complex column (see k_fft_cols):
+// W/2 columns are left, a whole number of tiles for the power-of-two widths whose long columns allow one workgroup per CU -
+// with W/2 + 1 columns the one extra tile costs a whole extra round of the chip.  Plain-radix column plans only.
+template <typename T>
+bool Plan2D<T>::packOk() const {
+    return packNyq && (W % 2) == 0 && W >= 4 && !col.bluestein;
 }
 
 template <typename T>
@@ -1297,6 +1375,11 @@ int Plan2D<T>::forward(const void* in, int inType, void* out, int batch, const d
         c.nLines = W / 2 + 1;
         c.nTiles = nf_div_up(c.nLines, colsPerWG);
     }
+    if (a.pairMode == 1 && packOk()) {
+        c.packNyq = 1;
+        c.nLines = W / 2;
+        c.nTiles = nf_div_up(c.nLines, colsPerWG);
+    }
     int rc = launch_lines<T>(a, false, batch, threadsRow, stream);
     if (rc) return rc;
     return launch_lines<T>(c, true, batch, threadsCol, stream);
@@ -1366,6 +1449,11 @@ int Plan2D<T>::inverse_half(const void* in, void* work, void* out, int outType, 
     a.epiScale = epiScale;
     a.epiMask = epiMask;
     a.epiZeroRef = epiZeroRef;
+    if (packOk()) {
+        c.packNyq = 1;
+        c.nLines = W / 2;
+        c.nTiles = nf_div_up(c.nLines, colsPerWG);
+    }
     int rc = launch_lines<T>(c, true, batch, threadsCol, stream);
     if (rc) return rc;
     return launch_lines<T>(a, false, batch, threadsRow, stream);

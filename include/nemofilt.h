@@ -212,7 +212,11 @@ int nf_label_components(int vtype, const void* sn_d, double threshold, int negat
                         int* work_d, int* numObjects, void* stream);
 
 /* nemo/photometry.py:243-246: per label id 0..numObjects a record of 6 doubles {count, sum v, sum v*y, sum v*x,
- * max v, raster index of first max}; stats_d must hold (numObjects+1)*8 doubles (the tail is scratch). */
+ * max v, raster index of first max}; stats_d must hold (numObjects+1)*NF_OBJECT_STATS_DOUBLES doubles (the tail is scratch).
+ * The three sums are accumulated exactly, as integers of v * 2^40 (v clamped to [0, 8e6]): their values do not depend on the
+ * order of the additions, so centre-of-mass positions are bit-reproducible from run to run (within 1e-12 of scipy's
+ * sequential float64 sums). */
+#define NF_OBJECT_STATS_DOUBLES 17
 int nf_object_stats(int vtype, const void* sn_d, int negate, const int* labels_d, int H, int W, int numObjects,
                     double* stats_d, void* stream);
 

@@ -4,8 +4,9 @@
 //  label_components  threshold (strict >) + 4-connected component labelling by union-find on pixel indices
 //                    (root = smallest raster index of the component), then consecutive numbering of the roots
 //                    in raster order - the numbering scipy.ndimage.label produces.
-//  object_stats      per label: pixel count, sum v, sum v*y, sum v*x (float64 atomics, aggregated over runs of
-//                    equal labels so a large component does not serialise on four addresses), maximum value and
+//  object_stats      per label: pixel count, sum v, sum v*y, sum v*x (exact integer accumulation of v * 2^40 with integer
+//                    atomics - order-independent, so positions are bit-reproducible; aggregated over runs of equal labels
+//                    so a large component does not serialise on a few addresses), maximum value and
 //                    the first raster position that attains it (ndimage.maximum_position).
 //  ring_flags        nemo/photometry.py:65-75: a component with > minRingPix pixels whose centre of mass does
 //                    not land on one of its own pixels is a ring.
@@ -249,12 +250,30 @@ int label_components(int vtype, const void* sn, double threshold, int negate, in
 #define NF_STAT_STRIDE 6
 #define NF_RUN 8
 
-__device__ __forceinline__ void flush_run(double* stats, int id, double cnt, double sv, double svy, double svx) {
-    double* r = stats + (long long)id * NF_STAT_STRIDE;
-    unsafeAtomicAdd(&r[0], cnt);
-    unsafeAtomicAdd(&r[1], sv);
-    unsafeAtomicAdd(&r[2], svy);
-    unsafeAtomicAdd(&r[3], svx);
+// Sums that do not depend on the order of the additions: every value v is taken as the integer I_v = rint(v * 2^40) (v > 0:
+// foreground lies above a threshold >= 0; the quantisation, 9e-13 absolute, is far below the 1e-9 position tolerance), and
+// sum I_v, sum I_v * y, sum I_v * x are accumulated EXACTLY in 128-bit integers spread over three 64-bit words each (32-bit
+// limbs, so the per-word sums cannot overflow), with integer atomics.  Integer addition is associative: the catalogue
+// positions come out bit for bit the same on every run, whatever the scheduling - which float64 atomics cannot promise.
+#define NF_FIX_SHIFT 40
+#define NF_FIX_VMAX 8.0e6    // values are clamped to [0, 8e6] before the conversion (8e6 * 2^40 < 2^63)
+#define NF_LIMB_WORDS 9      // 3 sums x 3 limbs per label
+
+__device__ __forceinline__ void flush_limbs(unsigned long long* w, unsigned __int128 v) {
+    const unsigned long long l0 = (unsigned long long)(v & 0xFFFFFFFFu), l1 = (unsigned long long)((v >> 32) & 0xFFFFFFFFu),
+                             l2 = (unsigned long long)(v >> 64);
+    if (l0) atomicAdd(&w[0], l0);
+    if (l1) atomicAdd(&w[1], l1);
+    if (l2) atomicAdd(&w[2], l2);
+}
+
+__device__ __forceinline__ void flush_run(double* stats, unsigned long long* limbs, int id, double cnt, unsigned __int128 sv,
+                                          unsigned __int128 svy, unsigned __int128 svx) {
+    unsafeAtomicAdd(&stats[(long long)id * NF_STAT_STRIDE], cnt);      // whole numbers below 2^53: exact in any order
+    unsigned long long* w = limbs + (long long)id * NF_LIMB_WORDS;
+    flush_limbs(w, sv);
+    flush_limbs(w + 3, svy);
+    flush_limbs(w + 6, svx);
 }
 
 __device__ __forceinline__ unsigned long long ordered_key(double v) {
@@ -264,38 +283,42 @@ __device__ __forceinline__ unsigned long long ordered_key(double v) {
 
 template <typename VT>
 __global__ void k_object_sums(const VT* __restrict__ sn, int negate, const int* __restrict__ labels, int H, int W,
-                              double* __restrict__ stats, unsigned long long* __restrict__ maxKey) {
+                              double* __restrict__ stats, unsigned long long* __restrict__ limbs,
+                              unsigned long long* __restrict__ maxKey) {
     const int segsPerRow = (W + NF_RUN - 1) / NF_RUN;
     const long long nseg = (long long)H * segsPerRow;
     for (long long sidx = blockIdx.x * (long long)blockDim.x + threadIdx.x; sidx < nseg; sidx += (long long)gridDim.x * blockDim.x) {
         int y = (int)(sidx / segsPerRow);
         int x0 = (int)(sidx % segsPerRow) * NF_RUN;
         int cur = 0;
-        double cnt = 0, sv = 0, svy = 0, svx = 0, mx = 0;
+        double cnt = 0, mx = 0;
+        unsigned __int128 sv = 0, svy = 0, svx = 0;
         for (int j = 0; j < NF_RUN && x0 + j < W; ++j) {
             long long p = (long long)y * W + x0 + j;
             int id = labels[p];
             if (id != cur) {
                 if (cur > 0) {
-                    flush_run(stats, cur, cnt, sv, svy, svx);
+                    flush_run(stats, limbs, cur, cnt, sv, svy, svx);
                     atomicMax(&maxKey[cur], ordered_key(mx));
                 }
                 cur = id;
-                cnt = sv = svy = svx = 0;
+                cnt = 0;
+                sv = svy = svx = 0;
                 mx = -INFINITY;
             }
             if (id > 0) {
                 double v = (double)sn[p];
                 if (negate) v = -v;
+                const unsigned long long iv = (unsigned long long)rint(fmin(fmax(v, 0.0), NF_FIX_VMAX) * (double)(1ULL << NF_FIX_SHIFT));
                 cnt += 1.0;
-                sv += v;
-                svy += v * (double)y;       // input * grid (float64), as ndimage.center_of_mass forms it
-                svx += v * (double)(x0 + j);
+                sv += iv;
+                svy += (unsigned __int128)iv * (unsigned)y;
+                svx += (unsigned __int128)iv * (unsigned)(x0 + j);
                 mx = fmax(mx, v);
             }
         }
         if (cur > 0) {
-            flush_run(stats, cur, cnt, sv, svy, svx);
+            flush_run(stats, limbs, cur, cnt, sv, svy, svx);
             atomicMax(&maxKey[cur], ordered_key(mx));
         }
     }
@@ -313,35 +336,49 @@ __global__ void k_object_argmax(const VT* __restrict__ sn, int negate, const int
     }
 }
 
-__global__ void k_stats_finish(double* __restrict__ stats, const unsigned long long* __restrict__ maxKey,
-                               const unsigned long long* __restrict__ argmax, int numObjects) {
+__device__ __forceinline__ double limbs_to_double(const unsigned long long* w) {
+    const unsigned __int128 t = (unsigned __int128)w[0] + ((unsigned __int128)w[1] << 32) + ((unsigned __int128)w[2] << 64);
+    const double hi = (double)(unsigned long long)(t >> 64), lo = (double)(unsigned long long)(t & 0xFFFFFFFFFFFFFFFFULL);
+    return (hi * 18446744073709551616.0 + lo) * (1.0 / (double)(1ULL << NF_FIX_SHIFT));
+}
+
+__global__ void k_stats_finish(double* __restrict__ stats, const unsigned long long* __restrict__ limbs,
+                               const unsigned long long* __restrict__ maxKey, const unsigned long long* __restrict__ argmax,
+                               int numObjects) {
     for (int id = blockIdx.x * blockDim.x + threadIdx.x; id <= numObjects; id += gridDim.x * blockDim.x) {
+        const unsigned long long* w = limbs + (long long)id * NF_LIMB_WORDS;
+        double* r = stats + (long long)id * NF_STAT_STRIDE;
+        r[1] = limbs_to_double(w);
+        r[2] = limbs_to_double(w + 3);
+        r[3] = limbs_to_double(w + 6);
         unsigned long long k = maxKey[id];
         unsigned long long b = (k & 0x8000000000000000ULL) ? (k & 0x7FFFFFFFFFFFFFFFULL) : ~k;
-        stats[(long long)id * NF_STAT_STRIDE + 4] = __longlong_as_double((long long)b);
-        stats[(long long)id * NF_STAT_STRIDE + 5] = (double)argmax[id];
+        r[4] = __longlong_as_double((long long)b);
+        r[5] = (double)argmax[id];
     }
 }
 
-// `stats` must hold (numObjects+1) * 6 doubles followed by 2 * (numObjects+1) uint64 of scratch
+// `stats` must hold (numObjects+1) * 17 doubles: 6 per record, then scratch - the 9 integer limbs, the maximum key and the
+// argmax of every label
 int object_stats(int vtype, const void* sn, int negate, const int* labels, int H, int W, int numObjects, double* stats,
                  hipStream_t s) {
     const long long n = (long long)H * W;
     const size_t nrec = (size_t)numObjects + 1;
-    unsigned long long* maxKey = (unsigned long long*)(stats + nrec * NF_STAT_STRIDE);
+    unsigned long long* limbs = (unsigned long long*)(stats + nrec * NF_STAT_STRIDE);
+    unsigned long long* maxKey = limbs + nrec * NF_LIMB_WORDS;
     unsigned long long* argmax = maxKey + nrec;
-    NF_HIP(hipMemsetAsync(stats, 0, nrec * NF_STAT_STRIDE * sizeof(double) + nrec * sizeof(unsigned long long), s));
+    NF_HIP(hipMemsetAsync(stats, 0, nrec * (NF_STAT_STRIDE + NF_LIMB_WORDS + 1) * sizeof(double), s));
     NF_HIP(hipMemsetAsync(argmax, 0xFF, nrec * sizeof(unsigned long long), s));
     const long long nseg = (long long)H * ((W + NF_RUN - 1) / NF_RUN);
     dim3 g(grid_for(nseg, 256)), b(256), gp(grid_for(n, 256));
     if (vtype == NF_F64) {
-        hipLaunchKernelGGL(k_object_sums<double>, g, b, 0, s, (const double*)sn, negate, labels, H, W, stats, maxKey);
+        hipLaunchKernelGGL(k_object_sums<double>, g, b, 0, s, (const double*)sn, negate, labels, H, W, stats, limbs, maxKey);
         hipLaunchKernelGGL(k_object_argmax<double>, gp, b, 0, s, (const double*)sn, negate, labels, n, maxKey, argmax);
     } else {
-        hipLaunchKernelGGL(k_object_sums<float>, g, b, 0, s, (const float*)sn, negate, labels, H, W, stats, maxKey);
+        hipLaunchKernelGGL(k_object_sums<float>, g, b, 0, s, (const float*)sn, negate, labels, H, W, stats, limbs, maxKey);
         hipLaunchKernelGGL(k_object_argmax<float>, gp, b, 0, s, (const float*)sn, negate, labels, n, maxKey, argmax);
     }
-    hipLaunchKernelGGL(k_stats_finish, dim3(grid_for(nrec, 256)), dim3(256), 0, s, stats, maxKey, argmax, numObjects);
+    hipLaunchKernelGGL(k_stats_finish, dim3(grid_for(nrec, 256)), dim3(256), 0, s, stats, limbs, maxKey, argmax, numObjects);
     NF_CHECK_LAUNCH("object_stats");
     return NF_OK;
 }

@@ -610,7 +610,7 @@ class TileEngine(object):
 
     def object_stats(self, sn, labels, numObjects, negate=False):
         t = self.t
-        stats = t.empty((numObjects + 1) * 8, dtype=t.float64, device=self.dev)
+        stats = t.empty((numObjects + 1) * 17, dtype=t.float64, device=self.dev)      # NF_OBJECT_STATS_DOUBLES
         check(self.lib.nf_object_stats(prec_of(sn), ptr(sn), 1 if negate else 0, ptr(labels), self.H, self.W, numObjects,
                                        ptr(stats), stream_ptr()), "nf_object_stats")
         return stats[:(numObjects + 1) * 6].reshape(numObjects + 1, 6)

@@ -44,9 +44,12 @@ def test_pipeline_async_equals_sync_and_matches_oracle():
     cat = pipelines.filterMapsAndMakeCatalogs(_config(helpers.product_maps(mapsL)), verbose=False)
     catSync = pipelines.filterMapsAndMakeCatalogs(_config(helpers.product_maps(mapsL), asyncDetection=False), verbose=False)
     assert len(cat) >= 3
-    # the second stream changes when things run, not what they compute (centroid sums use float64 atomics, whose order is
-    # not fixed: positions repeat to ~1e-15, not bit for bit)
-    _same_catalog(cat, catSync, snrTol=1e-12, posTol=1e-12)
+    # the second stream changes when things run, not what they compute: the centroid sums are exact integer accumulations
+    # (order-independent), so positions, S/N values and every other column repeat bit for bit
+    _same_catalog(cat, catSync, snrTol=0.0, posTol=0.0)
+    for k in cat.keys():
+        ia, ib = np.lexsort((cat['decDeg'], cat['RADeg'])), np.lexsort((catSync['decDeg'], catSync['RADeg']))
+        assert np.array_equal(np.asarray(cat[k])[ia], np.asarray(catSync[k])[ib]), k
     for k in ('y_c', 'fixed_y_c', 'fixed_SNR', 'deltaT_c'):
         assert k in cat.keys()
     # per scale against the oracle (filter + detection), then the reference's merge rules applied to the oracle's tables

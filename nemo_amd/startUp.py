@@ -24,6 +24,19 @@ from . import maps
 from .wcs import CARWCS
 
 
+def _overlay(target, source, levels):
+    """``source`` laid over ``target`` in place: values of ``source`` win; a dictionary value is merged into the one already
+    there as long as ``levels`` allows, and replaces it whole below that."""
+    for key, value in source.items():
+        if isinstance(value, dict) and levels > 0:
+            if not isinstance(target.get(key), dict):
+                target[key] = {}
+            _overlay(target[key], value, levels - 1)
+        else:
+            target[key] = value
+    return target
+
+
 def _applyDefaults(parDict):
     maskKeys = ['pointSourceMask', 'surveyMask', 'maskPointSourcesFromCatalog', 'apodizeUsingSurveyMask',
                 'maskSubtractedPointSources', 'RADecSection', 'maskHoleDilationFactor', 'reprojectToTan']
@@ -35,27 +48,11 @@ def _applyDefaults(parDict):
                 mapDict[k] = None
         if 'weightsType' not in mapDict.keys():
             mapDict['weightsType'] = 'invVar'
-    # allFilters: global filter options, anything in mapFilters has priority (up to three levels; :57-80)
-    if 'allFilters' in parDict.keys():
-        mapFiltersList = []
-        for filterDict in parDict['mapFilters']:
-            newDict = copy.deepcopy(parDict['allFilters'])
-            for key in filterDict.keys():
-                if type(filterDict[key]) == dict:
-                    if key not in newDict.keys():
-                        newDict[key] = {}
-                    for subkey in filterDict[key].keys():
-                        if type(filterDict[key][subkey]) == dict:
-                            if subkey not in newDict[key].keys():
-                                newDict[key][subkey] = {}
-                            for subsubkey in filterDict[key][subkey].keys():
-                                newDict[key][subkey][subsubkey] = filterDict[key][subkey][subsubkey]
-                        else:
-                            newDict[key][subkey] = filterDict[key][subkey]
-                else:
-                    newDict[key] = filterDict[key]
-            mapFiltersList.append(newDict)
-        parDict['mapFilters'] = mapFiltersList
+    # allFilters holds options common to every filter; what a mapFilters entry says itself wins (nemo/startUp.py:57-80:
+    # dictionaries are merged key by key for two levels below the entry - params, then e.g. noiseParams - deeper ones whole)
+    common = parDict.get('allFilters')
+    if common is not None:
+        parDict['mapFilters'] = [_overlay(copy.deepcopy(common), entry, 2) for entry in parDict['mapFilters']]
     if 'photFilter' not in parDict.keys():
         parDict['photFilter'] = None
     else:
@@ -280,55 +277,60 @@ class NemoConfig(object):
                     raise Exception("Use 'fileLabel' instead of 'label' in 'filterSetOptions' dictionaries")
                 self.filterSetLabels[setNum] = self.filterSetOptions[setNum].get('fileLabel', None)
 
+    # what one pass of a multi-pass run may change (nemo/startUp.py:751-843), as tables
+    _SET_OPTION_DEFAULTS = {'saveCatalog': False, 'maskHoleDilationFactor': None, 'maskHoleRadiusArcmin': None,
+                            'addSiphonedFromSets': None, 'ignoreSurveyMask': False}
+    _SET_OVERRIDES = ('thresholdSigma', 'objIdent', 'findCenterOfMass', 'measureShapes')       # run-level keys a set may replace
+    _OUTPUT_SWITCHES = ('saveFilteredMaps', 'saveFilter', 'saveRMSMap', 'savePlots', 'saveDS9Regions')
+    _CATALOG_ROUTES = (('subtractModelFromSets', 'subtractModelFromCatalog'), ('maskAndFillFromSets', 'maskAndFillFromCatalog'))
+
     def setFilterSet(self, setNum):
-        """nemo/startUp.py:751-843: activate the filters of one pass of a multi-pass run."""
+        """Activate pass ``setNum`` of a multi-pass run (``filterSets`` / ``filterSetOptions``; nemo/startUp.py:751-843): start
+        from the configuration as read, keep the filters that belong to the pass, and hand the catalogues of earlier passes
+        to the filters (noise term) and to the maps (model subtraction, masking and filling)."""
         self.restoreConfig()
-        options = None
-        if setNum in self.filterSetOptions.keys():
-            options = self.filterSetOptions[setNum]
+        allOptions = self.filterSetOptions
+        options = allOptions.get(setNum)
+        if options is not None:
             self.currentFilterSet = setNum
-            for k, v in [('saveCatalog', False), ('maskHoleDilationFactor', None), ('maskHoleRadiusArcmin', None),
-                         ('addSiphonedFromSets', None), ('ignoreSurveyMask', False)]:
-                if k not in options.keys():
-                    options[k] = v
-        if setNum != list(self.filterSetOptions.keys())[-1]:
-            self.parDict['catalogCuts'] = []
-        if options is not None:
-            for override in ['thresholdSigma', 'objIdent', 'findCenterOfMass', 'measureShapes']:
-                if override in options.keys():
-                    self.parDict[override] = options[override]
-        saveKeys = ['saveFilteredMaps', 'saveFilter', 'saveRMSMap', 'savePlots', 'saveDS9Regions']
-        filtersToActivate = []
-        for filtDict in self.parDict['mapFilters']:
-            if setNum in filtDict['filterSets']:
-                if options is not None:
-                    if 'mapToUse' in options.keys():
-                        filtDict['params']['mapToUse'] = options['mapToUse']
-                    if 'noiseModelCatalogFromSets' in options.keys():
-                        filtDict['params']['noiseModelCatalog'] = []
-                        for noiseSubIndex in options['noiseModelCatalogFromSets']:
-                            filtDict['params']['noiseModelCatalog'].append(self.filterSetOptions[noiseSubIndex]['catalog'])
-                if setNum != self.filterSets[-1]:
-                    for saveKey in saveKeys:
-                        if saveKey in filtDict['params'].keys():
-                            filtDict['params'][saveKey] = False
-                    self.parDict['forcedPhotometryCatalog'] = None
-                if type(options) == dict and 'saveFilteredMaps' in options.keys():
-                    filtDict['params']['saveFilteredMaps'] = options['saveFilteredMaps']
-                filtersToActivate.append(filtDict)
-        self.parDict['mapFilters'] = filtersToActivate
-        if options is not None:
-            for key, target in [('subtractModelFromSets', 'subtractModelFromCatalog'),
-                                ('maskAndFillFromSets', 'maskAndFillFromCatalog')]:
-                if key in options.keys():
-                    for mapDict in self.unfilteredMapsDictList:
-                        for idx in options[key]:
-                            if 'mapToUse' in self.filterSetOptions[idx].keys():
-                                if 'label' in mapDict.keys() and mapDict['label'] != self.filterSetOptions[idx]['mapToUse']:
-                                    continue
-                            mapDict[target] = self.filterSetOptions[idx]['catalog']
-            for mapDict in self.unfilteredMapsDictList:
-                mapDict['maskHoleDilationFactor'] = options['maskHoleDilationFactor']
-                mapDict['maskHoleRadiusArcmin'] = options['maskHoleRadiusArcmin']
-                if options['ignoreSurveyMask'] == True:
-                    mapDict['surveyMask'] = None
+            for key, value in self._SET_OPTION_DEFAULTS.items():
+                options.setdefault(key, value)
+            self.parDict.update({k: options[k] for k in self._SET_OVERRIDES if k in options})
+        lastListed = list(allOptions.keys())[-1]
+        if setNum != lastListed:
+            self.parDict['catalogCuts'] = []                 # cuts apply to the final catalogue only
+        finalPass = setNum == self.filterSets[-1]
+
+        active = [f for f in self.parDict['mapFilters'] if setNum in f['filterSets']]
+        for f in active:
+            params = f['params']
+            if options is not None:
+                if 'mapToUse' in options:
+                    params['mapToUse'] = options['mapToUse']
+                if 'noiseModelCatalogFromSets' in options:
+                    params['noiseModelCatalog'] = [allOptions[i]['catalog'] for i in options['noiseModelCatalogFromSets']]
+            if not finalPass:
+                # only the last pass writes maps / filters, or does forced photometry - unless a pass asks for it itself
+                params.update({k: False for k in self._OUTPUT_SWITCHES if k in params})
+                self.parDict['forcedPhotometryCatalog'] = None
+            if options is not None:
+                if 'forcedPhotometryCatalog' in options:
+                    self.parDict['forcedPhotometryCatalog'] = options['forcedPhotometryCatalog']
+                    self.parDict['thresholdSigma'] = -1000
+                if 'saveFilteredMaps' in options:
+                    params['saveFilteredMaps'] = options['saveFilteredMaps']
+        self.parDict['mapFilters'] = active
+        if options is None:
+            return
+
+        for mapDict in self.unfilteredMapsDictList:
+            for fromKey, mapKey in self._CATALOG_ROUTES:
+                for index in options.get(fromKey, []):
+                    wanted = allOptions[index].get('mapToUse')
+                    if wanted is not None and 'label' in mapDict and mapDict['label'] != wanted:
+                        continue
+                    mapDict[mapKey] = allOptions[index]['catalog']          # (the last listed set wins, as in the reference)
+            mapDict['maskHoleDilationFactor'] = options['maskHoleDilationFactor']
+            mapDict['maskHoleRadiusArcmin'] = options['maskHoleRadiusArcmin']
+            if options['ignoreSurveyMask'] == True:
+                mapDict['surveyMask'] = None

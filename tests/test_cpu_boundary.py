@@ -241,3 +241,83 @@ def test_worker_threads_are_bound_to_the_process_device(monkeypatch):
         assert pool.submit(cur).result() == 5
     finally:
         pool.shutdown()
+
+
+def _dr6_shaped_config():
+    """A configuration with the multi-pass structure of examples/ACT-DR6-clusters/DR6ClusterSearch.yml:133-215 (filter sets
+    1-6 per-frequency point-source passes, 10 and 11 the cluster passes), over small in-memory maps."""
+    from nemo_amd.wcs import CARWCS
+    shape = (40, 50)
+    wcs = CARWCS.make(shape)
+    maps_ = [{'mapData': np.zeros(shape), 'weightsData': np.ones(shape), 'wcs': wcs, 'obsFreqGHz': f, 'units': 'uK',
+              'beamFileName': None, 'label': lab} for lab, f in [('f090', 97.8), ('f150', 149.6), ('f220', 216.5)]]
+    opts = {}
+    for k, lab in [(1, 'f090'), (3, 'f150'), (5, 'f220')]:
+        opts[k] = {'mapToUse': lab, 'thresholdSigma': 50.0, 'objIdent': 'ACT-S', 'measureShapes': True, 'ignoreSurveyMask': True}
+        opts[k + 1] = {'mapToUse': lab, 'thresholdSigma': 5.0, 'objIdent': 'ACT-S', 'subtractModelFromSets': [k],
+                       'addSiphonedFromSets': [k], 'maskAndFillFromSets': [k], 'maskHoleDilationFactor': 3.0, 'saveCatalog': True,
+                       'saveFilteredMaps': False, 'fileLabel': 'ptsrc_%s' % lab}
+    opts[10] = {'subtractModelFromSets': [2, 4, 6], 'maskAndFillFromSets': [1, 3, 5], 'maskHoleDilationFactor': 3.0}
+    opts[11] = {'subtractModelFromSets': [2, 4, 6], 'maskAndFillFromSets': [1, 3, 5], 'maskHoleDilationFactor': 3.0,
+                'noiseModelCatalogFromSets': [10]}
+    return {'unfilteredMaps': maps_, 'surveyMask': 'mask.fits', 'thresholdSigma': 4.0, 'objIdent': 'ACT-CL', 'catalogCuts': ['SNR > 4'],
+            'photFilter': 'Arnaud_M2e14_z0p4', 'filterSetOptions': opts,
+            'allFilters': {'class': 'ArnaudModelMatchedFilter',
+                           'params': {'noiseParams': {'method': 'dataMap', 'noiseGridArcmin': 80.0}, 'saveFilteredMaps': False,
+                                      'saveRMSMap': False, 'outputUnits': 'yc', 'edgeTrimArcmin': 0.0},
+                           'filterSets': [10, 11]},
+            'mapFilters': [{'label': 'BeamPass1', 'class': 'BeamMatchedFilter', 'filterSets': [1, 3, 5],
+                            'params': {'outputUnits': 'uK', 'noiseParams': {'method': 'model'}}},
+                           {'label': 'BeamPass2', 'class': 'BeamMatchedFilter', 'filterSets': [2, 4, 6],
+                            'params': {'outputUnits': 'uK', 'noiseParams': {'method': 'dataMap'}}},
+                           {'label': 'Arnaud_M1e14_z0p2', 'params': {'M500MSun': 1e14, 'z': 0.2}},
+                           {'label': 'Arnaud_M2e14_z0p4', 'params': {'M500MSun': 2e14, 'z': 0.4, 'saveFilteredMaps': True}}],
+            'outputDir': None}
+
+
+def test_filter_sets_of_a_dr6_shaped_config():
+    """startUp.NemoConfig.setFilterSet (nemo/startUp.py:751-843) on the multi-pass layout of the DR6 cluster search."""
+    from nemo_amd import startUp
+    config = startUp.NemoConfig(_dr6_shaped_config(), makeOutputDirs=False, verbose=False)
+    assert config.filterSets == [1, 2, 3, 4, 5, 6, 10, 11]
+    # the allFilters merge: entries keep what they say themselves, inherit the rest, two dictionary levels deep
+    byLabel = {f['label']: f for f in config.parDict['mapFilters']}
+    assert byLabel['BeamPass1']['params']['noiseParams'] == {'method': 'model', 'noiseGridArcmin': 80.0}
+    assert byLabel['BeamPass1']['class'] == 'BeamMatchedFilter' and byLabel['BeamPass1']['filterSets'] == [1, 3, 5]
+    assert byLabel['Arnaud_M1e14_z0p2']['class'] == 'ArnaudModelMatchedFilter' and byLabel['Arnaud_M1e14_z0p2']['filterSets'] == [10, 11]
+    assert byLabel['Arnaud_M2e14_z0p4']['params']['saveFilter'] is True          # photFilter forces its filter to be kept
+    for setNum in config.filterSets:
+        config.filterSetOptions[setNum]['catalog'] = 'catalogue of set %d' % setNum      # what the driver stores per pass
+
+    config.setFilterSet(1)
+    assert [f['label'] for f in config.parDict['mapFilters']] == ['BeamPass1']
+    assert config.parDict['thresholdSigma'] == 50.0 and config.parDict['objIdent'] == 'ACT-S' and config.parDict['measureShapes'] is True
+    assert config.parDict['catalogCuts'] == [] and config.parDict['forcedPhotometryCatalog'] is None
+    assert config.parDict['mapFilters'][0]['params']['mapToUse'] == 'f090'
+    assert all(m['surveyMask'] is None for m in config.unfilteredMapsDictList)          # ignoreSurveyMask
+    assert config.filterSetOptions[1]['addSiphonedFromSets'] is None and config.filterSetOptions[1]['saveCatalog'] is False
+
+    config.setFilterSet(2)
+    assert [f['label'] for f in config.parDict['mapFilters']] == ['BeamPass2']
+    assert config.parDict['thresholdSigma'] == 5.0
+    byMap = {m['label']: m for m in config.unfilteredMapsDictList}
+    assert byMap['f090']['subtractModelFromCatalog'] == 'catalogue of set 1' and byMap['f090']['maskAndFillFromCatalog'] == 'catalogue of set 1'
+    assert 'subtractModelFromCatalog' not in byMap['f150'] and byMap['f150'].get('maskAndFillFromCatalog') is None
+    assert all(m['maskHoleDilationFactor'] == 3.0 and m['surveyMask'] == 'mask.fits' for m in config.unfilteredMapsDictList)
+    assert config.parDict['mapFilters'][0]['params']['saveFilteredMaps'] is False
+
+    config.setFilterSet(10)
+    assert [f['label'] for f in config.parDict['mapFilters']] == ['Arnaud_M1e14_z0p2', 'Arnaud_M2e14_z0p4']
+    assert config.parDict['thresholdSigma'] == 4.0 and config.parDict['objIdent'] == 'ACT-CL'      # back to the run-level values
+    byMap = {m['label']: m for m in config.unfilteredMapsDictList}
+    for lab, sub, fill in [('f090', 2, 1), ('f150', 4, 3), ('f220', 6, 5)]:
+        assert byMap[lab]['subtractModelFromCatalog'] == 'catalogue of set %d' % sub
+        assert byMap[lab]['maskAndFillFromCatalog'] == 'catalogue of set %d' % fill
+    assert all(f['params'].get('saveFilter', False) is False and f['params']['saveFilteredMaps'] is False for f in config.parDict['mapFilters'])
+    assert config.parDict['catalogCuts'] == []
+
+    config.setFilterSet(11)
+    phot = [f for f in config.parDict['mapFilters'] if f['label'] == 'Arnaud_M2e14_z0p4'][0]
+    assert phot['params']['saveFilter'] is True and phot['params']['saveFilteredMaps'] is True      # the last pass writes
+    assert all(f['params']['noiseModelCatalog'] == ['catalogue of set 10'] for f in config.parDict['mapFilters'])
+    assert config.parDict['catalogCuts'] == ['SNR > 4']

@@ -205,6 +205,43 @@ int nf_convolve2d(const float* in_d, float* out_d, int H, int W, const double* k
 int nf_convolve2d_f64(const double* in_d, double* out_d, int H, int W, const double* kernFlipped_d, int kh, int kw,
                       void* stream);
 
+/* ---- maps.MapDict.preprocess on the device (nemo/maps.py:178-480) ------------------------------------------------------
+ * scipy.ndimage.median_filter(data, size) with mode='reflect' (nemo/maps.py:366-368: the 20 x 20 moving median used as the
+ * hole-filling background): window [i - size//2, i + size - size//2 - 1] on both axes, element of rank size*size//2.
+ * size <= 48; in_d != out_d; rtype = map dtype. */
+int nf_median_filter(int rtype, const void* in_d, void* out_d, int H, int W, int size, void* stream);
+
+/* maps.makeDegreesDistanceMap (nemo/maps.py:2479-2536) and the masking / filling statements around its call sites
+ * (:419-424 maskPointSourcesFromCatalog, :459-465 maskAndFillFromCatalog).  A hole is rec = {x0, y0, xPixScale, yPixScale,
+ * limit} (device, 5 doubles) with box = {minX, maxX, minY, maxY} (device ints; boxHost / boxesHost: the same numbers on the host,
+ * checked against the map before anything is launched).
+ *   nf_disc_fill   rmap[y][x] = sqrt(((y - y0) yPixScale)^2 + ((x - x0) xPixScale)^2) inside the box - the persistent
+ *                  distance map of :391, which the reference never resets between catalogue rows;
+ *   nf_disc_apply  inside each of nBoxes boxes: where the distance (times 60 if times60) is below the limit, surveyMask = 0,
+ *                  psMask = 0, data = bck.  rmap_d == NULL: distances are formed in place and compared with each hole's own
+ *                  rec[4] (:459-465); else they are read from rmap_d and compared with `limit` (:422-424). */
+int nf_disc_fill(double* rmap_d, int H, int W, const double* rec_d, const int* box_d, const int* boxHost, void* stream);
+int nf_disc_apply(int rtype, void* data_d, const void* bck_d, unsigned char* surveyMask_d, unsigned char* psMask_d, int H, int W,
+                  const double* recs_d, const int* boxes_d, const int* boxesHost, int nBoxes, double limit, int times60,
+                  const double* rmap_d, void* stream);
+
+/* The painting loop of maps.makeModelImage (nemo/maps.py:1790-1840 -> signals._paintSignalMap, nemo/signals.py:675-688):
+ * out[y][x] (+)= sum over the nObj catalogue objects, IN ORDER, of the float32 value of object k's radial template at that
+ * pixel, inside object k's window only (painter semantics of nf_paint_radial).  Per object: obj_d[k] = {amp, sign, f1, f2,
+ * profile id, nf, -, -} (8 doubles; when nf > 0 the float32 value is multiplied by float32(f1), then float32(f2):
+ * maps.convertToDeltaT on the painted clip, :684-686), win_d[k] = {x0, x1, y0, y1, offAB, offC, profile id, -} (8 ints; the
+ * haversine tables of the window sit in geom_d: A then B per window row at offAB, C per window column at offC).  prof_d:
+ * nProf tables of 3 * ntab doubles (radii, profile, slopes).  winHost: win_d on the host (bounds are checked first).
+ * accumulate != 0 adds to what out_d holds. */
+int nf_paint_catalog(float* out_d, int H, int W, int nObj, const double* obj_d, const int* win_d, const int* winHost,
+                     const double* geom_d, long long geomLen, const double* prof_d, int nProf, int ntab, int accumulate,
+                     void* stream);
+
+/* nemo/maps.py:435-437 (subtract != 0: data -= model, flagMask += (model > 1); flagMask_d may be NULL) and :344 (subtract == 0:
+ * data += model). */
+int nf_add_model(int rtype, void* data_d, const float* model_d, unsigned char* flagMask_d, long long n, int subtract,
+                 void* stream);
+
 /* photometry.getObjectPositions, nemo/photometry.py:235-241: labels_d[H*W] int32 = scipy.ndimage.label numbering
  * of (map > threshold) (negate != 0: of (-map > threshold), nemo/photometry.py:54-55); work_d: int32 scratch of
  * H*W + 2*(H*W/1024) + 4 entries.  Synchronises the stream and returns the number of objects in *numObjects. */

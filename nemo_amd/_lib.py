@@ -72,6 +72,13 @@ SIGNATURES = {
     'nf_subtract': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_ll, c_void_p]),
     'nf_convolve2d': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
     'nf_convolve2d_f64': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
+    'nf_median_filter': (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    'nf_disc_fill': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, ctypes.POINTER(c_int), c_void_p]),
+    'nf_disc_apply': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, ctypes.POINTER(c_int),
+                              c_int, c_double, c_int, c_void_p, c_void_p]),
+    'nf_paint_catalog': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, ctypes.POINTER(c_int), c_void_p, c_ll, c_void_p,
+                                 c_int, c_int, c_int, c_void_p]),
+    'nf_add_model': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_ll, c_int, c_void_p]),
     'nf_label_components': (c_int, [c_int, c_void_p, c_double, c_int, c_void_p, c_int, c_int, c_void_p,
                                     ctypes.POINTER(c_int), c_void_p]),
     'nf_object_stats': (c_int, [c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),

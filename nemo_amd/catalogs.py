@@ -282,6 +282,28 @@ def getTableRADecKeys(tab):
 _OPS = {'<': operator.lt, '>': operator.gt, '<=': operator.le, '>=': operator.ge, '==': operator.eq, '!=': operator.ne}
 
 
+def getCatalogWithinImage(tab, shape, wcs, mask=None):
+    """Rows whose coordinates fall inside the image - 0 <= x < W - 1 and 0 <= y < H - 1 - and, with ``mask``, on a pixel where
+    the mask is 1 (nemo/catalogs.py:1039-1086)."""
+    if len(tab) == 0:
+        return tab
+    x, y = wcs.wcs2pix(np.asarray(tab['RADeg'], dtype=np.float64), np.asarray(tab['decDeg'], dtype=np.float64))
+    x, y = np.atleast_1d(x), np.atleast_1d(y)
+    with np.errstate(invalid='ignore'):
+        sel = ~np.isnan(x) & ~np.isnan(y) & (x >= 0) & (x < shape[1] - 1) & (y >= 0) & (y < shape[0] - 1)
+    if mask is not None and sel.any():
+        iy, ix = np.round(y[sel]).astype(np.int64), np.round(x[sel]).astype(np.int64)
+        if hasattr(mask, 'is_cuda'):
+            from . import engine
+            t = engine.torch()
+            onMask = mask[t.as_tensor(iy, device=mask.device), t.as_tensor(ix, device=mask.device)].cpu().numpy() == 1
+        else:
+            onMask = np.asarray(mask)[iy, ix] == 1
+        idx = np.flatnonzero(sel)
+        sel[idx[~onMask]] = False
+    return tab[sel]
+
+
 def selectFromCatalog(catalog, constraintsList):
     """nemo/catalogs.py:598-617: constraints of the form "key op value" (space separated)."""
     passed = catalog

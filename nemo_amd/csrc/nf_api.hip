@@ -532,6 +532,66 @@ int nf_convolve2d_f64(const double* in, double* out, int H, int W, const double*
     return nf::convolve2d(NF_F64, in, out, H, W, kernFlipped, kh, kw, S(stream));
 }
 
+int nf_median_filter(int rtype, const void* in, void* out, int H, int W, int size, void* stream) {
+    if (!in || !out || in == out || H < 1 || W < 1 || (rtype != NF_F32 && rtype != NF_F64)) {
+        nf_set_error("nf_median_filter: bad arguments");
+        return NF_ERR_ARG;
+    }
+    return nf::median_filter(rtype, in, out, H, W, size, S(stream));
+}
+
+int nf_disc_fill(double* rmap, int H, int W, const double* rec, const int* box, const int* boxHost, void* stream) {
+    if (!rmap || !rec || !box || !boxHost || boxHost[0] < 0 || boxHost[1] > W || boxHost[2] < 0 || boxHost[3] > H) {
+        nf_set_error("nf_disc_fill: bad arguments (box outside the map)");
+        return NF_ERR_ARG;
+    }
+    const int n = (boxHost[1] - boxHost[0]) * (boxHost[3] - boxHost[2]);
+    return nf::disc_fill(rmap, W, rec, box, n > 0 ? n : 0, S(stream));
+}
+
+int nf_disc_apply(int rtype, void* data, const void* bck, unsigned char* surveyMask, unsigned char* psMask, int H, int W,
+                  const double* recs, const int* boxes, const int* boxesHost, int nBoxes, double limit, int times60,
+                  const double* rmap, void* stream) {
+    if (!data || !bck || !surveyMask || !psMask || !recs || !boxes || !boxesHost || nBoxes < 0 || (rtype != NF_F32 && rtype != NF_F64)) {
+        nf_set_error("nf_disc_apply: bad arguments");
+        return NF_ERR_ARG;
+    }
+    for (int k = 0; k < nBoxes; ++k) {
+        const int* b = boxesHost + 4 * k;
+        if (b[0] < 0 || b[1] > W || b[2] < 0 || b[3] > H) {
+            nf_set_error("nf_disc_apply: box outside the map");
+            return NF_ERR_ARG;
+        }
+    }
+    return nf::disc_apply(rtype, data, bck, surveyMask, psMask, W, recs, boxes, nBoxes, limit, times60, rmap, S(stream));
+}
+
+int nf_paint_catalog(float* out, int H, int W, int nObj, const double* obj, const int* win, const int* winHost, const double* geom,
+                     long long geomLen, const double* prof, int nProf, int ntab, int accumulate, void* stream) {
+    if (!out || !obj || !win || !winHost || !geom || !prof || H < 1 || W < 1 || nObj < 1 || ntab < 2 || nProf < 1) {
+        nf_set_error("nf_paint_catalog: bad arguments");
+        return NF_ERR_ARG;
+    }
+    for (int k = 0; k < nObj; ++k) {
+        const int* w = winHost + 8 * k;
+        const long long rows = w[3] - w[2], cols = w[1] - w[0];
+        if (w[0] < 0 || w[1] > W || w[2] < 0 || w[3] > H || rows < 0 || cols < 0 || w[4] < 0 || w[5] < 0 || w[4] + 2 * rows > geomLen ||
+            w[5] + cols > geomLen || w[6] < 0 || w[6] >= nProf) {
+            nf_set_error("nf_paint_catalog: window or table offsets outside their arrays");
+            return NF_ERR_ARG;
+        }
+    }
+    return nf::paint_catalog(out, H, W, nObj, obj, win, geom, prof, ntab, accumulate, S(stream));
+}
+
+int nf_add_model(int rtype, void* data, const float* model, unsigned char* flagMask, long long n, int subtract, void* stream) {
+    if (!data || !model || n < 1 || (rtype != NF_F32 && rtype != NF_F64)) {
+        nf_set_error("nf_add_model: bad arguments");
+        return NF_ERR_ARG;
+    }
+    return nf::add_model(rtype, data, model, flagMask, n, subtract, S(stream));
+}
+
 int nf_label_components(int vtype, const void* sn, double threshold, int negate, int* labels, int H, int W, int* work,
                         int* numObjects, void* stream) {
     if (!sn || !labels || !work || !numObjects || H < 1 || W < 1) {

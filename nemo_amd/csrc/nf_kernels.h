@@ -46,6 +46,15 @@ int convolve2d(int rtype, const void* in, void* out, int H, int W, const double*
 int edge_check(int vtype, const void* filtered, const unsigned char* psMask, unsigned char* tmp, unsigned char* out, int H, int W,
                int size, hipStream_t s);
 
+// nf_preproc.hip
+int median_filter(int rtype, const void* in, void* out, int H, int W, int size, hipStream_t s);
+int disc_fill(double* rmap, int W, const double* rec, const int* box, int boxPixels, hipStream_t s);
+int disc_apply(int rtype, void* data, const void* bck, unsigned char* surveyMask, unsigned char* psMask, int W, const double* recs,
+               const int* boxes, int nBoxes, double limit, int times60, const double* rmap, hipStream_t s);
+int paint_catalog(float* out, int H, int W, int nObj, const double* obj, const int* win, const double* geom, const double* prof,
+                  int ntab, int accumulate, hipStream_t s);
+int add_model(int rtype, void* data, const float* model, unsigned char* flagMask, long long n, int subtract, hipStream_t s);
+
 // nf_noise.hip
 struct NoiseGrid {
     int ny, nx;          // number of cells per axis

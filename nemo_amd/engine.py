@@ -598,6 +598,87 @@ class TileEngine(object):
         check(fn(ptr(m), ptr(out), self.H, self.W, ptr(kf), kern2d.shape[0], kern2d.shape[1], stream_ptr()), "nf_convolve2d")
         return out
 
+    # ---- preprocessing (maps.MapDict.preprocess) -------------------------------------------------------------
+    def median_filter(self, x, size):
+        """scipy.ndimage.median_filter(x, size), mode reflect (nemo/maps.py:366-368)."""
+        out = self.t.empty_like(x)
+        check(self.lib.nf_median_filter(prec_of(x), ptr(x), ptr(out), self.H, self.W, int(size), stream_ptr()), "nf_median_filter")
+        return out
+
+    def mask_fill_discs(self, data, bck, surveyMask, psMask, recs, boxes, times60=True, persistentLimits=None):
+        """Holes around catalogue positions: where the flat-grid distance to the object is below the limit both masks become
+        0 and the data take the background (nemo/maps.py:419-424, 459-465).  recs [n, 5] float64 {x0, y0, xPixScale,
+        yPixScale, limit}, boxes [n, 4] int32 {minX, maxX, minY, maxY} as makeDegreesDistanceMap forms them.  Independent
+        holes by default; ``persistentLimits`` (n limits): the sequential form of maskPointSourcesFromCatalog, whose distance
+        map is never reset between catalogue rows."""
+        t = self.t
+        recs = np.ascontiguousarray(recs, dtype=np.float64).reshape(-1, 5)
+        boxes = np.ascontiguousarray(boxes, dtype=np.int32).reshape(-1, 4)
+        n = len(recs)
+        if n == 0:
+            return
+        recs_d, boxes_d = to_dev(recs), to_dev(boxes)
+        hostBoxes = boxes.ctypes.data_as(ctypes.POINTER(ctypes.c_int))
+        if persistentLimits is None:
+            check(self.lib.nf_disc_apply(prec_of(data), ptr(data), ptr(bck), ptr(surveyMask), ptr(psMask), self.H, self.W, ptr(recs_d),
+                                         ptr(boxes_d), hostBoxes, n, 0.0, 1 if times60 else 0, None, stream_ptr()), "nf_disc_apply")
+            return
+        # Sequential form.  Row k writes its box into the persistent map, then the WHOLE map is tested against row k's limit
+        # (nemo/maps.py:419-424).  Outside the boxes the map holds 1e6, so only boxes need testing, and an earlier box j only
+        # when row k's limit exceeds every limit its present values have already been tested against (tested[j]); a later box
+        # overlapping j rewrites part of it, values that have met that later row's limit only.
+        limits = np.asarray(persistentLimits, dtype=np.float64)
+        tested = np.zeros(n)
+        sched, starts = [], [0]
+        for k in range(n):
+            prev = np.flatnonzero(limits[k] > tested[:k])
+            tested[prev] = limits[k]
+            tested[k] = limits[k]
+            b, bk = boxes[:k], boxes[k]
+            over = np.flatnonzero((b[:, 0] < bk[1]) & (bk[0] < b[:, 1]) & (b[:, 2] < bk[3]) & (bk[2] < b[:, 3]))
+            tested[over] = np.minimum(tested[over], limits[k])
+            sched.append(np.concatenate([prev, [k]]))
+            starts.append(starts[-1] + len(prev) + 1)
+        order = np.concatenate(sched).astype(np.int64)
+        schedBoxes = np.ascontiguousarray(boxes[order])
+        schedBoxes_d = to_dev(schedBoxes)
+        rmap = t.full((self.H, self.W), 1e6, dtype=t.float64, device=self.dev)
+        for k in range(n):
+            hb = boxes[k].ctypes.data_as(ctypes.POINTER(ctypes.c_int))
+            check(self.lib.nf_disc_fill(ptr(rmap), self.H, self.W, ptr(recs_d[k]), ptr(boxes_d[k]), hb, stream_ptr()), "nf_disc_fill")
+            a, e = starts[k], starts[k + 1]
+            check(self.lib.nf_disc_apply(prec_of(data), ptr(data), ptr(bck), ptr(surveyMask), ptr(psMask), self.H, self.W, ptr(recs_d),
+                                         ptr(schedBoxes_d[a:e]), schedBoxes[a:e].ctypes.data_as(ctypes.POINTER(ctypes.c_int)), e - a,
+                                         float(limits[k]), 1 if times60 else 0, ptr(rmap), stream_ptr()), "nf_disc_apply")
+
+    def paint_catalog(self, objs, wins, geom, profs, ntab, out=None):
+        """Sum of the objects' radial templates, each inside its window, accumulated in float32 in catalogue order
+        (nf_paint_catalog).  objs [n, 8] float64, wins [n, 8] int32, geom: packed haversine tables, profs [nProf, 3, ntab]."""
+        t = self.t
+        objs = np.ascontiguousarray(objs, dtype=np.float64).reshape(-1, 8)
+        wins = np.ascontiguousarray(wins, dtype=np.int32).reshape(-1, 8)
+        geom = np.ascontiguousarray(geom, dtype=np.float64)
+        profs = np.ascontiguousarray(profs, dtype=np.float64)
+        acc = 1
+        if out is None:
+            out = t.empty((self.H, self.W), dtype=t.float32, device=self.dev)
+            acc = 0
+        if len(objs) == 0:
+            if not acc:
+                out.zero_()
+            return out
+        o_d, w_d, g_d, p_d = to_dev(objs), to_dev(wins), to_dev(geom), to_dev(profs)
+        check(self.lib.nf_paint_catalog(ptr(out), self.H, self.W, len(objs), ptr(o_d), ptr(w_d),
+                                        wins.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), ptr(g_d), geom.size, ptr(p_d),
+                                        profs.shape[0], int(ntab), acc, stream_ptr()), "nf_paint_catalog")
+        return out
+
+    def add_model(self, data, model, flagMask=None, subtract=False):
+        """data -= model, flagMask += (model > 1) (nemo/maps.py:435-437), or data += model (:344); in place."""
+        check(self.lib.nf_add_model(prec_of(data), ptr(data), ptr(model), ptr(flagMask), data.numel(), 1 if subtract else 0,
+                                    stream_ptr()), "nf_add_model")
+        return data
+
     # ---- detection -----------------------------------------------------------------------------------------
     def label(self, sn, threshold, negate=False):
         t = self.t

@@ -6,11 +6,14 @@ Mirrors, for the hot path only:
 * ``subtractBackground`` / ``smoothMap``       - nemo/maps.py:1279-1292,1357-1382
 * ``convertToDeltaT``                          - nemo/maps.py:679-697
 
+* ``makeModelImage`` / ``makeDegreesDistanceMap`` - nemo/maps.py:1658-1853, 2479-2536
+
 Maps are held in memory (numpy arrays, or torch tensors already resident in HBM): a ``MapDict`` takes
 ``mapData`` / ``weightsData`` (arrays) or ``mapFileName`` / ``weightsFileName`` (``.npy`` or simple FITS
-files readable by :mod:`nemo_amd.fitsio`).  The catalogue-driven preprocessing steps of the reference
-(hole filling, model subtraction, source injection: nemo/maps.py:294-465) are the "next" row of the scope
-table and raise if requested.
+files readable by :mod:`nemo_amd.fitsio`).  The catalogue-driven preprocessing steps of the reference (nemo/maps.py:326-465:
+source injection, the 20 x 20 median-filtered background, holes cut and filled at catalogue positions, model subtraction)
+run on the device: as soon as one of them is asked for, the tile is uploaded and stays in HBM for the filters.
+Catalogues are :class:`nemo_amd.catalogs.Table` objects (what the pipeline's earlier passes return).
 """
 import os
 
@@ -20,9 +23,9 @@ from . import engine
 from .signals import convertToDeltaT  # noqa: F401  (re-exported: reference has it in maps)
 from .wcs import calcAngSepDeg
 
-_UNSUPPORTED_KEYS = ['CMBSimSeed', 'injectSources', 'applyBeamConvolution', 'smoothKernel', 'extendedMask',
-                     'maskPointSourcesFromCatalog', 'subtractModelFromCatalog', 'maskAndFillFromCatalog',
-                     'apodizeUsingSurveyMask']
+# not on the path: simulated skies (pixell curvedsky), tILe-C beam matching, dilation by mahotas, unseeded random fills
+_UNSUPPORTED_KEYS = ['CMBSimSeed', 'applyBeamConvolution', 'smoothKernel', 'extendedMask', 'apodizeUsingSurveyMask']
+_DEVICE_KEYS = ['injectSources', 'maskPointSourcesFromCatalog', 'subtractModelFromCatalog', 'maskAndFillFromCatalog']
 
 
 def _is_tensor(x):
@@ -85,18 +88,24 @@ class MapDict(dict):
         """nemo/maps.py:178-480, the steps that apply to plain (map, weights, masks) inputs."""
         for k in _UNSUPPORTED_KEYS:
             if k in self and self[k] not in (None, False):
-                raise NotImplementedError("MapDict key '%s' (catalogue/simulation preprocessing, nemo/maps.py:294-465) "
-                                          "is not part of this build yet" % (k))
+                raise NotImplementedError("MapDict key '%s' (nemo/maps.py:252-262,294-323,346-379) is not part of this build" % (k))
+        onDevice = any(k in self and self[k] is not None for k in _DEVICE_KEYS)
         data, wcs = self.loadTile('mapFileName', tileName, returnWCS=True)
+        if onDevice:
+            data = engine.to_dev(data)
         if 'calibFactor' in self.keys():
             data = data * self['calibFactor']
         if self.get('weightsFileName') is not None or self.get('weightsData') is not None:
             weights = self.loadTile('weightsFileName', tileName)
+            if onDevice:
+                weights = engine.to_dev(weights)
         else:
             weights = np.ones(data.shape) if not _is_tensor(data) else engine.torch().ones_like(data)
         data[weights == 0] = 0                                                    # :243
         if self.get('surveyMask') is not None:
             surveyMask = self.loadTile('surveyMask', tileName)
+            if onDevice:
+                surveyMask = engine.to_dev(surveyMask, dtype=engine.torch().uint8)
         else:
             if _is_tensor(data):
                 surveyMask = (weights != 0).to(engine.torch().uint8)
@@ -105,11 +114,16 @@ class MapDict(dict):
                 surveyMask[weights == 0] = 0
         if self.get('pointSourceMask') is not None:
             psMask = self.loadTile('pointSourceMask', tileName)
+            if onDevice:
+                psMask = engine.to_dev(psMask, dtype=engine.torch().uint8)
         else:
             psMask = np.ones(data.shape, dtype=np.uint8) if not _is_tensor(data) else \
                 engine.torch().ones(data.shape, dtype=engine.torch().uint8, device=data.device)
         if self.get('flagMask') is not None:
-            flagMask = self.loadTile('flagMask', tileName) * surveyMask
+            flagMask = self.loadTile('flagMask', tileName)
+            if onDevice:
+                flagMask = engine.to_dev(flagMask, dtype=engine.torch().uint8)
+            flagMask = flagMask * surveyMask
         else:
             flagMask = np.zeros(tuple(data.shape), dtype=np.uint8) if not _is_tensor(data) else \
                 engine.torch().zeros(tuple(data.shape), dtype=engine.torch().uint8, device=data.device)
@@ -130,6 +144,8 @@ class MapDict(dict):
             wcs = type(wcs)(hdr)
             if data.shape[0] == 0 or data.shape[1] == 0:
                 raise Exception("Clipping using RADecSection returned empty array - check RADecSection in config .yml file is in map")
+        if onDevice:
+            data, surveyMask, psMask, flagMask = self._catalogueSteps(data, weights, wcs, surveyMask, psMask, flagMask, tileName)
         self['data'] = data
         self['weights'] = weights
         self['wcs'] = wcs
@@ -141,6 +157,221 @@ class MapDict(dict):
             raise Exception("Map and point source mask dimensions are not the same (they should also have same WCS)")
         if tuple(self['data'].shape) != tuple(self['surveyMask'].shape):
             raise Exception("Map and survey mask dimensions are not the same (they should also have same WCS)")
+
+
+def _holeTable(entry):
+    if isinstance(entry, str):
+        raise NotImplementedError("catalogues are given as nemo_amd.catalogs.Table objects (reading catalogue files needs astropy)")
+    return entry
+
+
+def _mapDictCatalogueSteps(self, data, weights, wcs, surveyMask, psMask, flagMask, tileName):
+    """nemo/maps.py:325-465 on device tensors: source injection, the median-filtered background, holes at catalogue
+    positions (masked in both masks, filled with the background), model subtraction with its flag."""
+    t = engine.torch()
+    from . import catalogs
+    eng = engine.TileEngine.get(tuple(data.shape))
+    shape = tuple(data.shape)
+    data = data.contiguous()
+    surveyMask = surveyMask.to(t.uint8).contiguous().clone()
+    psMask = psMask.to(t.uint8).contiguous().clone()
+    flagMask = flagMask.to(t.uint8).contiguous().clone()
+    if self.get('injectSources') is not None:                                     # :326-344
+        inj = self['injectSources']
+        GNFWParams, obsFreqGHz = (inj['GNFWParams'], self['obsFreqGHz']) if 'GNFWParams' in inj.keys() else (None, None)
+        valid = self.tileCoordsDict[tileName]['areaMaskInClipSection'] if self.tileCoordsDict is not None else None
+        modelMap = makeModelImage(shape, wcs, inj['catalog'], self['beamFileName'], obsFreqGHz=obsFreqGHz, GNFWParams=GNFWParams,
+                                  profile=inj['profile'], validAreaSection=valid, override=inj['override'])
+        if modelMap is not None:
+            modelMap = t.where(weights == 0, t.zeros((), dtype=modelMap.dtype, device=modelMap.device), modelMap)
+            data = (data + modelMap).contiguous()           # dtype promotes as numpy's does (float64 model in the override branch)
+    holeFilling = any(h in self.keys() for h in ['maskPointSourcesFromCatalog', 'maskAndFillFromCatalog', 'extendedMask'])
+    if holeFilling:                                                               # :360-368
+        pixRad = (10.0 / 60.0) / wcs.getPixelSizeDeg()
+        bckData = eng.median_filter(data, int(pixRad))
+    if self.get('maskPointSourcesFromCatalog') is not None:                       # :383-424
+        entries = self['maskPointSourcesFromCatalog']
+        if type(entries) is not list:
+            entries = self['maskPointSourcesFromCatalog'] = [entries]
+        psMask = t.ones_like(psMask)
+        recs, boxes, limits = [], [], []
+        for info in entries:
+            fluxCutJy = 0.0
+            if type(info) == dict:
+                tab, fluxCutJy = _holeTable(info['path']), info['fluxCutJy']
+            else:
+                tab = _holeTable(info)
+            if 'fluxJy' in tab.keys():
+                tab = tab[np.asarray(tab['fluxJy']) > fluxCutJy]
+            tab = catalogs.getCatalogWithinImage(tab, shape, wcs)
+            for row in tab:
+                if 'rArcmin' in tab.keys():
+                    maskRadiusArcmin = row['rArcmin']
+                elif 'ellipse_A' in tab.keys():
+                    xPixSizeArcmin = (wcs.getXPixelSizeDeg() / np.cos(np.radians(row['decDeg']))) * 60
+                    maskRadiusArcmin = (row['ellipse_A'] / xPixSizeArcmin) / 2
+                else:
+                    raise Exception("To mask sources in a catalog, need either 'rArcmin' or 'ellipse_A' column to be present.")
+                rec, box = degreesDistanceBox(shape, wcs, row['RADeg'], row['decDeg'], maskRadiusArcmin / 60)
+                recs.append(rec + [maskRadiusArcmin / 60.0])
+                boxes.append(box)
+                limits.append(maskRadiusArcmin / 60.0)
+        eng.mask_fill_discs(data, bckData, surveyMask, psMask, recs, boxes, times60=False, persistentLimits=limits)
+    if self.get('subtractModelFromCatalog') is not None:                          # :426-437
+        tabs = self['subtractModelFromCatalog']
+        if type(tabs) is not list:
+            tabs = self['subtractModelFromCatalog'] = [tabs]
+        for tab in tabs:
+            tab = catalogs.getCatalogWithinImage(_holeTable(tab), shape, wcs)
+            model = makeModelImage(shape, wcs, tab, self['beamFileName'], obsFreqGHz=self['obsFreqGHz'])
+            if model is not None:
+                eng.add_model(data, model.contiguous(), flagMask, subtract=True)
+    if self.get('maskAndFillFromCatalog') is not None:                            # :439-465
+        tabs = self['maskAndFillFromCatalog']
+        if type(tabs) is not list:
+            tabs = self['maskAndFillFromCatalog'] = [tabs]
+        for tab in tabs:
+            tab = catalogs.getCatalogWithinImage(_holeTable(tab), shape, wcs)
+            if len(tab) > 0 and 'ellipse_A' not in tab.keys() and 'maskHoleRadiusArcmin' not in self.keys():
+                raise Exception("Need to set measureShapes: True or set maskHoleRadiusArcmin to use maskAndFillFromCatalog")
+            recs, boxes = [], []
+            for row in tab:
+                if 'ellipse_B' in tab.keys():          # (the reference's test - 'ellipse_A' and 'ellipse_B' in keys - reads so)
+                    xPixSizeArcmin = (wcs.getXPixelSizeDeg() / np.cos(np.radians(row['decDeg']))) * 60
+                    maskRadiusArcmin = (row['ellipse_A'] / xPixSizeArcmin) / 2
+                if self.get('maskHoleRadiusArcmin') is not None:
+                    maskRadiusArcmin = self['maskHoleRadiusArcmin']
+                if self.get('maskHoleDilationFactor') is not None:
+                    maskRadiusArcmin = maskRadiusArcmin * self['maskHoleDilationFactor']
+                rec, box = degreesDistanceBox(shape, wcs, row['RADeg'], row['decDeg'], maskRadiusArcmin / 60)
+                recs.append(rec + [maskRadiusArcmin])
+                boxes.append(box)
+            eng.mask_fill_discs(data, bckData, surveyMask, psMask, recs, boxes, times60=True)
+    return data, surveyMask, psMask, flagMask
+
+
+MapDict._catalogueSteps = _mapDictCatalogueSteps
+
+
+def degreesDistanceBox(shape, wcs, RADeg, decDeg, maxDistDegrees):
+    """The scalars of maps.makeDegreesDistanceMap (nemo/maps.py:2506-2529): ([x0, y0, xPixScale, yPixScale], [minX, maxX, minY,
+    maxY]) - the map of distances itself is formed on the device (nf_disc_fill / nf_disc_apply)."""
+    x0, y0 = wcs.wcs2pix(RADeg, decDeg)
+    ra1, dec1 = wcs.pix2wcs(x0 + 1, y0 + 1)
+    xPixScale = calcAngSepDeg(RADeg, decDeg, ra1, decDeg)
+    yPixScale = calcAngSepDeg(RADeg, decDeg, RADeg, dec1)
+    xDistPix = int(round((maxDistDegrees) / xPixScale))
+    yDistPix = int(round((maxDistDegrees) / yPixScale))
+    Y, X = shape
+    minX, maxX = max(int(round(x0)) - xDistPix, 0), min(int(round(x0)) + xDistPix, X)
+    minY, maxY = max(int(round(y0)) - yDistPix, 0), min(int(round(y0)) + yDistPix, Y)
+    maxX, maxY = max(maxX, minX), max(maxY, minY)
+    return [float(x0), float(y0), float(xPixScale), float(yPixScale)], [minX, maxX, minY, maxY]
+
+
+def _modelObjects(catalog, beam, obsFreqGHz, GNFWParams, profile, override, TCMBAlpha, maxSizeDegMultiplier, cosmoModel):
+    """Per catalogue row what the painter needs (nemo/maps.py:1752-1840): (RADeg, decDeg, radial table, maxSizeDeg, float32
+    factors applied to the painted value)."""
+    from . import signals
+    out = []
+    keys = catalog.keys()
+    if 'y_c' in keys or 'true_y_c' in keys:
+        kind = {'A10': 'arnaud', 'B12': 'battaglia'}.get(profile)
+        if kind is None:
+            raise Exception("Didn't understand profile - should be A10 or B12.")
+        gp = 'default' if GNFWParams in (None, 'default') else GNFWParams
+        for row in catalog:
+            if override is not None:
+                z, M500, y0 = override['redshift'], override['M500'], row['y_c'] * 1e-4
+            elif 'true_M500c' in keys:
+                M500, z, y0 = row['true_M500c'] * 1e14, row['redshift'], row['true_y_c'] * 1e-4
+            else:
+                if 'template' not in keys:
+                    raise Exception("No M500, z, or template column found in catalog.")
+                bits = str(row['template']).split("#")[0].split("_")
+                M500 = float(bits[1][1:].replace("p", "."))
+                z = float(bits[2][1:].replace("p", "."))
+                y0 = row['y_c'] * 1e-4
+                if z == 0:
+                    raise Exception("z = 0 template? template = %s, tileName = %s" % (row['template'], row['tileName']))
+            theta500Arcmin = signals.calcTheta500Arcmin(z, M500, cosmoModel)
+            maxSizeDeg = (5 if override is not None else maxSizeDegMultiplier) * (theta500Arcmin / 60)
+            table = signals.clusterModelTable(kind, beam, z, M500, gp, float(y0), maxSizeDeg)
+            factors = None
+            if obsFreqGHz is not None:
+                factors = (float(signals.fSZ(obsFreqGHz, TCMBAlpha=TCMBAlpha, z=z)), signals.TCMB * 1e6)
+            out.append((row['RADeg'], row['decDeg'], table, maxSizeDeg, factors))
+    else:
+        base = signals.templateTables('beam', beam, {}, amplitude=1.0)       # nemo/signals.py:595-627; one table, many amplitudes
+        for row in catalog:
+            out.append((row['RADeg'], row['decDeg'], signals.scaledTable(base, row['deltaT_c']), 1.0, None))
+    return out
+
+
+def modelWindow(shape, wcs, RADeg, decDeg, maxSizeDeg):
+    """Pixel window of the box of +- maxSizeDeg around an object that signals._paintSignalMap clips before painting into an
+    existing map (nemo/signals.py:675-680; the rounding rule of the clip is this build's, as for RADecSection)."""
+    xa, ya = wcs.wcs2pix(RADeg + maxSizeDeg / np.cos(np.radians(decDeg)), decDeg - maxSizeDeg)
+    xb, yb = wcs.wcs2pix(RADeg - maxSizeDeg / np.cos(np.radians(decDeg)), decDeg + maxSizeDeg)
+    x0, x1 = sorted([int(round(xa)), int(round(xb))])
+    y0, y1 = sorted([int(round(ya)), int(round(yb))])
+    x0, y0 = min(max(x0, 0), shape[1]), min(max(y0, 0), shape[0])
+    x1, y1 = min(max(x1, x0), shape[1]), min(max(y1, y0), shape[0])
+    return x0, x1, y0, y1
+
+
+def makeModelImage(shape, wcs, catalog, beamFileName, obsFreqGHz=None, GNFWParams='default', profile='A10', cosmoModel=None,
+                   applyPixelWindow=True, override=None, validAreaSection=None, minSNR=-99, TCMBAlpha=0, reportTimingInfo=False,
+                   maxSizeDegMultiplier=5, useInferredSZProperties=False):
+    """Map of model clusters / point sources at the catalogue's positions (nemo/maps.py:1658-1853), float32, on the device;
+    None when no object lies inside the map.  The painter is this build's (signals.RadialTable + nf_paint_catalog): every
+    object inside its own +- maxSizeDeg window, summed in float32 in catalogue order."""
+    from . import signals, catalogs
+    if useInferredSZProperties:
+        raise NotImplementedError("useInferredSZProperties (nemoMass -I output) is outside the hot path")
+    catalog = catalogs.getCatalogWithinImage(_holeTable(catalog), shape, wcs)
+    SNRKey = 'SNR' if 'SNR' in catalog.keys() else ('fixed_SNR' if 'fixed_SNR' in catalog.keys() else None)
+    if SNRKey is not None and len(catalog) > 0:
+        catalog = catalog[np.asarray(catalog[SNRKey]) > minSNR]
+    if validAreaSection is not None and len(catalog) > 0:
+        x0, x1, y0, y1 = validAreaSection
+        x, y = wcs.wcs2pix(np.asarray(catalog['RADeg'], dtype=np.float64), np.asarray(catalog['decDeg'], dtype=np.float64))
+        x, y = np.atleast_1d(x), np.atleast_1d(y)
+        catalog = catalog[(x >= x0) & (x < x1) & (y >= y0) & (y < y1)]
+    if len(catalog) == 0:
+        return None
+    if cosmoModel is None:
+        cosmoModel = signals.fiducialCosmoModel
+    beam = signals._asBeam(beamFileName)
+    objects = _modelObjects(catalog, beam, obsFreqGHz, GNFWParams, profile, override, TCMBAlpha, maxSizeDegMultiplier, cosmoModel)
+    perObjectFactors = override is None          # the override branch converts the summed map instead (:1786-1788)
+    objs, wins, geomParts, profTabs, profIndex, off = [], [], [], [], {}, 0
+    for RADeg, decDeg, table, maxSizeDeg, factors in objects:
+        wx0, wx1, wy0, wy1 = modelWindow(shape, wcs, RADeg, decDeg, maxSizeDeg)
+        A, B, C = signals.paintGeometry(shape, wcs, RADeg, decDeg)
+        nrow, ncol = wy1 - wy0, wx1 - wx0
+        geomParts += [A[wy0:wy1], B[wy0:wy1], C[wx0:wx1]]
+        pid = profIndex.get(id(table.prof))
+        if pid is None:
+            pid = profIndex[id(table.prof)] = len(profTabs)
+            slope = np.zeros(len(table.r))
+            slope[:-1] = (table.prof[1:] - table.prof[:-1]) / (table.r[1:] - table.r[:-1])
+            profTabs.append(np.stack([table.r, table.prof, slope]))
+        useF = 1.0 if (factors is not None and perObjectFactors) else 0.0
+        f1, f2 = factors if factors is not None else (1.0, 1.0)
+        objs.append([table.amp, table.sign, f1, f2, float(pid), useF, 0.0, 0.0])
+        wins.append([wx0, wx1, wy0, wy1, off, off + 2 * nrow, pid, 0])
+        off += 2 * nrow + ncol
+    eng = engine.TileEngine.get(shape)
+    ntab = profTabs[0].shape[1]
+    modelMap = eng.paint_catalog(objs, wins, np.concatenate(geomParts) if off > 0 else np.zeros(1), np.array(profTabs), ntab)
+    if override is not None and obsFreqGHz is not None:
+        # convertToDeltaT of the whole map (:1786-1788): float32 * float64 scalar -> a float64 map from here on (numpy >= 2)
+        fx = float(signals.fSZ(obsFreqGHz, TCMBAlpha=TCMBAlpha, z=override['redshift']))
+        modelMap = (modelMap.double() * fx) * (signals.TCMB * 1e6)
+    if applyPixelWindow == True:
+        modelMap = eng.apply_window(modelMap.contiguous(), 1.0)
+    return modelMap
 
 
 def pixelScalesDeg(wcs, RADeg='centre', decDeg='centre'):

@@ -315,6 +315,7 @@ class RadialTable(object):
         self.r = np.ascontiguousarray(r, dtype=np.float64)
         self.prof = np.ascontiguousarray(prof, dtype=np.float64)
         self.amp = float(np.float32(amp))       # amps are cast to float32 (nemo/signals.py:644,670-673)
+        self.ampExact = float(amp)
         self.sign = float(sign)
         self.r0 = float(self.r[0])
         self.dlnr = float(np.log(self.r[-1] / self.r[0]) / (len(self.r) - 1))
@@ -372,6 +373,37 @@ def paintGeometry(shape, wcs, RADeg, decDeg):
     B = np.cos(dec) * np.cos(dec0)
     C = np.sin(dra / 2.0) ** 2
     return A, B, C
+
+
+_modelProfileCache = {}
+
+
+def clusterModelTable(kind, beam, z, M500, GNFWParams, amplitude, maxSizeDeg):
+    """Radial table of one model cluster of maps.makeModelImage (nemo/maps.py:1821-1831 -> make*ModelSignalMap,
+    nemo/signals.py:751-770): the beam-convolved projected GNFW profile out to ``maxSizeDeg``, central amplitude ``amplitude``."""
+    beam = _asBeam(beam)
+    gkey = 'default' if GNFWParams == 'default' else tuple(sorted(GNFWParams.items()))
+    ckey = (kind, float(z), float(M500), gkey)
+    if ckey not in _profileCache:
+        fn = makeArnaudModelProfile if kind == 'arnaud' else makeBattagliaModelProfile
+        _profileCache[ckey] = fn(z, M500, GNFWParams=GNFWParams)
+    # one table object per (profile, beam, size, amplitude): tables of equal profile share their arrays through the cache
+    key = (ckey, beam.cacheKey(), float(maxSizeDeg))
+    base = _modelProfileCache.get(key)
+    if base is None:
+        base = _modelProfileCache[key] = makeRadialTable(_profileCache[ckey]['tckP'], beam=beam, amplitude=1.0,
+                                                         maxSizeDeg=float(maxSizeDeg), convolveWithBeam=True, cacheKey=ckey)
+    return scaledTable(base, amplitude)
+
+
+def scaledTable(base, amplitude):
+    """A table made with amplitude 1 given another amplitude: amp = rprof[0] * amplitude (nemo/signals.py:662-664), cast to
+    float32 once.  The arrays are shared with ``base`` (one upload for a whole catalogue)."""
+    tab = RadialTable.__new__(RadialTable)
+    tab.r, tab.prof, tab.sign, tab.r0, tab.dlnr = base.r, base.prof, base.sign, base.r0, base.dlnr
+    tab.ampExact = base.ampExact * amplitude
+    tab.amp = float(np.float32(tab.ampExact))
+    return tab
 
 
 def templateTables(kind, beam, params, amplitude=None):

@@ -81,6 +81,12 @@ class CARWCS(object):
     def getPixelSizeDeg(self):
         return abs(self._cdelt2)
 
+    def getXPixelSizeDeg(self):
+        return abs(self._cdelt1)
+
+    def getYPixelSizeDeg(self):
+        return abs(self._cdelt2)
+
     def getImageMinMaxWCSCoords(self):
         W, H = self.header['NAXIS1'], self.header['NAXIS2']
         ra0, dec0 = self.pix2wcs(0.0, 0.0)

@@ -257,6 +257,15 @@ int nf_label_components(int vtype, const void* sn_d, double threshold, int negat
 int nf_object_stats(int vtype, const void* sn_d, int negate, const int* labels_d, int H, int W, int numObjects,
                     double* stats_d, void* stream);
 
+/* The segment moments behind measureShapes (photometry.findObjects, nemo/photometry.py:136-150): per label id 0..numObjects
+ * a record of 10 doubles {xMin, yMin, xMax, yMax, S, Sx, Sy, Sxx, Syy, Sxy} with S = sum v, Sx = sum v*(x - xMin),
+ * Sxx = sum v*(x - xMin)^2 ... over the segment's pixels (v as in nf_object_stats: exact integer sums of v * 2^40).
+ * shapes_d must hold (numObjects+1)*NF_OBJECT_SHAPES_DOUBLES doubles (the tail is scratch).  The ellipse itself
+ * (nemo/photometry.py:151-184) is a few scalar operations per object and stays with the caller. */
+#define NF_OBJECT_SHAPES_DOUBLES 30
+int nf_object_shapes(int vtype, const void* sn_d, int negate, const int* labels_d, int H, int W, int numObjects,
+                     double* shapes_d, void* stream);
+
 /* ndarray.max() / np.argmax of a whole map (nemo/filters.py:661,684; nemo/filters.py:1017-1019,1198): out_d holds
  * NF_MAP_MAX_DOUBLES doubles - [0] maximum, [1] flat index of its first occurrence, the rest is scratch (per-workgroup
  * partial results). */

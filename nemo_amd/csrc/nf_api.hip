@@ -612,6 +612,15 @@ int nf_object_stats(int vtype, const void* sn, int negate, const int* labels, in
     return nf::object_stats(vtype, sn, negate, labels, H, W, numObjects, stats, S(stream));
 }
 
+int nf_object_shapes(int vtype, const void* sn, int negate, const int* labels, int H, int W, int numObjects, double* shapes,
+                     void* stream) {
+    if (!sn || !labels || !shapes || H < 1 || W < 1 || numObjects < 0 || (vtype != NF_F32 && vtype != NF_F64)) {
+        nf_set_error("nf_object_shapes: bad arguments");
+        return NF_ERR_ARG;
+    }
+    return nf::object_shapes(vtype, sn, negate, labels, H, W, numObjects, shapes, S(stream));
+}
+
 size_t nf_xmatch_workspace_bytes(int n) { return n > 0 ? nf::xmatch_workspace_bytes(n) : 0; }
 
 int nf_xmatch_self(const double* unit_d, const double* snr_d, int n, double radiusDeg, int* count_d, int* best_d,

@@ -384,6 +384,122 @@ int object_stats(int vtype, const void* sn, int negate, const int* labels, int H
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Segment moments for the SExtractor-style shapes of photometry.findObjects (measureShapes, nemo/photometry.py:133-184):
+// per label the bounding box and sum v, sum v*dx, sum v*dy, sum v*dx^2, sum v*dy^2, sum v*dx*dy with dx = x - xMin,
+// dy = y - yMin (the reference shifts the coordinates by the box corner before it forms the moments, :143-150).
+// Same exact integer accumulation as the centroid sums above (I_v * dx^2 < 2^63 * 2^30: inside 128 bits).
+// shapes layout per label id: [0] xMin [1] yMin [2] xMax [3] yMax [4] S [5] Sx [6] Sy [7] Sxx [8] Syy [9] Sxy
+#define NF_SHAPE_STRIDE 10
+#define NF_SHAPE_LIMBS 18
+
+__global__ void k_shape_bbox(const int* __restrict__ labels, int H, int W, int* __restrict__ mins, int* __restrict__ maxs) {
+    const int segsPerRow = (W + NF_RUN - 1) / NF_RUN;
+    const long long nseg = (long long)H * segsPerRow;
+    for (long long sidx = blockIdx.x * (long long)blockDim.x + threadIdx.x; sidx < nseg; sidx += (long long)gridDim.x * blockDim.x) {
+        const int y = (int)(sidx / segsPerRow), x0 = (int)(sidx % segsPerRow) * NF_RUN;
+        int cur = 0, xa = 0, xb = 0;
+        for (int j = 0; j < NF_RUN && x0 + j < W; ++j) {
+            const int id = labels[(long long)y * W + x0 + j];
+            if (id != cur) {
+                if (cur > 0) {
+                    atomicMin(&mins[2 * cur], xa);
+                    atomicMin(&mins[2 * cur + 1], y);
+                    atomicMax(&maxs[2 * cur], xb);
+                    atomicMax(&maxs[2 * cur + 1], y);
+                }
+                cur = id;
+                xa = x0 + j;
+            }
+            xb = x0 + j;
+        }
+        if (cur > 0) {
+            atomicMin(&mins[2 * cur], xa);
+            atomicMin(&mins[2 * cur + 1], y);
+            atomicMax(&maxs[2 * cur], xb);
+            atomicMax(&maxs[2 * cur + 1], y);
+        }
+    }
+}
+
+template <typename VT>
+__global__ void k_shape_moments(const VT* __restrict__ sn, int negate, const int* __restrict__ labels, int H, int W,
+                                const int* __restrict__ mins, unsigned long long* __restrict__ limbs) {
+    const int segsPerRow = (W + NF_RUN - 1) / NF_RUN;
+    const long long nseg = (long long)H * segsPerRow;
+    for (long long sidx = blockIdx.x * (long long)blockDim.x + threadIdx.x; sidx < nseg; sidx += (long long)gridDim.x * blockDim.x) {
+        const int y = (int)(sidx / segsPerRow), x0 = (int)(sidx % segsPerRow) * NF_RUN;
+        int cur = 0, xMin = 0, yMin = 0;
+        unsigned __int128 acc[6] = {0, 0, 0, 0, 0, 0};
+        for (int j = 0; j < NF_RUN && x0 + j < W; ++j) {
+            const long long p = (long long)y * W + x0 + j;
+            const int id = labels[p];
+            if (id != cur) {
+                if (cur > 0) {
+                    unsigned long long* w = limbs + (long long)cur * NF_SHAPE_LIMBS;
+                    for (int k = 0; k < 6; ++k) flush_limbs(w + 3 * k, acc[k]);
+                }
+                cur = id;
+                for (int k = 0; k < 6; ++k) acc[k] = 0;
+                if (id > 0) {
+                    xMin = mins[2 * id];
+                    yMin = mins[2 * id + 1];
+                }
+            }
+            if (id > 0) {
+                double v = (double)sn[p];
+                if (negate) v = -v;
+                const unsigned long long iv = (unsigned long long)rint(fmin(fmax(v, 0.0), NF_FIX_VMAX) * (double)(1ULL << NF_FIX_SHIFT));
+                const unsigned long long dx = (unsigned long long)(x0 + j - xMin), dy = (unsigned long long)(y - yMin);
+                acc[0] += iv;
+                acc[1] += (unsigned __int128)iv * dx;
+                acc[2] += (unsigned __int128)iv * dy;
+                acc[3] += (unsigned __int128)iv * (dx * dx);
+                acc[4] += (unsigned __int128)iv * (dy * dy);
+                acc[5] += (unsigned __int128)iv * (dx * dy);
+            }
+        }
+        if (cur > 0) {
+            unsigned long long* w = limbs + (long long)cur * NF_SHAPE_LIMBS;
+            for (int k = 0; k < 6; ++k) flush_limbs(w + 3 * k, acc[k]);
+        }
+    }
+}
+
+__global__ void k_shape_finish(double* __restrict__ shapes, const unsigned long long* __restrict__ limbs, const int* __restrict__ mins,
+                               const int* __restrict__ maxs, int numObjects) {
+    for (int id = blockIdx.x * blockDim.x + threadIdx.x; id <= numObjects; id += gridDim.x * blockDim.x) {
+        double* r = shapes + (long long)id * NF_SHAPE_STRIDE;
+        r[0] = (double)mins[2 * id];
+        r[1] = (double)mins[2 * id + 1];
+        r[2] = (double)maxs[2 * id];
+        r[3] = (double)maxs[2 * id + 1];
+        const unsigned long long* w = limbs + (long long)id * NF_SHAPE_LIMBS;
+        for (int k = 0; k < 6; ++k) r[4 + k] = limbs_to_double(w + 3 * k);
+    }
+}
+
+// `shapes` must hold (numObjects+1) * 30 doubles: 10 per record, then scratch - 18 integer limbs and the box corners
+int object_shapes(int vtype, const void* sn, int negate, const int* labels, int H, int W, int numObjects, double* shapes, hipStream_t s) {
+    const size_t nrec = (size_t)numObjects + 1;
+    unsigned long long* limbs = (unsigned long long*)(shapes + nrec * NF_SHAPE_STRIDE);
+    int* mins = (int*)(limbs + nrec * NF_SHAPE_LIMBS);
+    int* maxs = mins + 2 * nrec;
+    NF_HIP(hipMemsetAsync(limbs, 0, nrec * NF_SHAPE_LIMBS * sizeof(unsigned long long), s));
+    NF_HIP(hipMemsetAsync(mins, 0x7F, 2 * nrec * sizeof(int), s));
+    NF_HIP(hipMemsetAsync(maxs, 0, 2 * nrec * sizeof(int), s));
+    const long long nseg = (long long)H * ((W + NF_RUN - 1) / NF_RUN);
+    dim3 g(grid_for(nseg, 256)), b(256);
+    hipLaunchKernelGGL(k_shape_bbox, g, b, 0, s, labels, H, W, mins, maxs);
+    if (vtype == NF_F64)
+        hipLaunchKernelGGL(k_shape_moments<double>, g, b, 0, s, (const double*)sn, negate, labels, H, W, mins, limbs);
+    else
+        hipLaunchKernelGGL(k_shape_moments<float>, g, b, 0, s, (const float*)sn, negate, labels, H, W, mins, limbs);
+    hipLaunchKernelGGL(k_shape_finish, dim3(grid_for(nrec, 256)), dim3(256), 0, s, shapes, limbs, mins, maxs, numObjects);
+    NF_CHECK_LAUNCH("object_shapes");
+    return NF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // np.argmax / ndarray.max of a whole map (nemo/filters.py:661,684): maximum value and FIRST raster index attaining it.
 // One pass: every thread keeps (value, first index) of its grid-stride share, the workgroup reduces with wavefront
 // shuffles + LDS and writes ONE partial; a second single-workgroup launch reduces the partials.  No atomics (65536

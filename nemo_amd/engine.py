@@ -696,6 +696,14 @@ class TileEngine(object):
                                        ptr(stats), stream_ptr()), "nf_object_stats")
         return stats[:(numObjects + 1) * 6].reshape(numObjects + 1, 6)
 
+    def object_shapes(self, sn, labels, numObjects, negate=False):
+        """Per label {xMin, yMin, xMax, yMax, S, Sx, Sy, Sxx, Syy, Sxy} (nemo/photometry.py:136-150), tensor [n+1, 10]."""
+        t = self.t
+        shapes = t.empty((numObjects + 1) * 30, dtype=t.float64, device=self.dev)     # NF_OBJECT_SHAPES_DOUBLES
+        check(self.lib.nf_object_shapes(prec_of(sn), ptr(sn), 1 if negate else 0, ptr(labels), self.H, self.W, numObjects,
+                                        ptr(shapes), stream_ptr()), "nf_object_shapes")
+        return shapes[:(numObjects + 1) * 10].reshape(numObjects + 1, 10)
+
     def ring_flags(self, ringLabels, ringStats, numRing, minRingPix=30):
         t = self.t
         isRing = t.empty(numRing + 1, dtype=t.uint8, device=self.dev)

@@ -381,17 +381,30 @@ class MatchedFilter(MapFilter):
                 # loop over the maps raises this for every method but 'dataMap' and 'model' (:539-561; pinned by
                 # tests/golden/matched_filter.npz 'maxDataMapCMB_raises')
                 raise Exception("'%s' is not a valid filter noise method name - fix the .yml config file" % (method))
-            if self.params.get('noiseModelCatalog', None) is not None:
-                raise NotImplementedError("noiseModelCatalog needs maps.makeModelImage (scope table row f1)")
-            if shared is not None and ('noiseCov', method) in shared:
-                noiseCov = shared[('noiseCov', method)]
+            noiseCats = self.params.get('noiseModelCatalog', None)
+            covKey = ('noiseCov', method, None if noiseCats is None else id(noiseCats))
+            if shared is not None and covKey in shared:
+                noiseCov = shared[covKey]
             else:
                 fMapsForNoise = fMapsToFilter                                     # identical to :548 without a catalog
+                if noiseCats is not None:                                         # :540-547
+                    assert(type(noiseCats) == list)
+                    planes = []
+                    for i, mapDict in enumerate(self.unfilteredMapsDictList):
+                        d = self._dData[i]
+                        for noiseModelCatalog in noiseCats:
+                            model = maps.makeModelImage(self.shape, self.wcs, noiseModelCatalog, mapDict['beamFileName'],
+                                                        obsFreqGHz=mapDict['obsFreqGHz'])
+                            if model is not None:
+                                d = d - model
+                        planes.append(d)
+                    fMapsForNoise = eng.fft(t.stack(planes).contiguous(), apod=True, half=True)
+                    del planes
                 NP = eng.cross_power(fMapsForNoise, half=True)                            # :573  K4
                 noiseCov = eng.gaussian_filter(NP, (3, 3))                        # :580  K5
-                del NP
+                del NP, fMapsForNoise
                 if shared is not None:
-                    shared[('noiseCov', method)] = noiseCov
+                    shared[covKey] = noiseCov
 
             w = self._frequencyWeights()                                          # :587-608
             y0 = 2e-4

@@ -129,8 +129,6 @@ def findObjects(filteredMapDict, threshold=3.0, minObjPix=3, rejectBorder=10, fi
     fetched in ONE transfer.  ``_prefetch`` (used by pipelines._detectAndMeasure): a list of (mapData, negate) whose
     values at the objects' sky positions :func:`measureFluxes` / :func:`getSNRValues` will ask for next - they join the
     same transfer and wait on the returned table, so that those calls do not go back to the device."""
-    if measureShapes:
-        raise NotImplementedError("measureShapes (nemo/photometry.py:133-184) is not part of this build yet")
     if threshold < 0:
         raise Exception("Detection threshold (thresholdSigma in the config file) cannot be negative unless in forced photometry mode.")
     wcs = filteredMapDict['wcs']
@@ -182,6 +180,9 @@ def findObjects(filteredMapDict, threshold=3.0, minObjPix=3, rejectBorder=10, fi
     flagsOnDevice = hasattr(flagMask, 'is_cuda')
     if flagsOnDevice:
         queued.append(('flags', _lookupDev(flagMask, iyr, ixr)))
+    if measureShapes == True:                                                     # :133-150 (the sums; the ellipse below)
+        shapes = eng.object_shapes(dSN, labels, numObjects, negate=invertMap)
+        queued.append(('shapes', shapes[t.as_tensor(sel, device=dSN.device)]))
 
     RADeg, decDeg = wcs.pix2wcs(xs, ys)                                           # :115-117
     RADeg = np.where(RADeg < 0, 360.0 + RADeg, RADeg)
@@ -225,6 +226,10 @@ def findObjects(filteredMapDict, threshold=3.0, minObjPix=3, rejectBorder=10, fi
     tab['galacticLatDeg'] = galacticLatDeg(tab['RADeg'], tab['decDeg'])
     tab['x'] = xs[keep]
     tab['y'] = ys[keep]
+    if measureShapes == True:
+        ell = _ellipses(got['shapes'].reshape(-1, 10)[keep], np.asarray(tab['numSigPix']), single=dSN.dtype == t.float32)
+        for k in _ELLIPSE_KEYS:
+            tab[k] = ell[k]
 
     # Ring flags only stand near a high S/N object (:196-204); then flags += ringFlag (:208)
     if tab['ringFlag'].any():
@@ -245,6 +250,37 @@ def findObjects(filteredMapDict, threshold=3.0, minObjPix=3, rejectBorder=10, fi
                 vals[inside] = got['pre%d' % k]
             tab._prefetched[(id(mapLike), bool(neg))] = (vals[keep], inside[keep], len(tab))
     return tab
+
+
+_ELLIPSE_KEYS = ('ellipse_PA', 'ellipse_A', 'ellipse_B', 'ellipse_x0', 'ellipse_y0', 'ellipse_e')
+
+
+def _ellipses(sh, numSigPix, single=False):
+    """SExtractor-style ellipses from the segment moments (nemo/photometry.py:135-184), all objects at once.  ``sh`` [n, 10] =
+    {xMin, yMin, xMax, yMax, S, Sx, Sy, Sxx, Syy, Sxy}.  ``single``: the S/N map is float32 - the reference's ``data[mask].sum()``
+    is then a float32 number, and so is the divisor here."""
+    n = len(sh)
+    out = {k: np.full(n, -99.0) for k in _ELLIPSE_KEYS}
+    if n == 0:
+        return out
+    S = sh[:, 4].astype(np.float32).astype(np.float64) if single else sh[:, 4]
+    with np.errstate(divide='ignore', invalid='ignore'):
+        cx2, cy2 = sh[:, 5] / S, sh[:, 6] / S                                     # :145-146
+        x2 = sh[:, 7] / S - cx2 ** 2                                              # :148-150
+        y2 = sh[:, 8] / S - cy2 ** 2
+        xy = sh[:, 9] / S - cx2 * cy2
+        theta = np.degrees(np.arctan(2 * (xy / (x2 - y2))) / 2.0)                 # :152-156
+        theta = np.where((xy > 0) & (theta < 0), theta + 90, np.where((xy < 0) & (theta > 0), theta - 90, theta))
+        ok = (numSigPix > 9) & (((theta > 0) & (xy > 0)) | ((theta < 0) & (xy < 0)))        # :135,157-160
+        root = np.sqrt(((x2 - y2) / 2) ** 2 + xy ** 2)
+        A = np.sqrt((x2 + y2) / 2.0 + root)                                       # :162-163
+        B = np.sqrt((x2 + y2) / 2.0 - root)
+        scaleFactor = np.sqrt(numSigPix / (A * B * np.pi))                        # :166-170 (segment area = its pixel count)
+        A, B = A * scaleFactor, B * scaleFactor
+        ecc = np.sqrt(1 - B ** 2 / A ** 2)
+    for k, v in zip(_ELLIPSE_KEYS, (theta, A, B, cx2 + sh[:, 0], cy2 + sh[:, 1], ecc)):
+        out[k][ok] = v[ok]
+    return out
 
 
 def _valuesAt(catalog, mapData, wcs, useInterpolator, negate=False, allRows=False):

@@ -42,9 +42,53 @@ def ring_mask(data, ringThresholdSigma, minRingPix=30):
     return np.array(np.less(ringSegMap, 0), dtype=int)
 
 
+_NO_SHAPE = {'ellipse_PA': -99, 'ellipse_A': -99, 'ellipse_B': -99, 'ellipse_x0': -99, 'ellipse_y0': -99, 'ellipse_e': -99}
+
+
+def measure_shape(data, segMap, objID, numSigPix):
+    """SExtractor-style moments of one segment (nemo/photometry.py:133-184), statement for statement (``data[mask].sum()`` keeps
+    the map's dtype, as it does there)."""
+    doubleCheck = False
+    out = {}
+    if numSigPix > 9:
+        mask = np.equal(segMap, objID)
+        ys, xs = np.where(segMap == objID)
+        yMin, xMin = ys.min(), xs.min()
+        xs = xs - xMin
+        ys = ys - yMin
+        cx2 = (xs * data[mask]).sum() / data[mask].sum()
+        cy2 = (ys * data[mask]).sum() / data[mask].sum()
+        x2 = (((xs ** 2) * data[mask]).sum() / data[mask].sum()) - cx2 ** 2
+        y2 = (((ys ** 2) * data[mask]).sum() / data[mask].sum()) - cy2 ** 2
+        xy = (((xs * ys) * data[mask]).sum() / data[mask].sum()) - cx2 * cy2
+        theta = np.degrees(np.arctan(2 * (xy / (x2 - y2))) / 2.0)
+        if xy > 0 and theta < 0:
+            theta = theta + 90
+        elif xy < 0 and theta > 0:
+            theta = theta - 90
+        if theta > 0 and xy > 0:
+            doubleCheck = True
+        if theta < 0 and xy < 0:
+            doubleCheck = True
+        if doubleCheck == True:
+            A = np.sqrt((x2 + y2) / 2.0 + np.sqrt(((x2 - y2) / 2) ** 2 + xy ** 2))
+            B = np.sqrt((x2 + y2) / 2.0 - np.sqrt(((x2 - y2) / 2) ** 2 + xy ** 2))
+            segArea = float(np.count_nonzero(np.equal(segMap, objID)))
+            curArea = A * B * np.pi
+            scaleFactor = np.sqrt(segArea / curArea)
+            A = A * scaleFactor
+            B = B * scaleFactor
+            ecc = np.sqrt(1 - B ** 2 / A ** 2)
+            out = {'ellipse_PA': theta, 'ellipse_A': A, 'ellipse_B': B, 'ellipse_x0': cx2 + xMin, 'ellipse_y0': cy2 + yMin,
+                   'ellipse_e': ecc}
+    if numSigPix <= 9 or doubleCheck == False:
+        out = dict(_NO_SHAPE)
+    return out
+
+
 def find_objects(SNMap, flagMask, pix2wcs, threshold=3.0, minObjPix=3, findCenterOfMass=True, flagRings=True,
                  ringThresholdSigma=0, ringFlagDistArcmin=12.0, ringFlagMinRingerSNR=20, invertMap=False,
-                 useInterpolator=True, angSepDeg=None):
+                 useInterpolator=True, angSepDeg=None, measureShapes=False):
     """photometry.findObjects (nemo/photometry.py:25-210) up to the catalog rows (list of dicts with keys
     id, x, y, RADeg, decDeg, numSigPix, SNR, flags, ringFlag).  Returns [] when nothing is significant."""
     data = SNMap
@@ -74,6 +118,9 @@ def find_objects(SNMap, flagMask, pix2wcs, threshold=3.0, minObjPix=3, findCente
             else:
                 obj['SNR'] = data[int(round(obj['y'])), int(round(obj['x']))]
             obj['flags'] = flagMask[int(round(obj['y'])), int(round(obj['x']))]
+            if measureShapes == True:                                             # :133-184
+                with np.errstate(divide='ignore', invalid='ignore'):
+                    obj.update(measure_shape(data, segMap, objIDs[i], obj['numSigPix']))
             if obj['SNR'] > threshold:                                            # :186
                 catalog.append(obj)
             idNumCount = idNumCount + 1                                           # :188

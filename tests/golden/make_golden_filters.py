@@ -423,12 +423,78 @@ def run_fluxes():
     np.savez_compressed(os.path.join(HERE, 'measure_fluxes.npz'), **out)
 
 
+def shapes_map(shape, seed, dtype):
+    """S/N-like map: unit correlated noise, elliptical sources of many sizes and position angles, one very bright source with
+    a faint ring around it, and a few negative sources (for the inverted run)."""
+    rng = np.random.default_rng(seed)
+    m = MG.correlated_map(shape, seed, sigmaPix=1.2)
+    yy, xx = np.mgrid[0:shape[0], 0:shape[1]].astype(np.float64)
+    n = 26
+    for k in range(n):
+        x0, y0 = rng.uniform(12, shape[1] - 12), rng.uniform(12, shape[0] - 12)
+        sa, sb = rng.uniform(1.0, 6.0), rng.uniform(0.8, 2.5)
+        pa = rng.uniform(0, np.pi)
+        amp = rng.choice([9.0, 14.0, 30.0, 80.0]) * (-1.0 if k % 6 == 5 else 1.0)
+        u = (xx - x0) * np.cos(pa) + (yy - y0) * np.sin(pa)
+        v = -(xx - x0) * np.sin(pa) + (yy - y0) * np.cos(pa)
+        m = m + amp * np.exp(-0.5 * ((u / sa) ** 2 + (v / sb) ** 2))
+    bx, by = shape[1] * 0.31, shape[0] * 0.62
+    r = np.sqrt((xx - bx) ** 2 + (yy - by) ** 2)
+    m = m + 300.0 * np.exp(-0.5 * (r / 1.6) ** 2) + 6.5 * np.exp(-0.5 * ((r - 11.0) / 1.3) ** 2)
+    return m.astype(dtype)
+
+
+def run_find_objects():
+    """photometry.findObjects (nemo/photometry.py:25-210) as it is, measureShapes and ring flags included.  Stand-ins: the
+    astropy Table made by catalogs.catalogListToTab (-> the product's plain column table, all keys kept), astCoords
+    (galactic latitude and separations from the product's host code: astLib is absent, unpinned)."""
+    from nemo import photometry
+    from nemo_amd import catalogs as pcatalogs, photometry as pphot
+
+    def listToTab(catalogList, keysToWrite=None, minStrLength=30):
+        return pcatalogs.Table(cols={k: [o[k] for o in catalogList] for k in catalogList[0].keys()})
+
+    photometry.catalogs.catalogListToTab = listToTab
+    photometry.astCoords = types.SimpleNamespace(
+        convertCoords=lambda a, b, ra, dec, epoch: (0.0, float(np.atleast_1d(pphot.galacticLatDeg(np.array([ra]), np.array([dec])))[0])),
+        calcAngSepDeg=calcAngSepDeg)
+    shape = (200, 240)
+    wcs = CARWCS.make(shape, RADeg=12.0, decDeg=2.0)
+    cases = [dict(dtype='float32', threshold=5.0, minObjPix=1, findCenterOfMass=True, flagRings=True, invertMap=False, useInterpolator=True),
+             dict(dtype='float64', threshold=4.0, minObjPix=1, findCenterOfMass=False, flagRings=False, invertMap=False, useInterpolator=True),
+             dict(dtype='float32', threshold=5.0, minObjPix=3, findCenterOfMass=True, flagRings=True, invertMap=True, useInterpolator=False),
+             dict(dtype='float32', threshold=50.0, minObjPix=3, findCenterOfMass=True, flagRings=True, invertMap=False, useInterpolator=True)]
+    out = {'header': np.array(header_json(wcs)), 'ncases': np.int64(len(cases))}
+    for k, c in enumerate(cases):
+        sn = shapes_map(shape, 900 + k, np.dtype(c['dtype']))
+        flagMask = (np.random.default_rng(950 + k).uniform(size=shape) > 0.97).astype(np.uint8) * 2
+        fmd = {'SNMap': sn, 'surveyMask': np.ones(shape, dtype=np.uint8), 'wcs': wcs, 'flagMask': flagMask, 'label': 'golden', 'tileName': 'PRIMARY'}
+        kw = {kk: v for kk, v in c.items() if kk != 'dtype'}
+        with np.errstate(divide='ignore', invalid='ignore'):
+            tab = photometry.findObjects(fmd, rejectBorder=0, measureShapes=True, objIdent='ACT-S', **kw)
+        p = 'c%d_' % k
+        out[p + 'meta'] = np.array(json.dumps(c))
+        out[p + 'SNMap'], out[p + 'flagMask'] = sn, flagMask
+        cols = [kk for kk in tab.keys() if kk not in ('template', 'tileName')]
+        out[p + 'cols'] = np.array(json.dumps(cols))
+        for kk in cols:
+            out[p + 'col_' + kk] = np.asarray(tab[kk])
+        shaped = int((np.asarray(tab['ellipse_A']) > 0).sum())
+        print("findObjects case %d: %d rows, %d with shapes, %d ring-flagged" % (k, len(tab), shaped, int(np.asarray(tab['ringFlag']).sum())))
+    np.savez_compressed(os.path.join(HERE, 'find_objects.npz'), **out)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == 'find_objects':
+        install_reference()
+        run_find_objects()
+        return
     filters, maps, signals = install_reference()
     with tempfile.TemporaryDirectory() as tmpDir:
         run_matched(filters, tmpDir)
         run_realspace(filters, maps, tmpDir)
     run_fluxes()
+    run_find_objects()
     print("golden vectors written to", HERE)
 
 

@@ -155,3 +155,36 @@ def test_noise_method_max_datamap_cmb_raises_as_the_reference_does():
     with pytest.raises(Exception) as e:
         helpers.oracle_matched(mapsL, wcs, params, meta['kind'])
     assert str(e.value) == message
+
+
+def _find_objects_cases():
+    import json
+    from nemo_amd.wcs import CARWCS
+    g = np.load(os.path.join(GOLDEN, 'find_objects.npz'))
+    hdr = json.loads(str(g['header']))
+    for key in ('NAXIS', 'NAXIS1', 'NAXIS2'):
+        hdr[key] = int(hdr[key])
+    wcs = CARWCS(hdr)
+    for k in range(int(g['ncases'])):
+        p = 'c%d_' % k
+        meta = json.loads(str(g[p + 'meta']))
+        cols = {c: g[p + 'col_' + c] for c in json.loads(str(g[p + 'cols']))}
+        yield k, meta, wcs, g[p + 'SNMap'], g[p + 'flagMask'], cols
+
+
+def test_oracle_find_objects_equals_reference_code():
+    """photometry.findObjects (nemo/photometry.py:25-210) run as it is (tests/golden/make_golden_filters.py, measureShapes on,
+    ring flags, inverted map) against the oracle's restatement: every numeric column bit for bit."""
+    from nemo_amd.wcs import calcAngSepDeg
+    from nemo_oracle import photometry as ophot
+    seen = 0
+    for k, meta, wcs, sn, flagMask, cols in _find_objects_cases():
+        kw = {kk: v for kk, v in meta.items() if kk != 'dtype'}
+        rows = ophot.find_objects(sn, flagMask, wcs.pix2wcs, angSepDeg=calcAngSepDeg, measureShapes=True, **kw)
+        assert len(rows) == len(cols['SNR']) and len(rows) > 0
+        for c in ('id', 'x', 'y', 'RADeg', 'decDeg', 'SNR', 'numSigPix', 'flags', 'ringFlag', 'ellipse_PA', 'ellipse_A', 'ellipse_B',
+                  'ellipse_x0', 'ellipse_y0', 'ellipse_e'):
+            got = np.array([r[c] for r in rows])
+            assert np.array_equal(got.astype(cols[c].dtype), cols[c], equal_nan=cols[c].dtype.kind == 'f'), (k, c)
+        seen += int((cols['ellipse_A'] > 0).sum())
+    assert seen > 40

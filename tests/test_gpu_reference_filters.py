@@ -158,3 +158,36 @@ def test_noise_method_max_datamap_cmb_raises_as_the_reference_does():
         filters.filterMaps(helpers.product_maps(mapsL), {'label': 'x', 'class': meta['class'], 'params': params}, 'PRIMARY',
                            diagnosticsDir=None, selFnDir=None, verbose=False)
     assert str(e.value) == message
+
+
+@pytest.mark.parametrize("k", range(4))
+def test_find_objects_vs_reference_code(k):
+    """photometry.findObjects as the reference runs it (fixture: tests/golden/find_objects.npz; measureShapes, ring flags, an
+    inverted map, peak positions).  Counts, flags, names: equal.  Positions 1e-9 px (exact integer sums against scipy's float64
+    running sums), S/N 1e-9 (spline), ellipses 1e-5 where the S/N map is float32 - the reference divides by a float32 pairwise
+    sum there (``data[mask].sum()``), which the build rounds once from its exact sum: most rows come out equal, a last-place
+    difference of that divisor moves a second moment by a few 1e-6 - and 1e-9 for float64 maps."""
+    from test_cpu_reference_filters import _find_objects_cases
+    from nemo_amd import photometry
+    kk, meta, wcs, sn, flagMask, cols = list(_find_objects_cases())[k]
+    kw = {a: v for a, v in meta.items() if a != 'dtype'}
+    fmd = {'SNMap': sn, 'surveyMask': np.ones(sn.shape, dtype=np.uint8), 'wcs': wcs, 'flagMask': flagMask, 'label': 'golden',
+           'tileName': 'PRIMARY'}
+    tab = photometry.findObjects(fmd, rejectBorder=0, measureShapes=True, objIdent='ACT-S', **kw)
+    assert len(tab) == len(cols['SNR'])
+    for c in ('numSigPix', 'flags', 'ringFlag'):
+        assert np.array_equal(np.asarray(tab[c]).astype(cols[c].dtype), cols[c]), c
+    assert list(np.asarray(tab['name'])) == list(cols['name'])
+    for c in ('x', 'y'):
+        assert np.abs(np.asarray(tab[c]) - cols[c]).max() < 1e-9
+    for c in ('RADeg', 'decDeg'):
+        assert np.abs(np.asarray(tab[c]) - cols[c]).max() < 1e-11
+    assert np.abs(np.asarray(tab['SNR']) / cols['SNR'] - 1).max() < 1e-9
+    tol = 1e-5 if sn.dtype == np.float32 else 1e-9
+    shaped = cols['ellipse_A'] > 0
+    assert shaped.sum() >= 4
+    for c in ('ellipse_PA', 'ellipse_A', 'ellipse_B', 'ellipse_x0', 'ellipse_y0', 'ellipse_e'):
+        got = np.asarray(tab[c])
+        assert np.array_equal(got[~shaped], cols[c][~shaped]), c                 # -99 rows: the same rows
+        scale = 90.0 if c == 'ellipse_PA' else np.abs(cols[c][shaped])
+        assert (np.abs(got[shaped] - cols[c][shaped]) / scale).max() < tol, c

@@ -158,10 +158,17 @@ def vstack(tables):
     else:
         for t in tables:
             t._materialiseNames()
-    for k in tables[0].keys():
+    # columns: the union, in order of first appearance (astropy's outer join masks what a table lacks; here -99, the
+    # catalogue's own "no value", or the empty string)
+    keys = []
+    for t in tables:
+        keys += [k for k in t.keys() if k not in keys]
+    for k in keys:
         if k == 'name' and out._nameSpec is not None:
             continue
-        out._cols[k] = np.concatenate([t[k] if k in t.keys() else np.full(len(t), -99) for t in tables])
+        have = [t[k] for t in tables if k in t.keys()]
+        fill = '' if have[0].dtype.kind in 'US' else -99
+        out._cols[k] = np.concatenate([t[k] if k in t.keys() else np.full(len(t), fill) for t in tables])
     return out
 
 

@@ -265,6 +265,8 @@ def degreesDistanceBox(shape, wcs, RADeg, decDeg, maxDistDegrees):
     Y, X = shape
     minX, maxX = max(int(round(x0)) - xDistPix, 0), min(int(round(x0)) + xDistPix, X)
     minY, maxY = max(int(round(y0)) - yDistPix, 0), min(int(round(y0)) + yDistPix, Y)
+    # a negative radius (ellipse_A = -99 rows of a shapes catalogue) gives an empty range there and an empty box here
+    minX, minY = min(minX, X), min(minY, Y)
     maxX, maxY = max(maxX, minX), max(maxY, minY)
     return [float(x0), float(y0), float(xPixScale), float(yPixScale)], [minX, maxX, minY, maxY]
 

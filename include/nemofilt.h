@@ -309,6 +309,16 @@ int nf_ring_flags(const int* ringLabels_d, const double* ringStats_d, int numRin
 int nf_spline_eval(int vtype, const void* map_d, int negate, int H, int W, const double* yx_d, int nPts, int halfWin,
                    int pointsClass, const int* edgeSel_d, int nEdge, double* out_d, void* stream);
 
+/* nf_spline_eval for several (map, point list) jobs at once - what one detection pass reads off its maps at the object
+ * positions (nemo/photometry.py:128 on the S/N map; :276-281 and :354-361 on the filtered map and on the reference scale's two
+ * maps, called from nemo/pipelines.py:299-311): one launch per kernel instead of one per map.  All maps have dtype `vtype`
+ * and shape [H, W].  Host arrays of nJobs (<= 8) entries: maps_d, negate, yx_d (nPts[j] pairs each), out_d (nPts[j] doubles
+ * each), edgeSel_d / nEdge (indices of job j's points whose window meets the map border; edgeSel_d[j] NULL: unknown, every
+ * point is offered to both kernels). */
+int nf_spline_eval_batch(int vtype, int nJobs, const void* const* maps_d, const int* negate, const double* const* yx_d,
+                         const int* nPts, const int* const* edgeSel_d, const int* nEdge, double* const* out_d, int H, int W,
+                         int halfWin, void* stream);
+
 /* Instrumentation (no counterpart in the reference; used by bench.py): when enabled, every entry point above brackets
  * the work it enqueues with a HIP event pair on the caller's stream.  nf_profile_enable(on) switches recording and
  * clears earlier records; nf_profile_read synchronises the recorded events of one tag and returns the number of calls,

@@ -677,4 +677,32 @@ int nf_spline_eval(int vtype, const void* map, int negate, int H, int W, const d
     return nf::spline_eval(vtype, map, negate, H, W, yx, nPts, halfWin, pointsClass, edgeSel, nEdge, out, S(stream));
 }
 
+int nf_spline_eval_batch(int vtype, int nJobs, const void* const* maps, const int* negate, const double* const* yx, const int* nPts,
+                         const int* const* edgeSel, const int* nEdge, double* const* out, int H, int W, int halfWin, void* stream) {
+    if (nJobs < 0 || nJobs > NF_SPL_MAXJOBS || !maps || !negate || !yx || !nPts || !edgeSel || !nEdge || !out || H < 4 || W < 4 ||
+        (vtype != NF_F32 && vtype != NF_F64)) {
+        nf_set_error("nf_spline_eval_batch: bad arguments (at most 8 jobs)");
+        return NF_ERR_ARG;
+    }
+    nf::SplineBatch b;
+    for (int j = 0; j < NF_SPL_MAXJOBS; ++j) {
+        const bool live = j < nJobs;
+        if (live && nPts[j] > 0 && (!maps[j] || !yx[j] || !out[j] || nEdge[j] < 0 || nEdge[j] > nPts[j])) {
+            nf_set_error("nf_spline_eval_batch: bad job");
+            return NF_ERR_ARG;
+        }
+        b.map[j] = live ? maps[j] : nullptr;
+        b.yx[j] = live ? yx[j] : nullptr;
+        b.edge[j] = live ? edgeSel[j] : nullptr;
+        b.out[j] = live ? out[j] : nullptr;
+        b.n[j] = live ? nPts[j] : 0;
+        b.nEdge[j] = live ? (edgeSel[j] ? nEdge[j] : nPts[j]) : 0;
+        b.negate[j] = live ? negate[j] : 0;
+    }
+    double bytes = 0.0;
+    for (int j = 0; j < nJobs; ++j) bytes += (double)nPts[j] * (2 * halfWin + 4) * (2 * halfWin + 4) * (vtype == NF_F32 ? 4.0 : 8.0);
+    nf::ProfScope ps(nf::PT_SPLINE, S(stream), bytes);
+    return nf::spline_eval_batch(vtype, b, nJobs, H, W, halfWin, S(stream));
+}
+
 }  // extern "C"

@@ -763,13 +763,11 @@ __global__ void __launch_bounds__(128) k_spline_eval_interior(const VT* __restri
     spline_eval_interior<VT>(map, negate, W, py, px, iy, ix, halfWin, lds, out + blockIdx.x);
 }
 
+// one point by the windowed solve (points whose window meets the map's border); shared memory as k_spline_eval lays it out
 template <typename VT>
-__global__ void k_spline_eval(const VT* __restrict__ map, int negate, int H, int W, const double* __restrict__ yx, int halfWin,
-                              const int* __restrict__ sel, double* __restrict__ out) {
-    extern __shared__ __align__(16) unsigned char nf_smem[];
-    double* win = (double*)nf_smem;                         // [ny][nxp]
-    const int pt = sel ? sel[blockIdx.x] : (int)blockIdx.x; // `sel`: the points this kernel serves (the others are interior)
-    const double py = yx[2 * pt], px = yx[2 * pt + 1];
+__device__ __forceinline__ void spline_eval_windowed(const VT* __restrict__ map, int negate, int H, int W, double py, double px,
+                                                     int halfWin, unsigned char* smem, double* __restrict__ outp) {
+    double* win = (double*)smem;                            // [ny][nxp]
     int iy = (int)floor(py), ix = (int)floor(px);
     int y0 = max(0, iy - halfWin), y1 = min(H - 1, iy + 1 + halfWin);
     int x0 = max(0, ix - halfWin), x1 = min(W - 1, ix + 1 + halfWin);
@@ -778,10 +776,10 @@ __global__ void k_spline_eval(const VT* __restrict__ map, int negate, int H, int
     double* colv = win + NF_SPL_MAXN * (NF_SPL_MAXN + 1);    // [ny]
     double* rw = colv + NF_SPL_MAXN;                         // [NF_SPL_MAXN] rho^k
     if (!(py >= 0.0 && py <= (double)(H - 1) && px >= 0.0 && px <= (double)(W - 1)) || ny < 4 || nx < 4) {
-        if (threadIdx.x == 0) out[pt] = nan("");
+        if (threadIdx.x == 0) *outp = nan("");
         return;
     }
-    if (spline_interior(iy, ix, H, W, halfWin)) return;      // k_spline_eval_interior wrote this point
+    if (spline_interior(iy, ix, H, W, halfWin)) return;      // the interior kernel wrote this point
 #pragma unroll 8
     for (int i = threadIdx.x; i < ny * nx; i += blockDim.x) {
         int r = i / nx, c = i % nx;
@@ -792,7 +790,38 @@ __global__ void k_spline_eval(const VT* __restrict__ map, int negate, int H, int
     __syncthreads();
     for (int r = threadIdx.x; r < ny; r += blockDim.x) colv[r] = nak_spline_eval(win + r * nxp, nx, px - (double)x0, rw);
     __syncthreads();
-    if (threadIdx.x == 0) out[pt] = nak_spline_eval(colv, ny, py - (double)y0, rw);
+    if (threadIdx.x == 0) *outp = nak_spline_eval(colv, ny, py - (double)y0, rw);
+}
+
+template <typename VT>
+__global__ void k_spline_eval(const VT* __restrict__ map, int negate, int H, int W, const double* __restrict__ yx, int halfWin,
+                              const int* __restrict__ sel, double* __restrict__ out) {
+    extern __shared__ __align__(16) unsigned char nf_smem[];
+    const int pt = sel ? sel[blockIdx.x] : (int)blockIdx.x; // `sel`: the points this kernel serves (the others are interior)
+    spline_eval_windowed<VT>(map, negate, H, W, yx[2 * pt], yx[2 * pt + 1], halfWin, nf_smem, out + pt);
+}
+
+// Several (map, point list) jobs in one launch: blockIdx.y is the job.  What a detection pass reads off its maps at the object
+// positions - S/N, the filtered map, the reference scale's two maps - is one launch of each kernel instead of one per map.
+template <typename VT>
+__global__ void __launch_bounds__(128) k_spline_batch_interior(SplineBatch b, int H, int W, int halfWin) {
+    __shared__ double lds[3 * NF_SPL_MAXN + 2];
+    const int j = blockIdx.y, pt = blockIdx.x;
+    if (pt >= b.n[j]) return;
+    const double py = b.yx[j][2 * pt], px = b.yx[j][2 * pt + 1];
+    if (!(py >= 0.0 && py <= (double)(H - 1) && px >= 0.0 && px <= (double)(W - 1))) return;
+    const int iy = (int)floor(py), ix = (int)floor(px);
+    if (!spline_interior(iy, ix, H, W, halfWin)) return;
+    spline_eval_interior<VT>((const VT*)b.map[j], b.negate[j], W, py, px, iy, ix, halfWin, lds, b.out[j] + pt);
+}
+
+template <typename VT>
+__global__ void k_spline_batch_windowed(SplineBatch b, int H, int W, int halfWin) {
+    extern __shared__ __align__(16) unsigned char nf_smem[];
+    const int j = blockIdx.y;
+    if ((int)blockIdx.x >= b.nEdge[j]) return;
+    const int pt = b.edge[j] ? b.edge[j][blockIdx.x] : (int)blockIdx.x;
+    spline_eval_windowed<VT>((const VT*)b.map[j], b.negate[j], H, W, b.yx[j][2 * pt], b.yx[j][2 * pt + 1], halfWin, nf_smem, b.out[j] + pt);
 }
 
 int spline_eval(int vtype, const void* map, int negate, int H, int W, const double* yx, int nPts, int halfWin, int pointsClass,
@@ -826,6 +855,46 @@ int spline_eval(int vtype, const void* map, int negate, int H, int W, const doub
                                halfWin, edgeSel, out);
     }
     NF_CHECK_LAUNCH("k_spline_eval");
+    return NF_OK;
+}
+
+int spline_eval_batch(int vtype, const SplineBatch& b, int nJobs, int H, int W, int halfWin, hipStream_t s) {
+    if (nJobs <= 0) return NF_OK;
+    if (2 * halfWin + 2 > NF_SPL_MAXN) {
+        nf_set_error("spline_eval_batch: window too large");
+        return NF_ERR_ARG;
+    }
+    int maxPts = 0, maxEdge = 0;
+    bool anyInterior = false;
+    for (int j = 0; j < nJobs; ++j) {
+        maxPts = b.n[j] > maxPts ? b.n[j] : maxPts;
+        maxEdge = b.nEdge[j] > maxEdge ? b.nEdge[j] : maxEdge;
+        if (b.edge[j] == nullptr || b.nEdge[j] < b.n[j]) anyInterior = true;
+    }
+    if (maxPts <= 0) return NF_OK;
+    const size_t lds = (size_t)(NF_SPL_MAXN * (NF_SPL_MAXN + 1) + 2 * NF_SPL_MAXN) * sizeof(double);
+    static bool attr[2] = {false, false};
+    const int a = vtype == NF_F64 ? 1 : 0;
+    if (!attr[a]) {
+        if (a)
+            NF_HIP(hipFuncSetAttribute((const void*)k_spline_batch_windowed<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        else
+            NF_HIP(hipFuncSetAttribute((const void*)k_spline_batch_windowed<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr[a] = true;
+    }
+    if (anyInterior) {
+        if (a)
+            hipLaunchKernelGGL(k_spline_batch_interior<double>, dim3(maxPts, nJobs), dim3(128), 0, s, b, H, W, halfWin);
+        else
+            hipLaunchKernelGGL(k_spline_batch_interior<float>, dim3(maxPts, nJobs), dim3(128), 0, s, b, H, W, halfWin);
+    }
+    if (maxEdge > 0) {
+        if (a)
+            hipLaunchKernelGGL(k_spline_batch_windowed<double>, dim3(maxEdge, nJobs), dim3(128), lds, s, b, H, W, halfWin);
+        else
+            hipLaunchKernelGGL(k_spline_batch_windowed<float>, dim3(maxEdge, nJobs), dim3(128), lds, s, b, H, W, halfWin);
+    }
+    NF_CHECK_LAUNCH("k_spline_batch");
     return NF_OK;
 }
 

@@ -86,4 +86,15 @@ int ring_flags(const int* ringLabels, const double* ringStats, int numRing, int 
 int spline_eval(int vtype, const void* map, int negate, int H, int W, const double* yx, int nPts, int halfWin, int pointsClass, const int* edgeSel, int nEdge,
                 double* out, hipStream_t s);
 
+// jobs of one batched spline evaluation (kernel argument, by value)
+#define NF_SPL_MAXJOBS 8
+struct SplineBatch {
+    const void* map[NF_SPL_MAXJOBS];      // the maps, all of one dtype
+    const double* yx[NF_SPL_MAXJOBS];     // (y, x) pairs
+    const int* edge[NF_SPL_MAXJOBS];      // indices of the points whose window meets the border (nullptr: try every point)
+    double* out[NF_SPL_MAXJOBS];
+    int n[NF_SPL_MAXJOBS], nEdge[NF_SPL_MAXJOBS], negate[NF_SPL_MAXJOBS];
+};
+int spline_eval_batch(int vtype, const SplineBatch& b, int nJobs, int H, int W, int halfWin, hipStream_t s);
+
 }  // namespace nf

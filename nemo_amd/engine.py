@@ -152,10 +152,11 @@ _EDGE_SEL = os.environ.get('NEMO_AMD_SPLINE_EDGESEL', '0') != '0'    # measured:
 
 
 class _SplinePoints(object):
-    __slots__ = ('dev', 'n', 'pointsClass', 'halfWin')
+    """Evaluation points on the device: (y, x) pairs and the indices of the points whose window meets the map border."""
+    __slots__ = ('dev', 'n', 'pointsClass', 'halfWin', 'edge', 'nEdge')
 
-    def __init__(self, dev, n, pointsClass, halfWin):
-        self.dev, self.n, self.pointsClass, self.halfWin = dev, n, pointsClass, halfWin
+    def __init__(self, dev, n, pointsClass, halfWin, edge=None, nEdge=0):
+        self.dev, self.n, self.pointsClass, self.halfWin, self.edge, self.nEdge = dev, n, pointsClass, halfWin, edge, nEdge
 
 
 class DeviceScalar(object):
@@ -724,22 +725,65 @@ class TileEngine(object):
         return res[0], int(res[1])
 
     def spline_points(self, yx, halfWin=32):
-        """Evaluation points uploaded once, for several spline_eval calls at the same positions (different maps)."""
+        """Evaluation points uploaded once (one transfer: the pairs, then the indices of the border points), for several
+        spline evaluations at the same positions (different maps)."""
         yx = np.ascontiguousarray(np.asarray(yx, dtype=np.float64).reshape(-1, 2))
+        n = len(yx)
+        if n == 0:
+            return _SplinePoints(None, 0, 1, halfWin)
         iy, ix = np.floor(yx[:, 0]), np.floor(yx[:, 1])
         interior = (iy - halfWin - 1 >= 0) & (iy + halfWin + 2 <= self.H - 1) & (ix - halfWin - 1 >= 0) & \
             (ix + halfWin + 2 <= self.W - 1) & (yx[:, 0] >= 0) & (yx[:, 0] <= self.H - 1) & (yx[:, 1] >= 0) & (yx[:, 1] <= self.W - 1)
         pointsClass = 1 if interior.all() else (2 if not interior.any() else 0)
-        return _SplinePoints(to_dev(yx) if len(yx) > 0 else None, len(yx), pointsClass, halfWin)
+        edgeIdx = np.flatnonzero(~interior).astype(np.int32)
+        buf = np.empty(2 * n + (len(edgeIdx) + 1) // 2, dtype=np.float64)
+        buf[:2 * n] = yx.reshape(-1)
+        if len(edgeIdx) > 0:
+            buf[2 * n:].view(np.int32)[:len(edgeIdx)] = edgeIdx
+        dev = to_dev(buf)
+        edge = dev[2 * n:].view(self.t.int32) if len(edgeIdx) > 0 else None
+        return _SplinePoints(dev[:2 * n], n, pointsClass, halfWin, edge, len(edgeIdx))
+
+    def spline_eval_batch(self, jobs):
+        """[(map tensor, _SplinePoints, negate)] -> list of float64 device tensors, one launch per kernel for all jobs of a
+        dtype (nf_spline_eval_batch)."""
+        t = self.t
+        outs = [None] * len(jobs)
+        total = sum(pts.n for _, pts, _ in jobs)
+        flat = t.empty(max(total, 1), dtype=t.float64, device=self.dev)
+        pos = 0
+        groups = {}
+        for k, (m, pts, neg) in enumerate(jobs):
+            outs[k] = flat[pos:pos + pts.n]
+            pos += pts.n
+            if pts.n > 0:
+                groups.setdefault((prec_of(m), pts.halfWin), []).append(k)
+        VP, CI = ctypes.c_void_p, ctypes.c_int
+        for (prec, halfWin), ks in groups.items():
+            for c0 in range(0, len(ks), 8):
+                part = ks[c0:c0 + 8]
+                nj = len(part)
+                maps = (VP * nj)(*[jobs[k][0].data_ptr() for k in part])
+                negs = (CI * nj)(*[1 if jobs[k][2] else 0 for k in part])
+                yxs = (VP * nj)(*[jobs[k][1].dev.data_ptr() for k in part])
+                ns = (CI * nj)(*[jobs[k][1].n for k in part])
+                edges = (VP * nj)(*[(jobs[k][1].edge.data_ptr() if jobs[k][1].edge is not None else None) for k in part])
+                # (no border points: an empty list, not "unknown" - the pointer must still be non-null to say so)
+                for i, k in enumerate(part):
+                    if jobs[k][1].edge is None:
+                        edges[i] = jobs[k][1].dev.data_ptr()
+                nes = (CI * nj)(*[jobs[k][1].nEdge for k in part])
+                os_ = (VP * nj)(*[outs[k].data_ptr() for k in part])
+                check(self.lib.nf_spline_eval_batch(prec, nj, maps, negs, yxs, ns, edges, nes, os_, self.H, self.W, halfWin, stream_ptr()),
+                      "nf_spline_eval_batch")
+        return outs
 
     def spline_eval(self, m, yx, negate=False, halfWin=32, to_host=True):
         t = self.t
         if isinstance(yx, _SplinePoints):
             if yx.n == 0:
                 return np.zeros(0)
-            out = t.empty(yx.n, dtype=t.float64, device=self.dev)
-            check(self.lib.nf_spline_eval(prec_of(m), ptr(m), 1 if negate else 0, self.H, self.W, ptr(yx.dev), yx.n, yx.halfWin,
-                                          yx.pointsClass, None, 0, ptr(out), stream_ptr()), "nf_spline_eval")
+            out = self.spline_eval_batch([(m, yx, negate)])[0]
             return out.cpu().numpy() if to_host else out
         yx = np.ascontiguousarray(np.asarray(yx, dtype=np.float64).reshape(-1, 2))
         if len(yx) == 0:

@@ -168,8 +168,9 @@ def findObjects(filteredMapDict, threshold=3.0, minObjPix=3, rejectBorder=10, fi
     iyr, ixr = np.round(ys).astype(np.int64), np.round(xs).astype(np.int64)      # int(round()): half to even, as np.round
     t = engine.torch()
     queued = []        # device results wanted on the host: (key, 1-D tensor), fetched together below
+    splineJobs = []    # (key, map, points, negate): every spline read of this pass goes out as one batch
     if useInterpolator == True:                                                   # :81-84,128
-        queued.append(('SNR', eng.spline_eval(dSN, np.stack([ys, xs], axis=1), negate=invertMap, to_host=False)))
+        splineJobs.append(('SNR', dSN, eng.spline_points(np.stack([ys, xs], axis=1)), invertMap))
     else:
         queued.append(('SNR', _lookupDev(dSN, iyr, ixr) * (-1.0 if invertMap else 1.0)))
     if ringLabels is not None:                                                    # :112-114
@@ -188,22 +189,29 @@ def findObjects(filteredMapDict, threshold=3.0, minObjPix=3, rejectBorder=10, fi
     RADeg = np.where(RADeg < 0, 360.0 + RADeg, RADeg)
     pre = []
     if _prefetch:
-        # the positions measureFluxes will compute from the catalogue's coordinates (_splineAt)
+        # the positions measureFluxes / getSNRValues will compute from the catalogue's coordinates (_splineAt), every row:
+        # clamped to the map as FITPACK clamps them; ``inside`` is getSNRValues' bounds test (:277)
         x2, y2 = wcs.wcs2pix(np.asarray(RADeg, dtype=np.float64), np.asarray(decDeg, dtype=np.float64))
         x2, y2 = np.atleast_1d(x2), np.atleast_1d(y2)
         inside = (x2.astype(np.int64) > 0) & (x2.astype(np.int64) < W) & (y2.astype(np.int64) > 0) & (y2.astype(np.int64) < H)
-        if inside.any():
-            yy = np.clip(y2[inside], 0.0, H - 1.0)
-            xx = np.clip(x2[inside], 0.0, W - 1.0)
-            pts = eng.spline_points(np.stack([yy, xx], axis=1)) if useInterpolator else None     # one upload for all maps
-            for k, (mapLike, neg) in enumerate(_prefetch):
-                d = engine.to_dev(mapLike)
-                if useInterpolator:
-                    queued.append(('pre%d' % k, eng.spline_eval(d, pts, negate=neg, to_host=False)))
-                else:
-                    queued.append(('pre%d' % k, _lookupDev(d, np.clip(np.round(yy).astype(np.int64), 0, H - 1),
-                                                           np.clip(np.round(xx).astype(np.int64), 0, W - 1)) * (-1.0 if neg else 1.0)))
-        pre = [(mapLike, neg) for mapLike, neg in _prefetch]
+        yy = np.clip(y2, 0.0, H - 1.0)
+        xx = np.clip(x2, 0.0, W - 1.0)
+        pts = eng.spline_points(np.stack([yy, xx], axis=1)) if useInterpolator else None     # one upload for all maps
+        for k, (mapLike, neg) in enumerate(_prefetch):
+            d = engine.to_dev(mapLike)
+            if useInterpolator:
+                splineJobs.append(('pre%d' % k, d, pts, neg))
+            else:
+                iyn, ixn = np.round(y2).astype(np.int64), np.round(x2).astype(np.int64)
+                if ((iyn >= H) | (ixn >= W) | (iyn < -H) | (ixn < -W)).any():
+                    pre = None           # (measureFluxes raises for such a row, as numpy indexing does: let it find out)
+                    break
+                queued.append(('pre%d' % k, _lookupDev(d, iyn % H, ixn % W) * (-1.0 if neg else 1.0)))
+        if pre is not None:
+            pre = [(mapLike, neg) for mapLike, neg in _prefetch]
+    if splineJobs:
+        for (key, _, _, _), out in zip(splineJobs, eng.spline_eval_batch([(m, p, n) for _, m, p, n in splineJobs])):
+            queued.append((key, out))
     tm = _mark('positions + enqueue reads', tm)
     got = _fetchTogether(queued)
     tm = _mark('fetch reads', tm)
@@ -245,10 +253,8 @@ def findObjects(filteredMapDict, threshold=3.0, minObjPix=3, rejectBorder=10, fi
     if pre:
         tab._prefetched = {}
         for k, (mapLike, neg) in enumerate(pre):
-            vals = np.zeros(len(sel), dtype=np.float64)
-            if inside.any():
-                vals[inside] = got['pre%d' % k]
-            tab._prefetched[(id(mapLike), bool(neg))] = (vals[keep], inside[keep], len(tab))
+            if 'pre%d' % k in got:
+                tab._prefetched[(id(mapLike), bool(neg))] = (got['pre%d' % k][keep], inside[keep], len(tab))
     return tab
 
 
@@ -288,8 +294,11 @@ def _valuesAt(catalog, mapData, wcs, useInterpolator, negate=False, allRows=Fals
     pre = getattr(catalog, '_prefetched', None)
     if pre is not None:
         hit = pre.get((id(mapData), bool(negate)), None)
-        if hit is not None and hit[2] == len(catalog) and (not allRows or hit[1].all()):
-            return hit[0].copy(), hit[1]
+        if hit is not None and hit[2] == len(catalog):
+            vals = hit[0].copy()
+            if not allRows:
+                vals[~hit[1]] = 0.0
+            return vals, hit[1]
     return _splineAt(mapData, wcs, catalog['RADeg'], catalog['decDeg'], useInterpolator, negate=negate, allRows=allRows)
 
 

@@ -44,6 +44,18 @@ int nf_device_count(void);
 int nf_plan_create(int H, int W, nf_plan** plan);
 int nf_plan_destroy(nf_plan* plan);
 
+/* enmap.apply_window(m, pow) (pixell; called at nemo/filters.py:98-101 to undo the pixel window, nemo/maps.py:1849 to apply it)
+ * multiplies the 2-D spectrum of a real map by wy[ky] * wx[kx]; the two 1-D operators commute, and nf_axis_filter is one of
+ * them: y = IFFT(FFT(x) * w) along axis 0 (x, within rows) or 1 (y, within columns) of `batch` real [H, W] maps, in ONE pass
+ * over the map (two real lines share one complex transform; the spectrum stays in LDS).  wperm_d: n doubles with
+ * wperm[rev[k]] = w[k] / n, rev from nf_plan_digit_reversal (n = W for axis 0, H for axis 1); w must be real and even
+ * (w[k] == w[n-k]).  zeroRef_d (optional, a map of the output type): where it is zero the output is zero
+ * (nemo/filters.py:99-101).  in_d == out_d is allowed.  Lengths with a prime factor above 13 are refused (NF_ERR_SIZE,
+ * *bluestein = 1 from nf_plan_digit_reversal): use the 2-D transforms there. */
+int nf_plan_digit_reversal(nf_plan* plan, int prec, int axis, unsigned short* rev_host, int* bluestein);
+int nf_axis_filter(nf_plan* plan, int prec, int axis, const void* in_d, int inType, void* out_d, int outType, int batch,
+                   const double* wperm_d, const void* zeroRef_d, void* stream);
+
 /* enmap.fft (pixell), as used at nemo/filters.py:525,548,559,615,646,679,845: full complex 2-D DFT of
  * `batch` maps.  Input may be real (promoted) or complex.  If apodY_d/apodX_d are non-NULL the real input is
  * multiplied by the apodisation profiles first - enmap.apod, nemo/filters.py:525 - (axis 0 profile, then

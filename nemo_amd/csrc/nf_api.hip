@@ -164,8 +164,7 @@ int nf_plan_create(int H, int W, nf_plan** plan) {
     p->H = H;
     p->W = W;
     p->haveF = p->haveD = false;
-    memset(&p->pf, 0, sizeof(p->pf));
-    memset(&p->pd, 0, sizeof(p->pd));
+    // (new nf_plan() value-initialises both Plan2D members: numbers and pointers zero, the host tables empty)
     *plan = p;
     return NF_OK;
 }
@@ -176,6 +175,38 @@ int nf_plan_destroy(nf_plan* p) {
     if (p->haveD) p->pd.destroy();
     delete p;
     return NF_OK;
+}
+
+int nf_plan_digit_reversal(nf_plan* p, int prec, int axis, unsigned short* rev, int* bluestein) {
+    if (!p || !rev || !bluestein || (axis != 0 && axis != 1)) {
+        nf_set_error("nf_plan_digit_reversal: bad arguments");
+        return NF_ERR_ARG;
+    }
+    int rc = ensure_prec(p, prec);
+    if (rc) return rc;
+    const std::vector<unsigned short>& v = prec == NF_F32 ? (axis == 0 ? p->pf.revRow : p->pf.revCol) : (axis == 0 ? p->pd.revRow : p->pd.revCol);
+    const int n = axis == 0 ? p->W : p->H;
+    *bluestein = prec == NF_F32 ? (axis == 0 ? p->pf.row.bluestein : p->pf.col.bluestein) : (axis == 0 ? p->pd.row.bluestein : p->pd.col.bluestein);
+    if (*bluestein) return NF_OK;      // (the table then belongs to the padded length: not handed out)
+    if ((int)v.size() < n) {
+        nf_set_error("nf_plan_digit_reversal: plan table missing");
+        return NF_ERR_ARG;
+    }
+    for (int i = 0; i < n; ++i) rev[i] = v[i];
+    return NF_OK;
+}
+
+int nf_axis_filter(nf_plan* p, int prec, int axis, const void* in, int inType, void* out, int outType, int batch,
+                   const double* wperm, const void* zeroRef, void* stream) {
+    if (!p || !in || !out || !wperm || batch < 1 || (axis != 0 && axis != 1) || (inType != NF_IN_REAL64 && inType != NF_IN_REAL32) ||
+        (outType != NF_IN_REAL64 && outType != NF_IN_REAL32)) {
+        nf_set_error("nf_axis_filter: bad arguments (real maps in and out)");
+        return NF_ERR_ARG;
+    }
+    int rc = ensure_prec(p, prec);
+    if (rc) return rc;
+    if (prec == NF_F32) return p->pf.axis_filter(axis, in, inType, out, outType, batch, wperm, zeroRef, S(stream));
+    return p->pd.axis_filter(axis, in, inType, out, outType, batch, wperm, zeroRef, S(stream));
 }
 
 int nf_fft2_forward(nf_plan* p, int prec, const void* in, int inType, void* out, int batch, const double* apodY,

@@ -1,6 +1,7 @@
 // Internal C++ interface of the FFT module (see nf_fft.hip).
 #pragma once
 #include "nf_common.h"
+#include <vector>
 
 #define NF_MAXFAC 24
 
@@ -79,7 +80,10 @@ struct Plan2D {
     int rowsPerWG, colsPerWG, threadsRow, tbRow, threadsCol;
     int useReal;    // real-data fast paths enabled (NF_FFT_REAL=0 switches them off)
     int packNyq;    // columns 0 and W/2 of half spectra share one complex column (NF_FFT_PACK_NYQ=0 switches it off)
+    std::vector<unsigned short> revRow, revCol;   // host copies of row.rev / col.rev (digit-reversed position of index k)
     bool packOk() const;
+    int axis_filter(int axis, const void* in, int inType, void* out, int outType, int batch, const double* wperm,
+                    const void* zeroRef, hipStream_t stream);
     int init(int H, int W);
     void destroy();
     int forward(const void* in, int inType, void* out, int batch, const double* apodY, const double* apodX,

@@ -947,6 +947,153 @@ __global__ void __launch_bounds__((MODE == 0 && SPEC == 3 && sizeof(T) == 8) ? 5
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------
+// Circular filtering of REAL lines by a real, even transfer function: y = IFFT(FFT(x) * w), one kernel, one pass over the map.
+// enmap.apply_window (nemo/filters.py:98-101, nemo/maps.py:1849) multiplies the 2-D spectrum by wy[ky] * wx[kx]: the two 1-D
+// operators along x and along y commute, each is this kernel once - the map is read and written twice instead of four times,
+// and no spectrum ever reaches HBM.  Two real lines travel as one complex line z = a + i b; a real, even w acts on both alike
+// and the inverse transform hands them back as real and imaginary part.  In LDS: natural order -> DIF stages -> multiply by
+// w at the digit-reversed positions (table wperm[rev[k]] = w[k] / n, given by the caller) and conjugate -> DIT stages ->
+// conjugate at the store.  Plain-radix lengths only (MODE 0 / 1).
+//   rows (COLS false): line p = rows 2p, 2p+1 of the map;  columns (COLS true): lane c of a tile = columns 2c, 2c+1.
+// a.winElem = wperm; a.inType / a.outType 1 = float64, 2 = float32; a.epiZeroRef: where that map (of the output type) is zero
+// the output is zero (nemo/filters.py:99-101).
+template <typename T>
+__device__ __forceinline__ T lf_load(const void* p, int type, size_t off) {
+    return type == 1 ? (T)((const double*)p)[off] : (T)((const float*)p)[off];
+}
+
+template <typename T>
+__device__ __forceinline__ void lf_store(const nf::LineArgs<T>& a, void* outP, size_t off, T v) {
+    if (a.outType == 1) {
+        double w = (double)v;
+        if (a.epiZeroRef != nullptr && ((const double*)a.epiZeroRef)[off] == 0.0) w = 0.0;
+        ((double*)outP)[off] = w;
+    } else {
+        float w = (float)v;
+        if (a.epiZeroRef != nullptr && ((const float*)a.epiZeroRef)[off] == 0.0f) w = 0.0f;
+        ((float*)outP)[off] = w;
+    }
+}
+
+template <typename T, bool COLS, int MODE>
+__global__ void __launch_bounds__(COLS ? NF_FFT_MAXTHREADS : 512) k_line_filter(nf::LineArgs<T> a) {
+    extern __shared__ __align__(16) unsigned char nf_smem[];
+    cpx<T>* buf = (cpx<T>*)nf_smem;
+    const nf::LinePlan<T>& p = a.plan;
+    const int n = p.n;
+    Geo G;
+    int nvalid = 0;
+    if (COLS) {
+        const int per = (a.nTiles + 7) >> 3;
+        const int tile = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+        if (tile >= a.nTiles) return;
+        G.TL = a.linesPerWG;
+        G.line0 = tile * G.TL;
+        nvalid = min(G.TL, a.nLines - G.line0);
+        G.tl = threadIdx.x & (G.TL - 1);
+        G.tb = threadIdx.x / G.TL;
+        G.TB = blockDim.x / G.TL;
+        G.nl = G.tl < nvalid ? G.tl + 1 : 0;
+    } else {
+        G.line0 = blockIdx.x * a.linesPerWG;
+        G.nl = min(a.linesPerWG, a.nLines - G.line0);
+        G.TB = a.tb;
+        G.TL = blockDim.x / a.tb;
+        G.tl = threadIdx.x / a.tb;
+        G.tb = threadIdx.x - G.tl * a.tb;
+    }
+    const size_t plane = (size_t)a.realH * (size_t)a.realW;
+    const size_t inEs = a.inType == 1 ? 8 : 4, outEs = a.outType == 1 ? 8 : 4;
+    G.inP = (const char*)a.in + (size_t)blockIdx.y * plane * inEs;
+    G.outP = (char*)a.out + (size_t)blockIdx.y * plane * outEs;
+    constexpr int NB = 4;
+    const size_t W = (size_t)a.realW;
+
+    // 1. two real lines -> one complex line, natural order
+    if (COLS) {
+        if (G.nl > 0) {
+            const size_t c0 = 2u * (size_t)(G.line0 + G.tl);
+            const bool haveB = c0 + 1 < W;
+            for (int e0 = G.tb; e0 < n; e0 += NB * G.TB) {
+                cpx<T> z[NB];
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    const int e = min(e0 + j * G.TB, n - 1);
+                    z[j].x = lf_load<T>(G.inP, a.inType, (size_t)e * W + c0);
+                    z[j].y = haveB ? lf_load<T>(G.inP, a.inType, (size_t)e * W + c0 + 1) : (T)0;
+                }
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    const int e = e0 + j * G.TB;
+                    if (e < n) buf[(unsigned)swz(e) * (unsigned)G.TL + (unsigned)G.tl] = z[j];
+                }
+            }
+        }
+    } else {
+        for (int line = G.tl; line < G.nl; line += G.TL) {
+            const size_t rowA = 2u * (size_t)(G.line0 + line);
+            const bool haveB = rowA + 1 < (size_t)a.realH;
+            cpx<T>* __restrict__ lb = buf + line * p.mPad;
+            for (int e0 = G.tb; e0 < n; e0 += NB * G.TB) {
+                cpx<T> z[NB];
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    const int e = min(e0 + j * G.TB, n - 1);
+                    z[j].x = lf_load<T>(G.inP, a.inType, rowA * W + (size_t)e);
+                    z[j].y = haveB ? lf_load<T>(G.inP, a.inType, (rowA + 1) * W + (size_t)e) : (T)0;
+                }
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    const int e = e0 + j * G.TB;
+                    if (e < n) lb[swz(e)] = z[j];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // 2. forward transform, decimation in frequency: the spectrum lands on the digit-reversed positions
+    for (int s = p.nst - 1; s >= 0; --s) fft_stage_dispatch<T, COLS, MODE, 0>(buf, a, s, true, false, false, G);
+    // 3. times the transfer function; conjugate (the way back is a forward transform of the conjugate)
+    for (int e = G.tb; e < n; e += G.TB) {
+        const T w = (T)a.winElem[e];
+        for (int line = G.tl; line < G.nl; line += (COLS ? G.nl : G.TL)) {
+            const unsigned at = COLS ? (unsigned)swz(e) * (unsigned)G.TL + (unsigned)line : (unsigned)line * (unsigned)p.mPad + (unsigned)swz(e);
+            cpx<T> v = buf[at];
+            v.x = v.x * w;
+            v.y = -(v.y * w);
+            buf[at] = v;
+        }
+    }
+    __syncthreads();
+    // 4. back, decimation in time: digit-reversed -> natural
+    for (int s = 0; s < p.nst; ++s) fft_stage_dispatch<T, COLS, MODE, 0>(buf, a, s, false, false, false, G);
+    // 5. the two real lines: real part and minus the imaginary part
+    if (COLS) {
+        if (G.nl > 0) {
+            const size_t c0 = 2u * (size_t)(G.line0 + G.tl);
+            const bool haveB = c0 + 1 < W;
+            for (int e = G.tb; e < n; e += G.TB) {
+                const cpx<T> v = buf[(unsigned)swz(e) * (unsigned)G.TL + (unsigned)G.tl];
+                lf_store<T>(a, G.outP, (size_t)e * W + c0, v.x);
+                if (haveB) lf_store<T>(a, G.outP, (size_t)e * W + c0 + 1, -v.y);
+            }
+        }
+    } else {
+        for (int line = G.tl; line < G.nl; line += G.TL) {
+            const size_t rowA = 2u * (size_t)(G.line0 + line);
+            const bool haveB = rowA + 1 < (size_t)a.realH;
+            const cpx<T>* __restrict__ lb = buf + line * p.mPad;
+            for (int e = G.tb; e < n; e += G.TB) {
+                const cpx<T> v = lb[swz(e)];
+                lf_store<T>(a, G.outP, rowA * W + (size_t)e, v.x);
+                if (haveB) lf_store<T>(a, G.outP, (rowA + 1) * W + (size_t)e, -v.y);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------
 // host side: plans
 // ------------------------------------------------------------------------------------------------------
@@ -1037,7 +1184,7 @@ static int upload_vec(const std::vector<V>& v, const V** dst) {
 }
 
 template <typename T>
-int make_line_plan(int n, LinePlan<T>* p) {
+int make_line_plan(int n, LinePlan<T>* p, std::vector<unsigned short>* revOut = nullptr) {
     memset(p, 0, sizeof(*p));
     p->n = n;
     const long double pi = 3.141592653589793238462643383279502884L;
@@ -1101,6 +1248,7 @@ int make_line_plan(int n, LinePlan<T>* p) {
         rev[i] = (unsigned short)pos;
         src[pos] = (unsigned short)i;
     }
+    if (revOut) *revOut = rev;
     rc = upload_vec<unsigned short>(rev, &p->rev);
     if (rc) return rc;
     rc = upload_vec<unsigned short>(src, &p->src);
@@ -1246,9 +1394,9 @@ template <typename T>
 int Plan2D<T>::init(int H_, int W_) {
     H = H_;
     W = W_;
-    int rc = make_line_plan<T>(W, &row);
+    int rc = make_line_plan<T>(W, &row, &revRow);
     if (rc) return rc;
-    rc = make_line_plan<T>(H, &col);
+    rc = make_line_plan<T>(H, &col, &revCol);
     if (rc) return rc;
     const size_t es = sizeof(cpx<T>);
     // ---- rows: bundle rows up to ~32 KB of LDS (several workgroups per CU hide each other's latencies), at least one ----
@@ -1457,6 +1605,71 @@ int Plan2D<T>::inverse_half(const void* in, void* work, void* out, int outType, 
     int rc = launch_lines<T>(c, true, batch, threadsCol, stream);
     if (rc) return rc;
     return launch_lines<T>(a, false, batch, threadsRow, stream);
+}
+
+// y = IFFT(FFT(x) * w) along one axis of a real map (k_line_filter): axis 0 = along the rows (x), 1 = along the columns (y).
+// wperm: device table of n doubles, wperm[rev[k]] = w[k] / n.  in == out is allowed for axis 1 only (a tile is read whole
+// before it is written; a rows workgroup would overwrite rows other workgroups still read... no: rows are disjoint too).
+template <typename T>
+int Plan2D<T>::axis_filter(int axis, const void* in, int inType, void* out, int outType, int batch, const double* wperm,
+                           const void* zeroRef, hipStream_t stream) {
+    const LinePlan<T>& lp = axis == 0 ? row : col;
+    if (lp.bluestein) {
+        nf_set_error("axis_filter: this length needs Bluestein's algorithm - use the 2-D transforms");
+        return NF_ERR_SIZE;
+    }
+    LineArgs<T> a;
+    memset(&a, 0, sizeof(a));
+    a.plan = lp;
+    a.in = in;
+    a.out = out;
+    a.inType = inType;
+    a.outType = outType;
+    a.realH = H;
+    a.realW = W;
+    a.winElem = wperm;
+    a.epiZeroRef = zeroRef;
+    a.conjInSign = a.conjOutSign = a.scale = 1.0;
+    int mode = 0;
+    for (int s = 0; s < lp.nst; ++s)
+        if (lp.st[s].R > 8) mode = 1;
+    static bool attrSet[2] = {false, false};
+    const int which = sizeof(T) == 8 ? 1 : 0;
+    if (!attrSet[which]) {
+#define NF_ATTR(K) NF_HIP(hipFuncSetAttribute((const void*)K, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds))
+        NF_ATTR((k_line_filter<T, false, 0>));
+        NF_ATTR((k_line_filter<T, false, 1>));
+        NF_ATTR((k_line_filter<T, true, 0>));
+        NF_ATTR((k_line_filter<T, true, 1>));
+#undef NF_ATTR
+        attrSet[which] = true;
+    }
+    const double bytes = (double)H * W * batch * ((inType == 1 ? 8.0 : 4.0) + (outType == 1 ? 8.0 : 4.0) * (zeroRef ? 2.0 : 1.0));
+    if (axis == 0) {
+        a.nLines = (H + 1) / 2;
+        a.linesPerWG = rowsPerWG;
+        a.tb = tbRow;
+        const size_t lds = (size_t)lp.mPad * a.linesPerWG * sizeof(cpx<T>);
+        ProfScope ps(sizeof(T) == 8 ? PT_FFT_ROWS_F64 : PT_FFT_ROWS_F32, stream, bytes);
+        dim3 grid(nf_div_up(a.nLines, a.linesPerWG), batch);
+        if (mode == 0)
+            hipLaunchKernelGGL((k_line_filter<T, false, 0>), grid, dim3(threadsRow), lds, stream, a);
+        else
+            hipLaunchKernelGGL((k_line_filter<T, false, 1>), grid, dim3(threadsRow), lds, stream, a);
+    } else {
+        a.nLines = (W + 1) / 2;
+        a.linesPerWG = colsPerWG;
+        a.nTiles = nf_div_up(a.nLines, colsPerWG);
+        const size_t lds = (size_t)lp.mPad * a.linesPerWG * sizeof(cpx<T>);
+        ProfScope ps(sizeof(T) == 8 ? PT_FFT_COLS_F64 : PT_FFT_COLS_F32, stream, bytes);
+        dim3 grid(((a.nTiles + 7) / 8) * 8, batch);
+        if (mode == 0)
+            hipLaunchKernelGGL((k_line_filter<T, true, 0>), grid, dim3(threadsCol), lds, stream, a);
+        else
+            hipLaunchKernelGGL((k_line_filter<T, true, 1>), grid, dim3(threadsCol), lds, stream, a);
+    }
+    NF_CHECK_LAUNCH("k_line_filter");
+    return NF_OK;
 }
 
 template struct Plan2D<float>;

@@ -107,6 +107,7 @@ def ptr(t):
 
 
 _PINNED_COPY_MAX = 4 << 20
+_AXIS_WINDOW = os.environ.get('NEMO_AMD_AXIS_WINDOW', '1') != '0'    # 0: apply_window through the 2-D transforms always
 
 
 def to_dev(x, dtype=None):
@@ -209,6 +210,7 @@ class TileEngine(object):
             tabs.append(to_dev(a))
         self.apodY, self.apodX = tabs
         self._win = {}
+        self._axisWin = {}
         self._gauss = {}
         self._geom = {}
         self._geomLast = None
@@ -380,10 +382,53 @@ class TileEngine(object):
               "nf_window_mul")
         return F
 
-    def apply_window(self, m, pow):
-        """enmap.apply_window(m, pow): real [H,W] map in, real map of the same dtype out."""
-        F = self.fft(m, unitary=True, half=True)
-        return self.ifft(F, out='f64' if m.dtype == self.t.float64 else 'f32', unitary=True, clobber=True, window=pow, half=True)
+    def _axis_window(self, pow, prec):
+        """Transfer functions of enmap.apply_window along x and y in the order nf_axis_filter reads them (digit-reversed
+        positions, divided by the length), or None where a side needs Bluestein's algorithm."""
+        key = (float(pow), prec)
+        if key not in self._axisWin:
+            tabs = []
+            for axis, n in ((0, self.W), (1, self.H)):
+                rev = (ctypes.c_ushort * n)()
+                blue = ctypes.c_int(0)
+                check(self.lib.nf_plan_digit_reversal(self.plan, prec, axis, rev, ctypes.byref(blue)), "nf_plan_digit_reversal")
+                if blue.value:
+                    tabs = None
+                    break
+                perm = np.empty(n, dtype=np.float64)
+                perm[np.frombuffer(rev, dtype=np.uint16).astype(np.int64)] = (np.sinc(np.fft.fftfreq(n)) ** pow) / n
+                tabs.append(to_dev(perm))
+            self._axisWin[key] = tabs
+        return self._axisWin[key]
+
+    def apply_window(self, m, pow, zero_ref=None):
+        """enmap.apply_window(m, pow): real [H,W] (or [N,H,W]) maps in, real maps of the same dtype out.  The window is a product
+        of a function of ky and one of kx: two 1-D circular filters, one pass over the map each (nf_axis_filter); the 2-D
+        transform pair with the window fused into the inverse's load where a side's length needs Bluestein's algorithm.
+        ``zero_ref``: pixels that are zero there are zero in the result (nemo/filters.py:99-101)."""
+        t = self.t
+        prec = prec_of(m)
+        tabs = self._axis_window(pow, prec) if _AXIS_WINDOW else None
+        if tabs is None:
+            F = self.fft(m, unitary=True, half=True)
+            if zero_ref is not None:
+                return self.ifft_half_epi(F, window=pow, unitary=True, out='f64' if m.dtype == t.float64 else 'f32', zero_ref=zero_ref,
+                                          clobber=True)
+            return self.ifft(F, out='f64' if m.dtype == t.float64 else 'f32', unitary=True, clobber=True, window=pow, half=True)
+        m3 = m.reshape(-1, self.H, self.W)
+        if not m3.is_contiguous():
+            m3 = m3.contiguous()
+        if zero_ref is m:
+            zero_ref = m3
+        if zero_ref is not None and (zero_ref.dtype != m.dtype or not zero_ref.is_contiguous() or m3.shape[0] != 1):
+            raise NemoFiltError("apply_window: zero_ref must be one contiguous map of the map's dtype")
+        out = t.empty_like(m3)
+        ty = 1 if m.dtype == t.float64 else 2
+        check(self.lib.nf_axis_filter(self.plan, prec, 0, ptr(m3), ty, ptr(out), ty, m3.shape[0], ptr(tabs[0]), None, stream_ptr()),
+              "nf_axis_filter")
+        check(self.lib.nf_axis_filter(self.plan, prec, 1, ptr(out), ty, ptr(out), ty, m3.shape[0], ptr(tabs[1]), ptr(zero_ref),
+                                      stream_ptr()), "nf_axis_filter")
+        return out.reshape(m.shape)
 
     # ---- templates -----------------------------------------------------------------------------------------
     def _tableDev(self, table):
@@ -538,9 +583,7 @@ class TileEngine(object):
     def undo_pixel_window(self, data):
         """filterMaps' last step (nemo/filters.py:98-101): apply_window(data, -1), zeros of ``data`` kept (restored while the
         inverse transform stores its rows)."""
-        F = self.fft(data, unitary=True, half=True)
-        return self.ifft_half_epi(F, window=-1.0, unitary=True, out='f64' if data.dtype == self.t.float64 else 'f32',
-                                  zero_ref=data, clobber=True)
+        return self.apply_window(data, -1.0, zero_ref=data)
 
     def ifft_half_epi(self, X, filtSym=None, sum=False, window=None, unitary=False, out='f32', scale=None, mask=None,
                       zero_ref=None, clobber=False):

@@ -28,7 +28,8 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E peak (MI355X_MICROARCH.md)
 
-SCALES = [(m, z) for z in (0.2, 0.4, 0.8, 1.2) for m in (1.0e14, 2.0e14, 4.0e14, 8.0e14)][:15]
+SCALES = [(m, z) for z in (0.2, 0.4, 0.8, 1.2) for m in (1.0e14, 2.0e14, 4.0e14, 8.0e14)]      # the DR5 bank (16; C2 uses 15)
+FREQS = [(97.8, 2.1, 30.0, 'f090'), (149.6, 1.4, 20.0, 'f150'), (225.0, 1.0, 60.0, 'f220')]  # GHz, beam FWHM', noise uK/px
 PHOT_FILTER = "Arnaud_M2e14_z0p4"
 
 
@@ -57,7 +58,7 @@ def make_workload(shape, seed, dtype):
     m = mapsL[0]
     data = engine.to_dev(m['mapData'])
     rng = np.random.default_rng(seed + 7)
-    bank = [(mm, zz) for mm, zz in SCALES]
+    bank = [(mm, zz) for mm, zz in SCALES[:15]]
     for k in range(50):
         y = rng.uniform(60, shape[0] - 60)
         x = rng.uniform(60, shape[1] - 60)
@@ -77,13 +78,55 @@ def make_workload(shape, seed, dtype):
     return [md], wcs, truth
 
 
-def make_config(mapsList, numScales):
+OVERLAP_PIX = 120       # tileOverlapDeg 1.0 at 0.5' pixels (examples/ACT-DR5-clusters/DR5ClusterSearch.yml:141-147)
+
+
+def make_workload_tiled(tileShape, tilesPerGPU, numFreqs, seed, dtype):
+    """C3-shaped workload: `tilesPerGPU` tiles of `tileShape` pixels INCLUDING the 1 degree overlap, cut side by
+    side from one synthetic strip per frequency (common CMB, white noise, painted clusters), resident in HBM.  Returns the
+    MapDicts, the WCS and the tile definitions (the cores; startUp adds the overlap back)."""
+    import numpy as np
+    from nemo_amd import signals, simgen, engine, maps as pmaps
+    H, W = tileShape
+    coreH, coreW = H - 2 * OVERLAP_PIX, W - 2 * OVERLAP_PIX
+    if coreH < 64 or coreW < 64:
+        raise SystemExit("--tile must leave a core beyond the 2 x %d overlap pixels" % OVERLAP_PIX)
+    # (one spare pixel all round: the overlap is only added where it stays strictly inside the map, nemo/startUp.py:620-657)
+    M = OVERLAP_PIX + 1
+    big = (H + 2, tilesPerGPU * coreW + 2 * M)
+    freqs = FREQS[:numFreqs]
+    beams = [signals.BeamProfile(FWHMArcmin=f[1]) for f in freqs]
+    eng = engine.TileEngine.get(big)
+    mapsL, wcs, truth = simgen.makeSimTile(big, [f[0] for f in freqs], beams, [f[2] for f in freqs], seed=seed,
+                                           numSources=6 * tilesPerGPU, kind='clusters', dtype=np.float64,
+                                           painter=lambda geom, table: eng.paint(geom, table).cpu().numpy(), borderPix=OVERLAP_PIX)
+    t = engine.torch()
+    tdt = t.float64 if dtype == 'f64' else t.float32
+    out = []
+    for m, f in zip(mapsL, freqs):
+        data = engine.to_dev(m['mapData']).to(tdt)
+        out.append(pmaps.MapDict({'mapData': data, 'weightsData': engine.to_dev(m['weightsData']).to(tdt), 'obsFreqGHz': f[0],
+                                  'units': 'uK', 'beamFileName': m['beamFileName'], 'label': f[3], 'wcs': wcs,
+                                  'surveyMask': t.ones(big, dtype=t.uint8, device=data.device),
+                                  'pointSourceMask': t.ones(big, dtype=t.uint8, device=data.device)}))
+    tileDefs = []
+    for k in range(tilesPerGPU):
+        x0, x1 = M + k * coreW, M + (k + 1) * coreW
+        raA, decA = wcs.pix2wcs(x0, M)
+        raB, decB = wcs.pix2wcs(x1, M + coreH)
+        tileDefs.append({'tileName': 'T%02d' % k, 'RADecSection': [min(raA, raB), max(raA, raB), min(decA, decB), max(decA, decB)]})
+    return out, wcs, tileDefs
+
+
+def make_config(mapsList, numScales, tileDefs=None):
     """The DR5 cluster-search configuration (examples/ACT-DR5-clusters/DR5ClusterSearch.yml:26-38,82-129) over in-memory maps."""
     from nemo_amd import startUp
     parDict = {'unfilteredMaps': [dict(m) for m in mapsList], 'thresholdSigma': 4.0, 'minObjPix': 1, 'findCenterOfMass': True,
                'useInterpolator': True, 'optimalCatalogMethod': 'ref-forced', 'rejectBorder': 0, 'objIdent': 'ACT-CL',
                'longNames': False, 'photFilter': PHOT_FILTER, 'mapFilters': filter_list(numScales), 'useTiling': False,
                'outputDir': None}
+    if tileDefs is not None:
+        parDict.update({'useTiling': True, 'tileDefinitions': tileDefs, 'tileOverlapDeg': 1.0})
     return startUp.NemoConfig(parDict, makeOutputDirs=False, verbose=False)
 
 
@@ -135,8 +178,9 @@ def cpu_baseline(procs, size):
     wall = max(secs)
     fsize = max(256, size // 4)
     fwall = _cpu_run(procs, fsize, True)
-    return {'value': round(procs * size * size / 1e6 / wall, 4), 'unit': 'Mpix/s', 'cores': procs, 'kind': 'port',
-            'sample': "%d process(es), each 1 scale (Arnaud M2e14 z0.4) of a %dx%d f64 crop of the same workload: "
+    return {'value': round(procs * size * size / 1e6 / wall, 4), 'unit': 'Mpix/s', 'cores': procs,
+            'host_cores': os.cpu_count(), 'kind': 'port',
+            'sample': "%d single-threaded process(es) (the box's CPU share for one GPU; os.cpu_count() counts the whole machine), each 1 scale (Arnaud M2e14 z0.4) of a %dx%d f64 crop of the same workload: "
                       "oracle MatchedFilter.buildAndApply + pixel-window undo + find_objects (vectorised inverse); "
                       "%.1f s per process" % (procs, size, size, wall),
             'reference_faithful': {'value': round(procs * fsize * fsize / 1e6 / fwall, 4), 'unit': 'Mpix/s', 'cores': procs,
@@ -165,6 +209,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", type=int, default=4096, help="tile side in pixels (headline: 4096)")
     ap.add_argument("--scales", type=int, default=15)
+    ap.add_argument("--tile", default=None, help="HxW in pixels, overlap included: the tiled (C3-shaped) workload, e.g. 840x1440")
+    ap.add_argument("--tiles-per-gpu", type=int, default=1, help="tiles each GPU filters per step (with --tile)")
+    ap.add_argument("--freqs", type=int, default=1, choices=[1, 2, 3], help="frequency maps per tile (with --tile)")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--cpu-procs", type=int, default=-1, help="processes for the CPU baseline (0 = skip; -1 = auto)")
     ap.add_argument("--cpu-size", type=int, default=2048)
@@ -189,13 +236,24 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local % torch.cuda.device_count())
     lib = _lib.load()
-    shape = (args.size, args.size)
-    mapsList, wcs, truth = make_workload(shape, 1234 + rank, args.dtype)
-    config = make_config(mapsList, args.scales)
+    tiled = args.tile is not None
+    if tiled:
+        shape = tuple(int(v) for v in args.tile.lower().split('x'))
+        mapsList, wcs, tileDefs = make_workload_tiled(shape, args.tiles_per_gpu, args.freqs, 1234 + rank, args.dtype)
+        config = make_config(mapsList, args.scales, tileDefs)
+    else:
+        shape = (args.size, args.size)
+        mapsList, wcs, truth = make_workload(shape, 1234 + rank, args.dtype)
+        config = make_config(mapsList, args.scales)
     # tiles are already one per rank (weak scaling): config.MPIEnabled stays False (no tile division inside the pipeline);
     # run_step() does the catalogue all-gather of the path itself when there are several ranks
     config.rank, config.size = rank, world
-    N, S = 1, len(config.parDict['mapFilters'])
+    N, S = len(mapsList), len(config.parDict['mapFilters'])
+    T = len(config.tileNames)
+    if tiled:
+        for tn in config.tileNames:
+            cs = config.tileCoordsDict[tn]['clippedSection']
+            assert (cs[3] - cs[2], cs[1] - cs[0]) == shape, (tn, cs)
 
     def barrier():
         torch.cuda.synchronize()
@@ -258,15 +316,16 @@ def main():
     kernels = {k: {kk: vv for kk, vv in v.items() if kk != 'tag'} for k, v in survey.items()}
 
     if rank == 0:
-        mpix = shape[0] * shape[1] * N * S * args.steps * world / 1e6
+        mpix = shape[0] * shape[1] * N * S * T * args.steps * world / 1e6
         out = {"metric": "filtered Mpix/sec (all scales, all freqs)", "value": round(mpix / elapsed, 2), "unit": "Mpix/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(1e3 * elapsed / args.steps, 2), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-               "config": {"workload": "C2: one %dx%d f090 tile per GPU, ArnaudModelMatchedFilter x %d theta500 scales "
-                                      "(DR5 bank), dataMap noise, 40' grid, yc, pixel-window undo, findObjects 4 sigma"
-                                      % (shape[0], shape[1], S),
-                          "tile": list(shape), "frequencies": N, "scales": S, "tiles_per_gpu": 1,
+               "config": {"workload": ("C3-shaped: %d tiles of %dx%d (1 deg overlap included) per GPU, %d frequency map(s), " % (T, shape[0], shape[1], N)
+                                       if tiled else "C2: one %dx%d f090 tile per GPU, " % (shape[0], shape[1])) +
+                                      "ArnaudModelMatchedFilter x %d theta500 scales (DR5 bank), dataMap noise, 40' grid, yc, "
+                                      "pixel-window undo, findObjects 4 sigma" % (S),
+                          "tile": list(shape), "frequencies": N, "scales": S, "tiles_per_gpu": T,
                           "objects_in_optimal_catalog": int(len(cat))}}
         if kernels:
             if dom is None:

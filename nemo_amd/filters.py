@@ -71,6 +71,57 @@ def filterMaps(unfilteredMapsDictList, filterParams, tileName, diagnosticsDir='.
 
 
 # ------------------------------------------------------------------------------------------------------------
+class _DeviceWeights(dict):
+    """fRelWeights whose values are still on the device: {obsFreqGHz: float32(plane value at the peak) / float32(peak)}
+    (nemo/filters.py:661-667), formed on first access from one small transfer."""
+
+    def __init__(self, freqs, pending):
+        super(_DeviceWeights, self).__init__()
+        self._freqs, self._pending = list(freqs), pending          # pending: N plane values, then the peak (float64 tensor)
+
+    def _resolve(self):
+        if self._pending is not None:
+            h = self._pending.cpu().numpy()
+            self._pending = None
+            total = np.float32(h[-1])
+            for f, v in zip(self._freqs, h[:-1]):
+                dict.__setitem__(self, f, np.float32(v) / total)
+        return self
+
+    def __getitem__(self, k):
+        return dict.__getitem__(self._resolve(), k)
+
+    def __iter__(self):
+        return dict.__iter__(self._resolve())
+
+    def __len__(self):
+        return dict.__len__(self._resolve())
+
+    def __contains__(self, k):
+        return dict.__contains__(self._resolve(), k)
+
+    def keys(self):
+        return dict.keys(self._resolve())
+
+    def values(self):
+        return dict.values(self._resolve())
+
+    def items(self):
+        return dict.items(self._resolve())
+
+    def get(self, k, default=None):
+        return dict.get(self._resolve(), k, default)
+
+    def __repr__(self):
+        return dict.__repr__(self._resolve())
+
+    def __eq__(self, other):
+        return dict.__eq__(self._resolve(), other)
+
+    def copy(self):
+        return dict(self._resolve())
+
+
 class MapFilter(object):
     """Base class defining the common interface (nemo/filters.py:109-513)."""
 
@@ -371,7 +422,7 @@ class MatchedFilter(MapFilter):
         if useCachedFilter == True and haveFile == False and self._dFilt is None and self._tileCache is not None:
             cached = self._tileCache.get(('cachedFilter', self.label), None)
             if cached is not None and tuple(cached.shape) == tuple(self.shape):
-                self._dFilt, self._signalNorm, self.fRelWeights = cached._dFilt, cached._signalNorm, dict(cached.fRelWeights)
+                self._dFilt, self._signalNorm, self.fRelWeights = cached._dFilt, cached._signalNorm, dict(cached.fRelWeights.items())
         if haveFile == False and useCachedFilter == False:
             method = self.params['noiseParams']['method']
             if method != 'dataMap':
@@ -443,12 +494,13 @@ class MatchedFilter(MapFilter):
                     # itself, so the relative weight is a float32 value divided by itself
                     self.fRelWeights[self.unfilteredMapsDictList[0]['obsFreqGHz']] = np.float32(1.0)
                 else:
-                    maxValue, maxIndex = eng.map_max(filteredSignal)              # :661
-                    totalSignal = np.float32(maxValue)
+                    # the peak and the planes' values there stay on the device; the float32 divisions of :667 are done on
+                    # the host when somebody reads the weights (_DeviceWeights) - the enqueueing thread does not wait
+                    mm = eng.map_max(filteredSignal, to_host=False)               # :661
                     planes = eng.ifft(fSignalMaps, out='f32', filt=self._filtFor(True), window=1.0, half=True)       # :662-667
-                    vals = planes.reshape(N, -1)[:, maxIndex].cpu().numpy()
-                    for i, mapDict in enumerate(self.unfilteredMapsDictList):
-                        self.fRelWeights[mapDict['obsFreqGHz']] = np.float32(vals[i]) / totalSignal
+                    vals = planes.reshape(N, -1).index_select(1, mm[1:2].to(t.int64)).reshape(N)
+                    self.fRelWeights = _DeviceWeights([m['obsFreqGHz'] for m in self.unfilteredMapsDictList],
+                                                      t.cat([vals.to(t.float64), mm[:1]]))
                 del fSignalMaps
             elif self.params['outputUnits'] == 'uK':                              # :669-685
                 # the reference paints and transforms the unit templates a second time (:672-679): same values as fSignals

@@ -323,6 +323,7 @@ class RadialTable(object):
 
 _TABLE_N = 4096
 _profileCache = {}
+_tableCache = {}
 
 
 def makeRadialTable(tckP, beam=None, amplitude=None, maxSizeDeg=10.0, convolveWithBeam=True, cacheKey=None):
@@ -353,12 +354,22 @@ def makeRadialTable(tckP, beam=None, amplitude=None, maxSizeDeg=10.0, convolveWi
             rprof = interpolate.splev(rDeg, tckP, ext=1)
         if key is not None:
             _profileCache[key] = (r, rprof)
+    # the finished table is kept per (profile, amplitude): the filter bank asks for the same few tables for every tile, and the
+    # painter keeps its device copy on the table object - one upload per table and process instead of one per tile and scale
+    tkey = None if key is None else (key, None if amplitude is None else float(amplitude))
+    if tkey is not None and tkey in _tableCache:
+        return _tableCache[tkey]
     amp = 1.0
     if amplitude is not None:
         amp = rprof[0] * amplitude
         rprof = rprof / rprof[0]
     sign = -1.0 if rprof[0] < 0 else 1.0
-    return RadialTable(r, abs(rprof), amp, sign)
+    table = RadialTable(r, abs(rprof), amp, sign)
+    if tkey is not None:
+        if len(_tableCache) >= 1024:
+            _tableCache.clear()
+        _tableCache[tkey] = table
+    return table
 
 
 def paintGeometry(shape, wcs, RADeg, decDeg):

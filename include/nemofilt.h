@@ -278,6 +278,17 @@ int nf_object_stats(int vtype, const void* sn_d, int negate, const int* labels_d
 int nf_object_shapes(int vtype, const void* sn_d, int negate, const int* labels_d, int H, int W, int numObjects,
                      double* shapes_d, void* stream);
 
+/* completeness.getRMSTab, nemo/completeness.py:1319-1333: the distinct non-zero values of a float32 noise map and, per value,
+ * the number of pixels and the survey area.  areaMask_d (uint8, optional: weight of a pixel's area, normally 0 / 1),
+ * flagMask_d (int32, optional: pixels with flag > maxFlags carry no area, :1319-1321), intersect_d (uint8, optional: where 0
+ * the noise map counts as 0 and the pixel carries no area, :1324-1327).  rowAreaFix_d: H uint64, the area of a pixel of row y
+ * in units of 2^-50 deg^2 (maps.getPixelAreaArcmin2Map's per-row float32 values / 3600).  Result: an open-addressing hash
+ * table of tableSize (power of two) slots - keys_d the float32 bits (0 = empty slot), counts_d, areas_d (2^-50 deg^2);
+ * *overflow_d != 0: the table was too small, ask again with a larger one.  Sums are integer: independent of the order. */
+int nf_rms_table(const float* rms_d, const unsigned char* areaMask_d, const int* flagMask_d, int maxFlags,
+                 const unsigned char* intersect_d, const unsigned long long* rowAreaFix_d, int H, int W, unsigned* keys_d,
+                 unsigned long long* counts_d, unsigned long long* areas_d, int tableSize, int* overflow_d, void* stream);
+
 /* ndarray.max() / np.argmax of a whole map (nemo/filters.py:661,684; nemo/filters.py:1017-1019,1198): out_d holds
  * NF_MAP_MAX_DOUBLES doubles - [0] maximum, [1] flat index of its first occurrence, the rest is scratch (per-workgroup
  * partial results). */

@@ -652,6 +652,16 @@ int nf_object_shapes(int vtype, const void* sn, int negate, const int* labels, i
     return nf::object_shapes(vtype, sn, negate, labels, H, W, numObjects, shapes, S(stream));
 }
 
+int nf_rms_table(const float* rms, const unsigned char* areaMask, const int* flagMask, int maxFlags, const unsigned char* intersect,
+                 const unsigned long long* rowAreaFix, int H, int W, unsigned* keys, unsigned long long* counts,
+                 unsigned long long* areas, int tableSize, int* overflow, void* stream) {
+    if (!rms || !rowAreaFix || !keys || !counts || !areas || !overflow || H < 1 || W < 1) {
+        nf_set_error("nf_rms_table: bad arguments");
+        return NF_ERR_ARG;
+    }
+    return nf::rms_table(rms, areaMask, flagMask, maxFlags, intersect, rowAreaFix, H, W, keys, counts, areas, tableSize, overflow, S(stream));
+}
+
 size_t nf_xmatch_workspace_bytes(int n) { return n > 0 ? nf::xmatch_workspace_bytes(n) : 0; }
 
 int nf_xmatch_self(const double* unit_d, const double* snr_d, int n, double radiusDeg, int* count_d, int* best_d,

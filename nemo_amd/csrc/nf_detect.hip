@@ -500,6 +500,86 @@ int object_shapes(int vtype, const void* sn, int negate, const int* labels, int 
 }
 
 // ---------------------------------------------------------------------------------------------------
+// completeness.getRMSTab (nemo/completeness.py:1329-1333): the distinct non-zero values of the noise map and the survey area
+// at each.  The noise map is piecewise constant (one value per noise cell and weight bin), so the table is small: an
+// open-addressing hash table keyed by the value's bits, filled with integer atomics - pixel counts, and areas as exact
+// multiples of 2^-50 deg^2 (a float32 pixel area above 2^-27 deg^2 is such a multiple: sums do not depend on the order).
+// A thread takes NF_RUN consecutive pixels of a row and inserts one entry per run of equal values.
+#define NF_RMS_AREA_SHIFT 50
+
+__device__ __forceinline__ void rms_insert(unsigned* __restrict__ keys, unsigned long long* __restrict__ cnt,
+                                           unsigned long long* __restrict__ area, unsigned mask, unsigned key, unsigned long long n,
+                                           unsigned long long a, int* __restrict__ overflow) {
+    unsigned h = (key * 2654435761u) >> 7;
+    for (unsigned probe = 0; probe <= mask; ++probe) {
+        h &= mask;
+        const unsigned old = atomicCAS(&keys[h], 0u, key);
+        if (old == 0u || old == key) {
+            atomicAdd(&cnt[h], n);
+            if (a) atomicAdd(&area[h], a);
+            return;
+        }
+        ++h;
+    }
+    atomicOr(overflow, 1);
+}
+
+__global__ void k_rms_table(const float* __restrict__ rms, const unsigned char* __restrict__ areaMask, const int* __restrict__ flagMask,
+                            int maxFlags, const unsigned char* __restrict__ intersect, const unsigned long long* __restrict__ rowAreaFix,
+                            int H, int W, unsigned* __restrict__ keys, unsigned long long* __restrict__ cnt,
+                            unsigned long long* __restrict__ area, unsigned mask, int* __restrict__ overflow) {
+    const int segsPerRow = (W + NF_RUN - 1) / NF_RUN;
+    const long long nseg = (long long)H * segsPerRow;
+    for (long long sidx = blockIdx.x * (long long)blockDim.x + threadIdx.x; sidx < nseg; sidx += (long long)gridDim.x * blockDim.x) {
+        const int y = (int)(sidx / segsPerRow), x0 = (int)(sidx % segsPerRow) * NF_RUN;
+        const unsigned long long ra = rowAreaFix[y];
+        unsigned cur = 0;
+        unsigned long long n = 0, a = 0;
+        for (int j = 0; j < NF_RUN && x0 + j < W; ++j) {
+            const long long p = (long long)y * W + x0 + j;
+            float v = rms[p];
+            bool in = areaMask == nullptr || areaMask[p] != 0;
+            if (flagMask != nullptr && flagMask[p] > maxFlags) in = false;
+            if (intersect != nullptr && intersect[p] == 0) {
+                in = false;
+                v = 0.0f;
+            }
+            const unsigned key = v == 0.0f ? 0u : __float_as_uint(v);
+            if (key != cur) {
+                if (cur != 0u) rms_insert(keys, cnt, area, mask, cur, n, a, overflow);
+                cur = key;
+                n = 0;
+                a = 0;
+            }
+            if (key != 0u) {
+                ++n;
+                if (in) a += ra * (unsigned long long)(areaMask ? areaMask[p] : 1);
+            }
+        }
+        if (cur != 0u) rms_insert(keys, cnt, area, mask, cur, n, a, overflow);
+    }
+}
+
+// keys: tableSize (a power of two) uint32, zeroed by this call; cnt / area: tableSize uint64 each
+int rms_table(const float* rms, const unsigned char* areaMask, const int* flagMask, int maxFlags, const unsigned char* intersect,
+              const unsigned long long* rowAreaFix, int H, int W, unsigned* keys, unsigned long long* cnt, unsigned long long* area,
+              int tableSize, int* overflow, hipStream_t s) {
+    if (tableSize < 64 || (tableSize & (tableSize - 1)) != 0) {
+        nf_set_error("rms_table: the table size must be a power of two >= 64");
+        return NF_ERR_ARG;
+    }
+    NF_HIP(hipMemsetAsync(keys, 0, (size_t)tableSize * sizeof(unsigned), s));
+    NF_HIP(hipMemsetAsync(cnt, 0, (size_t)tableSize * sizeof(unsigned long long), s));
+    NF_HIP(hipMemsetAsync(area, 0, (size_t)tableSize * sizeof(unsigned long long), s));
+    NF_HIP(hipMemsetAsync(overflow, 0, sizeof(int), s));
+    const long long nseg = (long long)H * ((W + NF_RUN - 1) / NF_RUN);
+    hipLaunchKernelGGL(k_rms_table, dim3(grid_for(nseg, 256)), dim3(256), 0, s, rms, areaMask, flagMask, maxFlags, intersect, rowAreaFix, H, W,
+                       keys, cnt, area, (unsigned)(tableSize - 1), overflow);
+    NF_CHECK_LAUNCH("k_rms_table");
+    return NF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // np.argmax / ndarray.max of a whole map (nemo/filters.py:661,684): maximum value and FIRST raster index attaining it.
 // One pass: every thread keeps (value, first index) of its grid-stride share, the workgroup reduces with wavefront
 // shuffles + LDS and writes ONE partial; a second single-workgroup launch reduces the partials.  No atomics (65536

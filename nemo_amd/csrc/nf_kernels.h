@@ -80,6 +80,9 @@ int label_components(int vtype, const void* sn, double threshold, int negate, in
 int object_stats(int vtype, const void* sn, int negate, const int* labels, int H, int W, int numObjects, double* stats,
                  hipStream_t s);
 int object_shapes(int vtype, const void* sn, int negate, const int* labels, int H, int W, int numObjects, double* shapes, hipStream_t s);
+int rms_table(const float* rms, const unsigned char* areaMask, const int* flagMask, int maxFlags, const unsigned char* intersect,
+              const unsigned long long* rowAreaFix, int H, int W, unsigned* keys, unsigned long long* cnt, unsigned long long* area,
+              int tableSize, int* overflow, hipStream_t s);
 int map_max(int vtype, const void* m, long long n, double* out, hipStream_t s);
 int ring_flags(const int* ringLabels, const double* ringStats, int numRing, int minRingPix, int H, int W, unsigned char* isRing,
                hipStream_t s);

@@ -748,6 +748,36 @@ class TileEngine(object):
                                         ptr(shapes), stream_ptr()), "nf_object_shapes")
         return shapes[:(numObjects + 1) * 10].reshape(numObjects + 1, 10)
 
+    def rms_table(self, rms, areaMask, flagMask, maxFlags, intersect, rowAreaDeg2):
+        """Distinct non-zero values of a float32 noise map (ascending, as np.unique gives them), pixel counts, and survey
+        area in deg^2 per value (nf_rms_table).  rowAreaDeg2: float32 per row, > 2^-27."""
+        t = self.t
+        ra = np.asarray(rowAreaDeg2, dtype=np.float64)
+        if len(ra) != self.H or (ra < 2.0 ** -27).any() or (ra > 1.0).any():
+            raise NemoFiltError("rms_table: one pixel area per row, between 2^-27 and 1 deg^2")
+        fix = np.round(ra * 2.0 ** 50).astype(np.uint64)
+        fix_d = to_dev(fix.view(np.int64))
+        size = 1 << 16
+        while True:
+            keys = t.empty(size, dtype=t.int32, device=self.dev)
+            cnt = t.empty(size, dtype=t.int64, device=self.dev)
+            area = t.empty(size, dtype=t.int64, device=self.dev)
+            over = t.empty(1, dtype=t.int32, device=self.dev)
+            check(self.lib.nf_rms_table(ptr(rms), ptr(areaMask), ptr(flagMask), int(maxFlags) if maxFlags is not None else 0,
+                                        ptr(intersect), ptr(fix_d), self.H, self.W, ptr(keys), ptr(cnt), ptr(area), size, ptr(over),
+                                        stream_ptr()), "nf_rms_table")
+            if int(over.item()) == 0:
+                break
+            size *= 16
+            if size > (1 << 28):
+                raise NemoFiltError("rms_table: the noise map has too many distinct values")
+        used = keys != 0
+        k = keys[used].cpu().numpy().view(np.float32)
+        c = cnt[used].cpu().numpy()
+        a = area[used].cpu().numpy().view(np.uint64).astype(np.float64) / 2.0 ** 50
+        order = np.argsort(k, kind='stable')
+        return k[order], c[order], a[order]
+
     def ring_flags(self, ringLabels, ringStats, numRing, minRingPix=30):
         t = self.t
         isRing = t.empty(numRing + 1, dtype=t.uint8, device=self.dev)

@@ -376,6 +376,22 @@ def makeModelImage(shape, wcs, catalog, beamFileName, obsFreqGHz=None, GNFWParam
     return modelMap
 
 
+def getPixelAreaArcmin2Map(shape, wcs, rowsOnly=False):
+    """Pixel area in arcmin^2 (nemo/maps.py:1385-1406): measured per row at the map's central column, float32, the same for
+    every pixel of a row.  ``rowsOnly``: the per-row values [H] instead of the map [H, W]."""
+    RACentre, decCentre = wcs.getCentreWCSCoords()
+    x0, _ = wcs.wcs2pix(RACentre, decCentre)
+    ys = np.arange(shape[0], dtype=np.float64)
+    ra0, dec0 = wcs.pix2wcs(np.full(shape[0], x0), ys)
+    ra1, dec1 = wcs.pix2wcs(np.full(shape[0], x0 + 1), ys + 1)
+    xPixScale = calcAngSepDeg(ra0, dec0, ra1, dec0)
+    yPixScale = calcAngSepDeg(ra0, dec0, ra0, dec1)
+    pixAreasArcmin2 = np.array(xPixScale * yPixScale, dtype=np.float32) * (60 ** 2)
+    if rowsOnly:
+        return pixAreasArcmin2
+    return np.array([pixAreasArcmin2] * shape[1]).transpose()
+
+
 def pixelScalesDeg(wcs, RADeg='centre', decDeg='centre'):
     """x / y pixel scales (degrees) at the given coordinates, as nemo/maps.py:1367-1377 derives them."""
     ra0, dec0 = wcs.getCentreWCSCoords()

@@ -53,6 +53,59 @@ def initDistributed():
 _NAME_CHARS = 30      # width of the name column (catalogs.catalogListToTab: minStrLength = 30)
 
 
+def makeRMSTables(config, selFnDir=None):
+    """Noise / area table of every tile for the reference filter (nemo/pipelines.py:401-503, the 'full' footprint): each rank
+    tabulates its tiles on its GPU (completeness.getRMSTab), the rows travel to every rank in one all-gather of fixed-width
+    rows (the reference gathers pickled tables on rank 0, :464-475), and the merged table - columns areaDeg2, y0RMS, tileName,
+    sorted by y0RMS (:496-501) - is returned on every rank.  None without a photFilter (:409-410)."""
+    from . import completeness
+    if config.parDict['photFilter'] is None:
+        return None
+    photFilterLabel = config.parDict['photFilter']
+    maxFlags = config.parDict.get('selFnOptions', {}).get('maxFlags', None)
+    selFnDir = selFnDir if selFnDir is not None else config.selFnDir
+    tileIndex = {name: i for i, name in enumerate(config.allTileNames)}
+    rows = []
+    for tileName in config.tileNames:
+        tab = completeness.getRMSTab(tileName, photFilterLabel, selFnDir, maxFlags=maxFlags, config=config)
+        part = np.zeros((len(tab), 3), dtype=np.float64)
+        part[:, 0], part[:, 1], part[:, 2] = tab['areaDeg2'], tab['y0RMS'], tileIndex[tileName]
+        rows.append(part)
+    rows = np.concatenate(rows) if rows else np.zeros((0, 3))
+    if config.MPIEnabled == True and config.size > 1:
+        rows = _gatherRows(rows, config)
+    out = catalogs.Table()
+    order = np.argsort(rows[:, 1], kind='stable')
+    strLen = max([len(name) for name in config.allTileNames] + [1])
+    out['areaDeg2'] = rows[order, 0]
+    out['y0RMS'] = rows[order, 1].astype(np.float32)
+    out['tileName'] = np.array([config.allTileNames[int(i)] for i in rows[order, 2]], dtype='<U%d' % (strLen))
+    from . import __version__
+    out.meta['NEMOVER'] = __version__
+    return out
+
+
+def _gatherRows(rows, config):
+    """All-gather of float64 rows of equal width (counts first, then the rows padded to the largest count); every rank gets the
+    rows of all ranks in rank order."""
+    import torch
+    import torch.distributed as dist
+    dev = torch.device('cuda', torch.cuda.current_device()) if dist.get_backend() == 'nccl' else torch.device('cpu')
+    n, width = rows.shape
+    counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(config.size)]
+    dist.all_gather(counts, torch.tensor([n], dtype=torch.int64, device=dev))
+    counts = [int(c) for c in torch.cat(counts).cpu().tolist()]
+    nmax = max(counts)
+    if nmax == 0:
+        return rows
+    padded = torch.zeros((nmax, width), dtype=torch.float64, device=dev)
+    if n > 0:
+        padded[:n] = torch.from_numpy(np.ascontiguousarray(rows)).to(dev)
+    parts = [torch.zeros_like(padded) for _ in range(config.size)]
+    dist.all_gather(parts, padded)
+    return np.concatenate([p[:c].cpu().numpy() for p, c in zip(parts, counts)])
+
+
 def _gatherCatalogs(optimalCatalog, config):
     """All ranks end up with the rows of all ranks: all-gather of the row counts, then of the rows padded to the largest
     count.  Rows are [len(_GATHER_COLS) + 2] float64: the listed columns, the index of the template in the filter list and

@@ -16,4 +16,4 @@ Pinning status:
   PARITY UNPINNED for those pieces (none of them is available offline, and the reference holds no
   golden vectors).
 """
-from . import pixell_restated, painter, filters, photometry  # noqa: F401
+from . import pixell_restated, painter, filters, photometry, maps, completeness  # noqa: F401

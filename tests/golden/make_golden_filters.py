@@ -484,7 +484,64 @@ def run_find_objects():
     np.savez_compressed(os.path.join(HERE, 'find_objects.npz'), **out)
 
 
+class ColTable(object):
+    """Stands where the astropy Table stands in completeness.getRMSTab: named columns."""
+
+    def __init__(self):
+        self.cols, self.meta = {}, {}
+
+    def add_column(self, col):
+        data, name = col
+        self.cols[name] = np.asarray(data)
+
+    def __getitem__(self, name):
+        return self.cols[name]
+
+
+def rms_case(k):
+    """A noise map as the path makes them - one value per noise cell, zero outside the survey area - with an area mask with
+    holes and a flag mask."""
+    rng = np.random.default_rng(1200 + k)
+    shape = (150, 220)
+    cell = 25
+    vals = (rng.uniform(2e-5, 6e-5, (shape[0] // cell + 1, shape[1] // cell + 1)) * rng.choice([1.0, 1.0, 2.0], (7, 9))).astype(np.float32)
+    vals[2, 3] = vals[4, 1]                    # the same level in two cells
+    rms = np.repeat(np.repeat(vals, cell, axis=0), cell, axis=1)[:shape[0], :shape[1]].copy()
+    area = np.ones(shape, dtype=np.uint8)
+    area[:12, :] = 0
+    area[40:60, 100:130] = 0
+    rms[:8, :] = 0                             # (rows 8-11: noise level known, but outside the area mask)
+    rms[40:60, 100:130] = 0
+    flag = (rng.uniform(size=shape) > 0.9).astype(np.int32) * rng.integers(1, 4, shape)
+    return rms, area, flag
+
+
+def run_rms_tab():
+    """completeness.getRMSTab (nemo/completeness.py:1284-1345) and maps.getPixelAreaArcmin2Map (nemo/maps.py:1385-1406) as
+    they are; the three loaders hand over arrays instead of reading selFn/ files."""
+    from nemo import completeness
+    completeness.atpy = types.SimpleNamespace(Table=ColTable, Column=lambda data, name: (data, name))
+    wcs = CARWCS.make((150, 220), RADeg=30.0, decDeg=-35.0)
+    out = {'header': np.array(header_json(wcs)), 'ncases': np.int64(3)}
+    for k, maxFlags in enumerate([None, 1, 0]):
+        rms, area, flag = rms_case(k)
+        completeness.loadRMSMap = lambda tileName, selFnDir, photFilter: (rms.copy(), wcs)
+        completeness.loadAreaMask = lambda tileName, selFnDir: (area.copy(), wcs)
+        completeness.loadFlagMask = lambda tileName, selFnDir: (flag.copy(), wcs)
+        tab = completeness.getRMSTab('PRIMARY', 'golden', '/nonexistent/selFn', maxFlags=maxFlags)
+        p = 'c%d_' % k
+        out[p + 'RMSMap'], out[p + 'areaMask'], out[p + 'flagMask'] = rms, area, flag
+        out[p + 'maxFlags'] = np.int64(-1 if maxFlags is None else maxFlags)
+        out[p + 'areaDeg2'], out[p + 'y0RMS'] = tab['areaDeg2'], tab['y0RMS']
+        print("RMS table case %d: %d levels, %.4f deg2" % (k, len(tab['y0RMS']), tab['areaDeg2'].sum()))
+    np.savez_compressed(os.path.join(HERE, 'rms_tab.npz'), **out)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == 'rms_tab':
+        install_reference()
+        run_rms_tab()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == 'find_objects':
         install_reference()
         run_find_objects()
@@ -495,6 +552,7 @@ def main():
         run_realspace(filters, maps, tmpDir)
     run_fluxes()
     run_find_objects()
+    run_rms_tab()
     print("golden vectors written to", HERE)
 
 

@@ -188,3 +188,28 @@ def test_oracle_find_objects_equals_reference_code():
             assert np.array_equal(got.astype(cols[c].dtype), cols[c], equal_nan=cols[c].dtype.kind == 'f'), (k, c)
         seen += int((cols['ellipse_A'] > 0).sum())
     assert seen > 40
+
+
+def _rms_tab_cases():
+    import json
+    from nemo_amd.wcs import CARWCS
+    g = np.load(os.path.join(GOLDEN, 'rms_tab.npz'))
+    hdr = json.loads(str(g['header']))
+    for key in ('NAXIS', 'NAXIS1', 'NAXIS2'):
+        hdr[key] = int(hdr[key])
+    wcs = CARWCS(hdr)
+    for k in range(int(g['ncases'])):
+        p = 'c%d_' % k
+        maxFlags = int(g[p + 'maxFlags'])
+        yield wcs, g[p + 'RMSMap'], g[p + 'areaMask'], g[p + 'flagMask'], (None if maxFlags < 0 else maxFlags), g[p + 'areaDeg2'], g[p + 'y0RMS']
+
+
+def test_oracle_rms_table_equals_reference_code():
+    """completeness.getRMSTab / maps.getPixelAreaArcmin2Map run as they are (tests/golden/make_golden_filters.py) against the
+    oracle's restatement: noise levels and areas bit for bit."""
+    from nemo_oracle import completeness as ocomp
+    for wcs, rms, area, flag, maxFlags, areaDeg2, y0RMS in _rms_tab_cases():
+        gotArea, gotRMS = ocomp.get_rms_tab(rms, area, wcs, flagMask=flag, maxFlags=maxFlags)
+        assert np.array_equal(gotRMS, y0RMS) and gotRMS.dtype == y0RMS.dtype
+        assert np.array_equal(gotArea, areaDeg2)
+        assert len(y0RMS) > 40

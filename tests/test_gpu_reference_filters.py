@@ -191,3 +191,42 @@ def test_find_objects_vs_reference_code(k):
         assert np.array_equal(got[~shaped], cols[c][~shaped]), c                 # -99 rows: the same rows
         scale = 90.0 if c == 'ellipse_PA' else np.abs(cols[c][shaped])
         assert (np.abs(got[shaped] - cols[c][shaped]) / scale).max() < tol, c
+
+
+def test_rms_table_vs_reference_code():
+    """completeness.getRMSTab as the reference runs it (fixture: tests/golden/rms_tab.npz): the noise levels bit for bit, the
+    areas to 2e-6 - the reference sums float32 pixel areas pairwise in float32, the build adds the same float32 values exactly
+    (integer sums) - and the total area likewise."""
+    from test_cpu_reference_filters import _rms_tab_cases
+    from nemo_amd import completeness
+    import types
+    for wcs, rms, area, flag, maxFlags, areaDeg2, y0RMS in _rms_tab_cases():
+        config = types.SimpleNamespace(cachedRMSMapDict={'PRIMARY': rms}, areaMaskDict={'PRIMARY': area}, flagMaskDict={'PRIMARY': flag},
+                                       tileCoordsDict={'PRIMARY': {'wcs': wcs}})
+        tab = completeness.getRMSTab('PRIMARY', 'golden', None, maxFlags=maxFlags, config=config)
+        assert np.array_equal(np.asarray(tab['y0RMS']), y0RMS)
+        got = np.asarray(tab['areaDeg2'])
+        assert np.array_equal(got == 0, areaDeg2 == 0)
+        nz = areaDeg2 > 0
+        assert np.abs(got[nz] / areaDeg2[nz] - 1).max() < 2e-6
+        assert abs(got.sum() / areaDeg2.sum() - 1) < 1e-6
+
+
+def test_rms_tables_through_the_driver():
+    """pipelines.makeRMSTables after a run: per tile the table of the photFilter's noise map over the survey area, merged and
+    sorted by noise level; its area is the area of the survey mask."""
+    from nemo_amd import pipelines, startUp, maps as pmaps
+    mapsL, wcs, truth = helpers.make_tile((300, 360), seed=8, numSources=5, kind='clusters', holes=True)
+    params = {'noiseParams': {'method': 'dataMap', 'noiseGridArcmin': 20.0}, 'outputUnits': 'yc', 'edgeTrimArcmin': 0.0, 'M500MSun': 2e14, 'z': 0.4}
+    parDict = {'unfilteredMaps': [dict(m) for m in helpers.product_maps(mapsL)], 'thresholdSigma': 4.0, 'minObjPix': 1, 'photFilter': 'A',
+               'mapFilters': [{'label': 'A', 'class': 'ArnaudModelMatchedFilter', 'params': params}], 'useTiling': False, 'outputDir': None}
+    config = startUp.NemoConfig(parDict, makeOutputDirs=False, verbose=False)
+    pipelines.filterMapsAndMakeCatalogs(config, verbose=False, writeAreaMask=True, writeFlagMask=True)
+    tab = pipelines.makeRMSTables(config)
+    assert set(tab.keys()) == {'areaDeg2', 'y0RMS', 'tileName'} and len(tab) > 10
+    assert np.all(np.diff(np.asarray(tab['y0RMS'])) >= 0) and np.all(np.asarray(tab['tileName']) == 'PRIMARY')
+    areaMask = config.areaMaskDict['PRIMARY'].cpu().numpy()
+    want = (pmaps.getPixelAreaArcmin2Map(areaMask.shape, wcs) * areaMask / 3600.0).sum(dtype=np.float64)
+    rmsMap = config.cachedRMSMapDict['PRIMARY'].cpu().numpy()
+    assert ((rmsMap != 0) >= (areaMask != 0)).all()
+    assert abs(np.asarray(tab['areaDeg2']).sum() / want - 1) < 1e-6

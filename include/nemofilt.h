@@ -249,6 +249,11 @@ int nf_paint_catalog(float* out_d, int H, int W, int nObj, const double* obj_d, 
                      const double* geom_d, long long geomLen, const double* prof_d, int nProf, int ntab, int accumulate,
                      void* stream);
 
+/* MatchedFilter.reshapeFilter, nemo/filters.py:806-815: N float32 planes [H, W] sampled by linear interpolation at the
+ * fractional source positions yIdx_d[H2] x xIdx_d[W2] (outside the grid: the edge value) -> out_d [N, H2, W2]. */
+int nf_resample_bilinear(const float* in_d, float* out_d, int N, int H, int W, int H2, int W2, const double* yIdx_d,
+                         const double* xIdx_d, void* stream);
+
 /* nemo/maps.py:435-437 (subtract != 0: data -= model, flagMask += (model > 1); flagMask_d may be NULL) and :344 (subtract == 0:
  * data += model). */
 int nf_add_model(int rtype, void* data_d, const float* model_d, unsigned char* flagMask_d, long long n, int subtract,

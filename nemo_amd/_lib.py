@@ -83,6 +83,7 @@ SIGNATURES = {
                                     ctypes.POINTER(c_int), c_void_p]),
     'nf_object_stats': (c_int, [c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     'nf_object_shapes': (c_int, [c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'nf_resample_bilinear': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'nf_rms_table': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
                              c_void_p, c_void_p]),
     'nf_xmatch_workspace_bytes': (c_size_t, [c_int]),

@@ -615,6 +615,15 @@ int nf_paint_catalog(float* out, int H, int W, int nObj, const double* obj, cons
     return nf::paint_catalog(out, H, W, nObj, obj, win, geom, prof, ntab, accumulate, S(stream));
 }
 
+int nf_resample_bilinear(const float* in, float* out, int N, int H, int W, int H2, int W2, const double* yIdx, const double* xIdx,
+                         void* stream) {
+    if (!in || !out || !yIdx || !xIdx || N < 1 || H < 1 || W < 1 || H2 < 1 || W2 < 1 || H2 > 65535 || N > 65535) {
+        nf_set_error("nf_resample_bilinear: bad arguments");
+        return NF_ERR_ARG;
+    }
+    return nf::resample_bilinear(in, out, N, H, W, H2, W2, yIdx, xIdx, S(stream));
+}
+
 int nf_add_model(int rtype, void* data, const float* model, unsigned char* flagMask, long long n, int subtract, void* stream) {
     if (!data || !model || n < 1 || (rtype != NF_F32 && rtype != NF_F64)) {
         nf_set_error("nf_add_model: bad arguments");

@@ -80,6 +80,8 @@ int label_components(int vtype, const void* sn, double threshold, int negate, in
 int object_stats(int vtype, const void* sn, int negate, const int* labels, int H, int W, int numObjects, double* stats,
                  hipStream_t s);
 int object_shapes(int vtype, const void* sn, int negate, const int* labels, int H, int W, int numObjects, double* shapes, hipStream_t s);
+int resample_bilinear(const float* in, float* out, int N, int H, int W, int H2, int W2, const double* yIdx, const double* xIdx,
+                      hipStream_t s);
 int rms_table(const float* rms, const unsigned char* areaMask, const int* flagMask, int maxFlags, const unsigned char* intersect,
               const unsigned long long* rowAreaFix, int H, int W, unsigned* keys, unsigned long long* cnt, unsigned long long* area,
               int tableSize, int* overflow, hipStream_t s);

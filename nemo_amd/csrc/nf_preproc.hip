@@ -292,4 +292,31 @@ int add_model(int rtype, void* data, const float* model, unsigned char* flagMask
     return NF_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// MatchedFilter.reshapeFilter (nemo/filters.py:793-817): the float32 filter planes sampled by linear interpolation at
+// fractional index positions yIdx[y'] / xIdx[x'] of the source grid (positions outside it take the edge value).
+__global__ void k_resample_bilinear(const float* __restrict__ in, float* __restrict__ out, int H, int W, int H2, int W2,
+                                    const double* __restrict__ yIdx, const double* __restrict__ xIdx) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= W2) return;
+    const float* __restrict__ pl = in + (size_t)blockIdx.z * (size_t)H * (size_t)W;
+    double fy = fmin(fmax(yIdx[y], 0.0), (double)(H - 1)), fx = fmin(fmax(xIdx[x], 0.0), (double)(W - 1));
+    int y0 = (int)floor(fy), x0 = (int)floor(fx);
+    if (y0 > H - 2) y0 = H - 2 > 0 ? H - 2 : 0;
+    if (x0 > W - 2) x0 = W - 2 > 0 ? W - 2 : 0;
+    const int y1 = y0 + 1 < H ? y0 + 1 : y0, x1 = x0 + 1 < W ? x0 + 1 : x0;
+    const double ty = fy - (double)y0, tx = fx - (double)x0;
+    const double a = (double)pl[(size_t)y0 * W + x0], b = (double)pl[(size_t)y0 * W + x1];
+    const double c = (double)pl[(size_t)y1 * W + x0], d = (double)pl[(size_t)y1 * W + x1];
+    const double top = a + (b - a) * tx, bot = c + (d - c) * tx;
+    out[((size_t)blockIdx.z * H2 + y) * (size_t)W2 + x] = (float)(top + (bot - top) * ty);
+}
+
+int resample_bilinear(const float* in, float* out, int N, int H, int W, int H2, int W2, const double* yIdx, const double* xIdx,
+                      hipStream_t s) {
+    hipLaunchKernelGGL(k_resample_bilinear, dim3(nf_div_up(W2, 256), H2, N), dim3(256), 0, s, in, out, H, W, H2, W2, yIdx, xIdx);
+    NF_CHECK_LAUNCH("k_resample_bilinear");
+    return NF_OK;
+}
+
 }  // namespace nf

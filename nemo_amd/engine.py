@@ -717,6 +717,18 @@ class TileEngine(object):
                                         profs.shape[0], int(ntab), acc, stream_ptr()), "nf_paint_catalog")
         return out
 
+    def resample_bilinear(self, planes, H2, W2, yIdx, xIdx):
+        """float32 planes [N, H, W] sampled by linear interpolation at fractional source positions (nf_resample_bilinear)."""
+        t = self.t
+        p3 = planes.reshape(-1, self.H, self.W)
+        if p3.dtype != t.float32 or not p3.is_contiguous():
+            p3 = p3.to(t.float32).contiguous()
+        out = t.empty((p3.shape[0], int(H2), int(W2)), dtype=t.float32, device=self.dev)
+        y_d, x_d = to_dev(np.ascontiguousarray(yIdx, dtype=np.float64)), to_dev(np.ascontiguousarray(xIdx, dtype=np.float64))
+        check(self.lib.nf_resample_bilinear(ptr(p3), ptr(out), p3.shape[0], self.H, self.W, int(H2), int(W2), ptr(y_d), ptr(x_d),
+                                            stream_ptr()), "nf_resample_bilinear")
+        return out
+
     def add_model(self, data, model, flagMask=None, subtract=False):
         """data -= model, flagMask += (model > 1) (nemo/maps.py:435-437), or data += model (:344); in place."""
         check(self.lib.nf_add_model(prec_of(data), ptr(data), ptr(model), ptr(flagMask), data.numel(), 1 if subtract else 0,

@@ -591,8 +591,28 @@ class MatchedFilter(MapFilter):
         self.loadFRelWeights()
 
     def reshapeFilter(self, shape):
-        raise NotImplementedError("reshapeFilter (nemo/filters.py:793-817) is only reached when map and filter shapes "
-                                  "differ; not part of this build yet")
+        """The filter resampled to another map shape of the same pixel size by linear interpolation in multipole space
+        (nemo/filters.py:793-817): every output mode (ly', lx') is looked up at its fractional index position in the
+        filter's own mode grid.  float32 [N, H', W'] (a device tensor when RETURN_DEVICE_ARRAYS, else numpy).
+
+        The reference's interpolator (scipy.interpolate.interp2d) no longer exists in SciPy >= 1.14, and its call only
+        works for square maps (it hands the axes over transposed); restated here as what it computes there - bilinear
+        interpolation at (yOut, xOut), positions outside the grid taking the edge value.  PARITY UNPINNED."""
+        from scipy import interpolate
+        if len(shape) == 2:
+            shape = [self._dFilt.shape[0], shape[0], shape[1]]
+        assert (len(shape) == 3)
+        H, W = self.shape
+        H2, W2 = int(shape[1]), int(shape[2])
+        # enmap.laxes: multipoles of the modes along each axis, 2 pi fftfreq(n, pixel size in radians)
+        ry, rx = np.radians(self.wcs.getYPixelSizeDeg()), np.radians(self.wcs.getXPixelSizeDeg())
+        ly, lx = 2 * np.pi * np.fft.fftfreq(H, d=ry), 2 * np.pi * np.fft.fftfreq(W, d=rx)
+        lxToX = interpolate.interp1d(lx, np.arange(lx.shape[0]), fill_value='extrapolate')
+        lyToY = interpolate.interp1d(ly, np.arange(ly.shape[0]), fill_value='extrapolate')
+        xOut = lxToX(2 * np.pi * np.fft.fftfreq(W2, d=rx))
+        yOut = lyToY(2 * np.pi * np.fft.fftfreq(H2, d=ry))
+        out = self.engine.resample_bilinear(self._dFilt, H2, W2, yOut, xOut)
+        return out if RETURN_DEVICE_ARRAYS else _asnumpy(out)
 
     def _filtFor(self, half):
         """The filter as the inverse transform wants it: float32 planes, or - for half-stored spectra - their symmetrised
@@ -612,8 +632,25 @@ class MatchedFilter(MapFilter):
         optional pixel-window factor are applied while the inverse transform loads the Fourier planes."""
         eng = self.engine
         t = engine.torch()
-        if tuple(cube.shape[-2:]) != self.shape:
-            raise NotImplementedError("map / filter shape mismatch needs reshapeFilter")
+        if tuple(cube.shape[-2:]) != self.shape:                                  # :837-840
+            # another map shape: the filter is interpolated onto that shape's modes, the transforms run on its own engine
+            eng2 = engine.TileEngine.get(tuple(cube.shape[-2:]))
+            keep = RETURN_DEVICE_ARRAYS
+            globals()['RETURN_DEVICE_ARRAYS'] = True
+            try:
+                filt = self.reshapeFilter(tuple(cube.shape))
+            finally:
+                globals()['RETURN_DEVICE_ARRAYS'] = keep
+            fMaps = cube if cube.is_complex() else eng2.fft(cube, apod=True)
+            out = eng2.ifft(fMaps.reshape(-1, *cube.shape[-2:]), out='f32', unitary=False, filt=filt, sum=True, window=window)
+            if 'bckSub' in self.params.keys() and 'bckSubScaleArcmin' in self.params.keys() and self.params['bckSub'] == True:
+                out = maps.subtractBackground(out, self.wcs, smoothScaleDeg=self.params['bckSubScaleArcmin'] / 60.)
+            if scale:
+                if isinstance(self.signalNorm, np.float64):
+                    out = out.to(t.float64) * float(self.signalNorm)
+                elif float(np.float32(self.signalNorm)) != 1.0:
+                    out = out * float(np.float32(self.signalNorm))
+            return out
         if cube.is_complex():
             fMaps = cube
         else:

@@ -438,3 +438,128 @@ def templateTables(kind, beam, params, amplitude=None):
     signalDict = _profileCache[ckey]
     return makeRadialTable(signalDict['tckP'], beam=beam, amplitude=amplitude, maxSizeDeg=15.0,
                            convolveWithBeam=True, cacheKey=ckey)
+
+
+# ------------------------------------------------------------------------------------------------------------
+def _QScaleGrid(refParams, zDepQ, cosmoModel):
+    """The (z, M500) pairs the filter mismatch function is measured at (nemo/signals.py:933-998): the reference filter's own
+    scale first, then masses that give the wanted theta500 values at the listed redshifts."""
+    def massFor(theta500Arcmin, z):                                                # :947-950
+        Ez = cosmoModel.h_over_h0(1 / (1 + z))
+        criticalDensity = RHO_CRITICAL * (Ez * cosmoModel['h']) ** 2
+        R500Mpc = np.tan(np.radians(theta500Arcmin / 60.0)) * cosmoModel.angular_diameter_distance(1 / (1 + z))
+        return (4 / 3.0) * np.pi * np.power(R500Mpc, 3) * 500 * criticalDensity
+
+    MRange, zRange = [refParams['M500MSun']], [refParams['z']]
+    if zDepQ == 0:
+        theta500Arcmin_wanted = np.power(10, np.arange(np.log10(0.1), np.log10(50), 0.05055349))
+        zRange_wanted = [2.0] * 10 + [1.0] * 10 + [0.6] * 10 + [0.3] * 10 + [0.1] * 10 + [0.07] * 4
+        for theta500Arcmin, z in zip(theta500Arcmin_wanted, zRange_wanted):
+            MRange.append(massFor(theta500Arcmin, z))
+        zRange = zRange + zRange_wanted
+    else:
+        zGrid = [0.05, 0.1, 0.2, 0.3, 0.4, 0.6, 0.8, 1.0, 1.2, 1.6, 2.0]
+        theta500Arcmin_wanted = np.logspace(np.log10(0.1), np.log10(100.0), 24)
+        for z in zGrid:
+            for theta500Arcmin in theta500Arcmin_wanted:
+                MRange.append(massFor(theta500Arcmin, z))
+                zRange.append(z)
+    return zRange, MRange
+
+
+def fitQ(config, scales=None):
+    """The filter mismatch function Q on a grid of cluster scales, per tile (nemo/signals.py:897-1163): model clusters of
+    y0 = 2e-4 at the tile centre, through the pixel window, through the reference filter; Q = interpolated peak / y0.
+    Everything a scale needs - painter, window, transforms, filter, spline - runs on the device; the peaks of a tile come
+    back in one transfer.  Returns {tileName: Table(Q, theta500Arcmin, z; meta ZDEPQ, TILENAME)} sorted by theta500Arcmin,
+    the same on every rank (the reference gathers on rank 0 and writes selFn/QFit.fits, :1140-1160).
+    ``scales``: optional [(z, M500MSun)] list replacing the standard grid (the reference filter's own scale is always first)."""
+    from . import engine, catalogs, filters
+    cosmoModel = fiducialCosmoModel
+    photFilterLabel = config.parDict['photFilter']
+    ref = None
+    for f in config.parDict['mapFilters']:
+        if f['label'] == photFilterLabel:
+            ref = f
+    if ref is None:
+        raise Exception("couldn't find filter that matches photFilter")
+    if ref['class'].find("Arnaud") != -1:
+        kind, zDepQ = 'arnaud', 0
+    elif ref['class'].find("Battaglia") != -1:
+        kind, zDepQ = 'battaglia', 1
+    else:
+        raise Exception("Signal model for Q calculation should either be 'Arnaud' or 'Battaglia'")
+    if scales is None:
+        zRange, MRange = _QScaleGrid(ref['params'], zDepQ, cosmoModel)
+    else:
+        zRange = [ref['params']['z']] + [s[0] for s in scales]
+        MRange = [ref['params']['M500MSun']] + [s[1] for s in scales]
+    GNFWParams = config.parDict.get('GNFWParams', 'default')
+    t = engine.torch()
+    y0 = 2e-04
+    QTabDict = {}
+    for tileName in config.tileNames:
+        if tileName in config.cachedFilters.keys():                                # :1007-1022
+            filterObj = config.cachedFilters[tileName]
+        else:
+            filterClass = getattr(filters, ref['class'])
+            filterObj = filterClass(ref['label'], config.unfilteredMapsDictList, ref['params'], tileName=tileName,
+                                    diagnosticsDir=config.diagnosticsDir)
+            filterObj.loadFilter()
+        realSpace = isinstance(filterObj, filters.RealSpaceMatchedFilter)
+        eng = filterObj.engine
+        shape, wcs = filterObj.shape, filterObj.wcs
+        RADeg, decDeg = wcs.getCentreWCSCoords()
+        x, y = wcs.wcs2pix(RADeg, decDeg)
+        geom = paintGeometry(shape, wcs, RADeg, decDeg)
+        beams = [(m['obsFreqGHz'], m['beamFileName']) for m in config.parDict['unfilteredMaps']]       # :1031-1034
+        peaks, thetas = [], []
+        for z, M500MSun in zip(zRange, MRange):
+            planes = []
+            for obsFreqGHz, beam in beams:
+                amplitude = convertToDeltaT(y0, obsFreqGHz) if obsFreqGHz is not None else y0         # :1085-1088
+                table = clusterModelTable(kind, beam, z, M500MSun, GNFWParams if GNFWParams is not None else 'default', amplitude, 15.0)
+                planes.append(eng.apply_window(eng.paint(geom, table), 1.0))       # :1094-1099
+            cube = t.stack(planes)
+            if realSpace:
+                filteredSignal = filterObj._applyFilterDevice(cube)
+            else:
+                filteredSignal = filterObj._applyFilterDevice(eng.fft(cube, unitary=True, half=True), half=True)      # :1108-1112
+            peaks.append(eng.spline_eval(filteredSignal, [[y, x]], to_host=False))                  # :1113-1116
+            thetas.append(calcTheta500Arcmin(z, M500MSun, cosmoModel))
+        peaks = t.cat([p.reshape(1) for p in peaks]).cpu().numpy()
+        Q, QTheta500Arcmin, Qz = [], [], []
+        for p, th, z in zip(peaks, thetas, zRange):                                # :1119-1122 (a repeated peak value is dropped)
+            if p not in Q:
+                Q.append(p)
+                QTheta500Arcmin.append(th)
+                Qz.append(z)
+        Q = np.array(Q)
+        if abs(1 - Q[0] / y0) > 1e-6:
+            raise Exception("Q[0]/y0 outside tolerance")
+        Q = Q / y0
+        QTab = catalogs.Table()
+        QTab['Q'] = Q
+        QTab['theta500Arcmin'] = np.array(QTheta500Arcmin)
+        QTab['z'] = np.array(Qz)
+        QTab.sort('theta500Arcmin')
+        from . import __version__
+        QTab.meta['NEMOVER'] = __version__
+        QTab.meta['ZDEPQ'] = zDepQ
+        QTab.meta['TILENAME'] = tileName
+        QTabDict[tileName] = QTab
+    if config.MPIEnabled == True and config.size > 1:
+        from . import pipelines
+        tileIndex = {name: i for i, name in enumerate(config.allTileNames)}
+        rows = [np.stack([tab['Q'], tab['theta500Arcmin'], tab['z'], np.full(len(tab), tileIndex[name])], axis=1)
+                for name, tab in QTabDict.items()]
+        rows = pipelines._gatherRows(np.concatenate(rows) if rows else np.zeros((0, 4)), config)
+        QTabDict = {}
+        for i, name in enumerate(config.allTileNames):
+            sel = rows[:, 3] == i
+            if sel.any():
+                QTab = catalogs.Table()
+                QTab['Q'], QTab['theta500Arcmin'], QTab['z'] = rows[sel, 0], rows[sel, 1], rows[sel, 2]
+                QTab.meta.update({'ZDEPQ': zDepQ, 'TILENAME': name})
+                QTabDict[name] = QTab
+    return QTabDict

@@ -216,3 +216,35 @@ def test_cached_filter_reuse(tmp_path):
     # in the cached branch instead of promoting to float64 (numpy >= 2 scalar rules): one float32 rounding apart
     assert _rel(got2['SNMap'], got1['SNMap']) < 3e-7
     assert _rel(got2['data'], got1['data']) < 3e-7
+
+
+def test_reshape_filter_and_apply_to_another_shape():
+    """MatchedFilter.reshapeFilter / applyFilter on a map of another shape (nemo/filters.py:793-817, 837-840): the filter
+    interpolated to the new shape's modes against numpy bilinear interpolation at the same positions, then applied against
+    the numpy statement of applyFilter with that filter.  (The reference's interp2d call cannot be run any more - removed
+    from SciPy - and only ever worked for square maps: parity unpinned, see the method's docstring.)"""
+    from scipy import interpolate
+    from nemo_amd import filters as pfilters
+    from nemo_oracle import pixell_restated as enmap
+    shape = (128, 128)
+    mapsL, wcs, truth = helpers.make_tile(shape, seed=3, numSources=2, kind='clusters')
+    params = {'noiseParams': {'method': 'dataMap', 'noiseGridArcmin': 20.0}, 'outputUnits': 'yc', 'edgeTrimArcmin': 0.0,
+              'M500MSun': 2e14, 'z': 0.4}
+    f = pfilters.ArnaudModelMatchedFilter('reshape', helpers.product_maps(mapsL), params)
+    f.buildAndApply()
+    filt = np.asarray(f.filt)
+    for shape2 in [(192, 192), (96, 160)]:
+        got = np.asarray(f.reshapeFilter(shape2))
+        assert got.shape == (1,) + shape2 and got.dtype == np.float32
+        r = np.radians(wcs.getPixelSizeDeg())
+        yOut = interpolate.interp1d(np.fft.fftfreq(shape[0], d=r), np.arange(shape[0]), fill_value='extrapolate')(np.fft.fftfreq(shape2[0], d=r))
+        xOut = interpolate.interp1d(np.fft.fftfreq(shape[1], d=r), np.arange(shape[1]), fill_value='extrapolate')(np.fft.fftfreq(shape2[1], d=r))
+        want = interpolate.RegularGridInterpolator((np.arange(shape[0]), np.arange(shape[1])), filt[0].astype(np.float64), method='linear')(
+            np.stack(np.meshgrid(np.clip(yOut, 0, shape[0] - 1), np.clip(xOut, 0, shape[1] - 1), indexing='ij'), axis=-1)).astype(np.float32)
+        assert np.abs(got[0] - want).max() <= 2e-7 * np.abs(want).max()
+        rng = np.random.default_rng(9)
+        cube = rng.normal(0, 30, (1,) + shape2)
+        out = np.asarray(f.applyFilter(cube))
+        ref = np.real(enmap.ifft(enmap.fft(enmap.apod(cube, 20)) * want[None], normalize=False)).sum(axis=0).astype(np.float32) * f.signalNorm
+        assert out.shape == shape2
+        assert np.abs(out - ref).max() <= 2e-5 * np.abs(ref).max()

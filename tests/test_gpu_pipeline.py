@@ -112,3 +112,41 @@ def test_forced_photometry_in_the_driver():
     ia, ib = np.argsort(np.asarray(cat['RADeg'])), np.argsort(np.asarray(detected['RADeg']))
     ratio = np.asarray(cat['SNR'])[ia] / np.asarray(detected['SNR'])[ib]
     assert np.all(ratio > 0.8) and np.all(ratio < 1.05)
+
+
+def test_fitQ_against_the_oracle():
+    """signals.fitQ (nemo/signals.py:897-1163) after a two-frequency run: a handful of cluster scales (and the reference
+    filter's own, which must give Q = 1) painted, windowed, filtered with the reference filter and read at the centre, against
+    the same steps taken with the oracle's filter object."""
+    from scipy import interpolate
+    from nemo_amd import signals, maps as pmaps
+    from nemo_oracle import pixell_restated as enmap
+    mapsL, wcs, truth = helpers.make_tile(SHAPE, freqs=(150.0, 98.0), fwhm=(1.4, 2.1), noise=(12.0, 16.0), seed=5, numSources=6,
+                                          kind='clusters')
+    config = _config(helpers.product_maps(mapsL))
+    config.parDict['mapFilters'] = [f for f in config.parDict['mapFilters'] if f['label'] == config.parDict['photFilter']]
+    pipelines.filterMapsAndMakeCatalogs(config, verbose=False)
+    scales = [(0.3, 6e14), (0.8, 1e14), (1.5, 3e13), (0.1, 4e14)]
+    QTab = signals.fitQ(config, scales=scales)['PRIMARY']
+    assert QTab.meta['ZDEPQ'] == 0 and len(QTab) == 5
+    assert np.all(np.diff(np.asarray(QTab['theta500Arcmin'])) > 0)
+    # oracle: the same filter built by the oracle, applied to oracle-painted, oracle-windowed templates
+    lab, m, z = SCALES[0]
+    params = {'noiseParams': {'method': 'dataMap', 'noiseGridArcmin': 20.0}, 'outputUnits': 'yc', 'edgeTrimArcmin': 0.0, 'M500MSun': m, 'z': z}
+    ref, omf = helpers.oracle_matched(mapsL, wcs, params, 'arnaud')
+    RADeg, decDeg = wcs.getCentreWCSCoords()
+    x, y = wcs.wcs2pix(RADeg, decDeg)
+    geom = signals.paintGeometry(SHAPE, wcs, RADeg, decDeg)
+    want = {}
+    for zz, mm in [(z, m)] + scales:
+        cube = []
+        for mp in mapsL:
+            table = signals.clusterModelTable('arnaud', mp['beamFileName'], zz, mm, 'default', signals.convertToDeltaT(2e-4, mp['obsFreqGHz']), 15.0)
+            cube.append(enmap.fft(enmap.apply_window(helpers.cpu_paint(geom, table), pow=1.0)))
+        filtered = omf.apply(np.array(cube))
+        spl = interpolate.RectBivariateSpline(np.arange(SHAPE[0]), np.arange(SHAPE[1]), filtered, kx=3, ky=3)
+        want[signals.calcTheta500Arcmin(zz, mm, signals.fiducialCosmoModel)] = spl(y, x)[0][0] / 2e-4
+    theta = sorted(want)
+    assert np.abs(np.asarray(QTab['theta500Arcmin']) - np.array(theta)).max() < 1e-12
+    assert np.abs(np.asarray(QTab['Q']) / np.array([want[k] for k in theta]) - 1).max() < 2e-5
+    assert abs(float(np.asarray(QTab['Q'])[np.asarray(QTab['z']) == z][0]) - 1) < 1e-6

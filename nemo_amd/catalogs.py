@@ -311,6 +311,88 @@ def getCatalogWithinImage(tab, shape, wcs, mask=None):
     return tab[sel]
 
 
+def writeCatalog(catalog, outFileName, constraintsList=[]):
+    """nemo/catalogs.py:675-701: the catalogue (after the cuts) as a FITS table, or tab-delimited text for ``.csv``; the
+    build's version goes into the header as NEMOVER.  Nothing is written for an empty catalogue."""
+    from . import fitsio, __version__
+    if len(catalog) == 0:
+        return None
+    cut = selectFromCatalog(catalog, constraintsList)
+    cut.meta['NEMOVER'] = __version__
+    keys = cut.keys()
+    if outFileName.split(".")[-1] == 'csv':
+        with open(outFileName, "w") as f:
+            f.write("\t".join(keys) + "\n")
+            cols = [np.asarray(cut[k]) for k in keys]
+            for i in range(len(cut)):
+                f.write("\t".join(str(c[i]) for c in cols) + "\n")
+    else:
+        fitsio.writeTable(outFileName, {k: np.asarray(cut[k]) for k in keys}, meta=cut.meta)
+
+
+def readCatalog(fileName):
+    """A catalogue written by :func:`writeCatalog` (FITS table or tab-delimited ``.csv``) as a :class:`Table`."""
+    from . import fitsio
+    if fileName.split(".")[-1] == 'csv':
+        with open(fileName) as f:
+            lines = [ln.rstrip("\n") for ln in f if ln.strip() != ""]
+        keys = lines[0].split("\t")
+        raw = [ln.split("\t") for ln in lines[1:]]
+        cols = {}
+        for j, k in enumerate(keys):
+            vals = [r[j] for r in raw]
+            if all(v in ('True', 'False') for v in vals):
+                cols[k] = np.array([v == 'True' for v in vals])
+                continue
+            try:
+                cols[k] = np.array([int(v) for v in vals])
+            except ValueError:
+                try:
+                    cols[k] = np.array([float(v) for v in vals])
+                except ValueError:
+                    cols[k] = np.array(vals)
+        return Table(cols=cols)
+    data, header = fitsio.readTable(fileName)
+    tab = Table(cols=data)
+    if 'NEMOVER' in header:
+        tab.meta['NEMOVER'] = header['NEMOVER']
+    return tab
+
+
+def catalog2DS9(catalog, outFileName, constraintsList=[], addInfo=[], idKeyToUse='name', RAKeyToUse='RADeg', decKeyToUse='decDeg',
+                color="cyan", showNames=True, writeNemoInfo=True, coordSys='fk5', regionShape='point', width=1, radiusArcsec=360):
+    """A DS9 region file of the catalogue (nemo/catalogs.py:365-433)."""
+    import datetime
+    from . import __version__
+    cut = selectFromCatalog(catalog, constraintsList)
+    with open(outFileName, "w") as outFile:
+        comment = "# DS9 region file"
+        if writeNemoInfo == True:
+            comment = comment + " generated by nemo (version: %s on %s)\n" % (__version__, datetime.datetime.today().date().isoformat())
+        else:
+            comment = comment + "\n"
+        outFile.write(comment)
+        outFile.write('global dashlist=8 3 width=%d font="helvetica 10 normal" select=1 highlite=1 dash=0 fixed=0 edit=1 move=1 '
+                      'delete=1 include=1 source=1\n' % (width))
+        for obj in cut:
+            infoString = ""
+            if len(addInfo) > 0:
+                for d in addInfo:
+                    if infoString != "":
+                        infoString = infoString + " "
+                    infoString = infoString + d['fmt'] % (obj[d['key']])
+                infoString = " [" + infoString + "]"
+            colorString = obj['color'] if color == 'key' else color
+            if showNames == True:
+                infoString = str(obj[idKeyToUse]) + infoString
+            if regionShape == 'point':
+                outFile.write("%s;point(%.6f,%.6f) # point=cross color={%s} text={%s}\n"
+                              % (coordSys, obj[RAKeyToUse], obj[decKeyToUse], colorString, infoString))
+            elif regionShape == 'circle':
+                outFile.write('%s;circle(%.6f,%.6f,%.1f") # color={%s} text={%s}\n'
+                              % (coordSys, obj[RAKeyToUse], obj[decKeyToUse], radiusArcsec, colorString, infoString))
+
+
 def selectFromCatalog(catalog, constraintsList):
     """nemo/catalogs.py:598-617: constraints of the form "key op value" (space separated)."""
     passed = catalog

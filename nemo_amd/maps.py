@@ -161,7 +161,8 @@ class MapDict(dict):
 
 def _holeTable(entry):
     if isinstance(entry, str):
-        raise NotImplementedError("catalogues are given as nemo_amd.catalogs.Table objects (reading catalogue files needs astropy)")
+        from . import catalogs
+        return catalogs.readCatalog(entry)       # FITS table or tab-delimited .csv, as catalogs.writeCatalog writes them
     return entry
 
 
@@ -374,6 +375,131 @@ def makeModelImage(shape, wcs, catalog, beamFileName, obsFreqGHz=None, GNFWParam
     if applyPixelWindow == True:
         modelMap = eng.apply_window(modelMap.contiguous(), 1.0)
     return modelMap
+
+
+def saveFITS(outputFileName, mapData, wcs, compressionType=None):
+    """A map and its WCS header as a FITS image (nemo/maps.py:2436-2476).  ``compressionType`` names what the reference would
+    tile-compress with (PLIO_1 for masks, RICE_1): masks are written as uint8, everything uncompressed (nemo_amd.fitsio)."""
+    from . import fitsio
+    data = mapData.cpu().numpy() if _is_tensor(mapData) else np.asarray(mapData)
+    if compressionType == 'PLIO_1':
+        data = np.array(data, dtype=np.uint8)
+    fitsio.writeFITS(outputFileName, data, dict(wcs.header) if wcs is not None else {})
+
+
+class TileDict(dict):
+    """Tile images by tile name, to be saved as one multi-extension FITS file or stitched into one image
+    (nemo/maps.py:508-614).  Values may be device tensors: the stitching is done where the tiles are."""
+
+    def __init__(self, inputDict, tileCoordsDict=None):
+        super(TileDict, self).__init__(inputDict)
+        self.tileCoordsDict = tileCoordsDict
+
+    def copy(self):
+        return TileDict(self, tileCoordsDict=self.tileCoordsDict)
+
+    def _tileHeader(self, tileName):
+        if self.tileCoordsDict[tileName]['reprojectToTan'] == True:
+            raise NotImplementedError("reprojectToTan (TAN <-> CAR reprojection of tiles) is outside the hot path")
+        return self.tileCoordsDict[tileName]['header']
+
+    def saveMEF(self, outFileName, compressionType=None):
+        """nemo/maps.py:539-571: one image extension per tile, named after the tile, with the tile's WCS header."""
+        from . import fitsio
+        hdus = []
+        for tileName in self.keys():
+            data = self[tileName].cpu().numpy() if _is_tensor(self[tileName]) else np.asarray(self[tileName])
+            if compressionType is not None:
+                data = np.array(data, dtype=np.uint8 if compressionType == 'PLIO_1' else np.float32)
+            hdus.append((tileName, data, self._tileHeader(tileName)))
+        fitsio.writeMEF(outFileName, hdus)
+
+    def stitch(self, stitchedWCS):
+        """The monolithic float32 image of nemo/maps.py:592-612: tiles added into their clippedSection (overlaps add up:
+        the tiles carry zeros outside their own area)."""
+        shape = (stitchedWCS.header['NAXIS2'], stitchedWCS.header['NAXIS1'])
+        onDevice = any(_is_tensor(v) for v in self.values())
+        if onDevice:
+            t = engine.torch()
+            d = t.zeros(shape, dtype=t.float32, device=engine.require_gpu())
+        else:
+            d = np.zeros(shape, dtype=np.float32)
+        for tileName in self.keys():
+            self._tileHeader(tileName)
+            minX, maxX, minY, maxY = self.tileCoordsDict[tileName]['clippedSection']
+            tile = self[tileName]
+            if onDevice:
+                tile = engine.to_dev(tile).to(d.dtype)
+            try:
+                d[minY:maxY, minX:maxX] = d[minY:maxY, minX:maxX] + tile
+            except Exception:
+                raise Exception("Stitching error on tile %s" % (tileName))
+        return d
+
+    def saveStitchedFITS(self, outFileName, stitchedWCS, compressionType=None):
+        """nemo/maps.py:574-614."""
+        saveFITS(outFileName, self.stitch(stitchedWCS), stitchedWCS, compressionType=compressionType)
+
+
+def autotiler(surveyMask, wcs, targetTileWidth, targetTileHeight):
+    """Tile definitions ({tileName, RADecSection}) that cover the valid area of a survey mask with tiles of about the wanted
+    size in degrees (nemo/maps.py:700-825): every connected region of the mask taller than 1000 pixels is cut into rows of
+    equal height, every row into columns whose width grows with 1 / cos(dec).  Host code (once per run, on a mask)."""
+    from scipy import ndimage
+    flipper = -1 if wcs.isFlipped() == 1 else 1
+    mapCentreRA, mapCentreDec = wcs.getCentreWCSCoords()
+    skyWidth, skyHeight = wcs.getFullSizeSkyDeg()
+    handle180Wrap = (mapCentreRA < 0.1 and skyWidth < 0.1) or skyWidth > 359.9
+    segMap, numObjects = ndimage.label(np.asarray(surveyMask) > 0)
+    leftEdgeRADeg, _ = wcs.pix2wcs(0, 0)
+    rightEdgeRADeg, _ = wcs.pix2wcs(surveyMask.shape[1], 0)
+    if rightEdgeRADeg > 359.999:
+        rightEdgeRADeg = 359.999
+    tileList = []
+    for maskSection, f in zip(ndimage.find_objects(segMap), np.arange(1, numObjects + 1)):
+        yMin, yMax = maskSection[0].start, maskSection[0].stop - 1
+        if yMax - yMin < 1000:
+            continue
+        xc = int((maskSection[1].start + (maskSection[1].stop - 1)) / 2)
+        RAc, decMin = wcs.pix2wcs(xc, yMin)
+        RAc, decMax = wcs.pix2wcs(xc, yMax)
+        numRows = int((decMax - decMin) / targetTileHeight)
+        if numRows == 0:
+            raise Exception("targetTileHeight is larger than the height of the map - edit your config file accordingly.")
+        tileHeight = np.round(((decMax - decMin) / numRows) * 1000) / 1000
+        for i in range(numRows):
+            decBottom = decMin + i * tileHeight
+            decTop = decMin + (i + 1) * tileHeight
+            _, yBottom = wcs.wcs2pix(RAc, decBottom)
+            _, yTop = wcs.wcs2pix(RAc, decTop)
+            yBottom, yTop = int(yBottom), int(yTop)
+            yc = int((yTop + yBottom) / 2)
+            ys, xs = np.where(segMap[yBottom:yTop] == f)
+            xMin, xMax = xs.min(), xs.max()
+            stripWidthDeg = (xMax - xMin) * wcs.getXPixelSizeDeg()
+            RAMax, _ = wcs.pix2wcs(xMin, yc)
+            RAMin, _ = wcs.pix2wcs(xMax, yc)
+            stretchFactor = 1 / np.cos(np.radians(decTop))
+            numCols = int(stripWidthDeg / (targetTileWidth * stretchFactor))
+            for j in range(numCols):
+                tileWidth = np.ceil((stripWidthDeg / numCols) * 100) / 100
+                RALeft = RAMax - flipper * j * tileWidth
+                RARight = RAMax - flipper * (j + 1) * tileWidth
+                if RALeft < 0:
+                    RALeft = RALeft + 360
+                if RARight < 0:
+                    RARight = RARight + 360
+                if handle180Wrap == True:
+                    if RARight < 180.01 and RALeft < 180 + tileWidth and RALeft > 180.01:
+                        RARight = 180.01
+                if flipper == -1:
+                    if RARight >= rightEdgeRADeg:
+                        RARight = rightEdgeRADeg
+                    if RARight > RALeft:
+                        RALeft, RARight = RARight, RALeft
+                tileList.append({'tileName': '%d_%d_%d' % (f, i, j),
+                                 'RADecSection': [float(RARight), float(RALeft), float(decBottom), float(decTop)]})
+    return tileList
 
 
 def getPixelAreaArcmin2Map(shape, wcs, rowsOnly=False):

@@ -19,7 +19,7 @@ import time
 
 import numpy as np
 
-from . import catalogs, filters, photometry, engine, fitsio
+from . import catalogs, filters, photometry, engine, fitsio, maps
 
 # columns exchanged between ranks (fixed-width float64 rows; strings are rebuilt from indices / coordinates)
 _GATHER_COLS = ['RADeg', 'decDeg', 'SNR', 'numSigPix', 'flags', 'ringFlag', 'galacticLatDeg', 'x', 'y']
@@ -436,4 +436,48 @@ def _filterMapsAndMakeCatalogs(config, rootOutDir=None, useCachedFilters=False, 
         optimalCatalog = _gatherCatalogs(optimalCatalog, config)
         if len(optimalCatalog) > 0:
             optimalCatalog, numDuplicatesFound, names = catalogs.removeDuplicates(optimalCatalog)
+    if config.selFnDir is not None and config.filteredMapsDir is not None and config.parDict.get('writeTileProducts', True):
+        _writeTileProducts(config, photFilter, writeAreaMask, writeFlagMask)
     return optimalCatalog
+
+
+def _writeTileProducts(config, photFilter, writeAreaMask, writeFlagMask):
+    """The five per-tile products of a pass - area mask, flag mask, RMS map, filtered map, S/N map of the reference filter -
+    brought to rank 0 and written as multi-extension files and / or stitched images (nemo/pipelines.py:338-396; same file
+    names).  Tiles travel as host arrays through gather_object (the reference sends pickled dictionaries rank by rank)."""
+    fileLabel = ''
+    if config.currentFilterSet is not None and 'fileLabel' in config.filterSetOptions[config.currentFilterSet].keys() \
+            and config.filterSetOptions[config.currentFilterSet]['fileLabel'] is not None:
+        fileLabel = config.filterSetOptions[config.currentFilterSet]['fileLabel'] + '-'
+    sep = os.path.sep
+    if config.rank == 0:
+        for d in (config.selFnDir, config.filteredMapsDir):
+            os.makedirs(d, exist_ok=True)
+    products = [('area mask', config.areaMaskDict, writeAreaMask, writeAreaMask, config.selFnDir + sep + "areaMask.fits",
+                 config.selFnDir + sep + "stitched_areaMask.fits", 'PLIO_1'),
+                ('flag mask', config.flagMaskDict, writeFlagMask, writeFlagMask, config.selFnDir + sep + "flagMask.fits",
+                 config.selFnDir + sep + "stitched_flagMask.fits", 'PLIO_1'),
+                ('RMS map', config.stitchedRMSMapDict, True, True, config.selFnDir + sep + "RMSMap_%s%s.fits" % (fileLabel, photFilter),
+                 config.selFnDir + sep + "stitched_RMSMap_%s%s.fits" % (fileLabel, photFilter), None),
+                ('filtered map', config.stitchedFilteredMapDict, False, True, None,
+                 config.filteredMapsDir + sep + "stitched_%s%s_filteredMap.fits" % (fileLabel, photFilter), None),
+                ('S/N map', config.stitchedSNMapDict, False, True, None,
+                 config.filteredMapsDir + sep + "stitched_%s%s_SNMap.fits" % (fileLabel, photFilter), None)]
+    for label, tiles, writeMEF, writeStitched, MEFPath, stitchedPath, compressionType in products:
+        if not (writeMEF or writeStitched):
+            continue
+        tileDict = maps.TileDict(dict(tiles), tileCoordsDict=config.tileCoordsDict)
+        if config.MPIEnabled == True and config.size > 1:
+            import torch.distributed as dist
+            mine = {k: (v.cpu().numpy() if hasattr(v, 'is_cuda') else np.asarray(v)) for k, v in tileDict.items()}
+            gathered = [None] * config.size if config.rank == 0 else None
+            dist.gather_object(mine, gathered, dst=0)
+            if config.rank == 0:
+                for part in gathered:
+                    for tileName in part.keys():
+                        tileDict[tileName] = part[tileName]
+        if config.rank == 0 and len(tileDict) > 0:
+            if writeMEF == True and MEFPath is not None:
+                tileDict.saveMEF(MEFPath, compressionType=compressionType)
+            if writeStitched == True and stitchedPath is not None:
+                tileDict.saveStitchedFITS(stitchedPath, config.origWCS, compressionType=compressionType)

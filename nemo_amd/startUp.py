@@ -177,6 +177,12 @@ class NemoConfig(object):
         if self.MPIEnabled and divideTilesByProcesses:
             numPix = [self.tileCoordsDict[k]['numPix'] for k in self.tileNames]
             self.tileNames = assignTiles(self.tileNames, numPix, self.size)[self.rank]
+        if writeTileInfo == True and self.selFnDir is not None and self.rank == 0:           # nemo/startUp.py:689-693
+            import pickle
+            os.makedirs(self.selFnDir, exist_ok=True)
+            plain = {k: {kk: vv for kk, vv in v.items() if kk != 'wcs'} for k, v in self.tileCoordsDict.items()}
+            with open(self.selFnDir + os.path.sep + "tileCoordsDict.pkl", "wb") as pickleFile:
+                pickle.Pickler(pickleFile).dump(plain)
         if makeOutputDirs and self.diagnosticsDir is not None:
             for tileName in self.tileNames:
                 for d in [self.diagnosticsDir, self.selFnDir]:
@@ -210,6 +216,33 @@ class NemoConfig(object):
         data, header = fitsio.readFITS(name, headerOnly=True)
         return CARWCS(header), (header['NAXIS2'], header['NAXIS1'])
 
+    def addAutoTileDefinitions(self):
+        """tileDefinitions given as {mask, targetTileWidthDeg, targetTileHeightDeg} become the list maps.autotiler makes
+        (nemo/startUp.py:510-563).  ``mask``: an array (with the map's WCS), a FITS / .npy file, or None - then the area where
+        the first map is non-zero."""
+        td = self.parDict.get('tileDefinitions')
+        if type(td) != dict:
+            return
+        wcs, shape = self._mapWCS()
+        mask = td.get('mask')
+        if mask is None:
+            first = maps.MapDict(self.parDict['unfilteredMaps'][0])
+            data = first._load(first.get('mapData', first.get('mapFileName')))
+            data = data.cpu().numpy() if hasattr(data, 'is_cuda') else np.asarray(data)
+            mask = np.array(data[0] if data.ndim == 3 else data) != 0
+        elif isinstance(mask, str):
+            if mask.endswith('.npy'):
+                mask = np.load(mask)
+            else:
+                from . import fitsio
+                mask, header = fitsio.readFITS(mask)
+                wcs = CARWCS(header)
+        mask = mask.cpu().numpy() if hasattr(mask, 'is_cuda') else np.asarray(mask)
+        self.parDict['tileDefinitions'] = maps.autotiler(np.array(mask != 0, dtype=np.uint8), wcs, td['targetTileWidthDeg'],
+                                                         td['targetTileHeightDeg'])
+        if self.verbose:
+            print("... breaking map into %d tiles" % (len(self.parDict['tileDefinitions'])))
+
     def getTileCoordsDict(self):
         """nemo/startUp.py:566-661 for CAR maps: pixel sections of every tile (+ overlap on interior sides), the tile WCS
         header, the part of the tile that is kept when stitching, and its pixel count."""
@@ -220,9 +253,10 @@ class NemoConfig(object):
             out['PRIMARY'] = {'clippedSection': [0, W, 0, H], 'header': dict(wcs.header), 'wcs': wcs,
                               'areaMaskInClipSection': [0, W, 0, H], 'reprojectToTan': False, 'numPix': int(H * W)}
             return out
+        self.addAutoTileDefinitions()
         if 'tileDefinitions' not in self.parDict or type(self.parDict['tileDefinitions']) != list:
-            raise NotImplementedError("automatic tiling from a mask (maps.autotiler, nemo/maps.py:700-825) is not part of this "
-                                      "build yet: give tileDefinitions as a list of {tileName, RADecSection}")
+            raise Exception("useTiling needs tileDefinitions: a list of {tileName, RADecSection}, or {mask, targetTileWidthDeg, "
+                            "targetTileHeightDeg} for automatic tiling")
         overlapPix = self.parDict['tileOverlapDeg'] / wcs.getPixelSizeDeg()
         for tileDict in self.parDict['tileDefinitions']:
             ra0, ra1, dec0, dec1 = tileDict['RADecSection']

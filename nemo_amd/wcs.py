@@ -81,6 +81,20 @@ class CARWCS(object):
     def getPixelSizeDeg(self):
         return abs(self._cdelt2)
 
+    def isFlipped(self):
+        """1 when RA increases with x (CDELT1 > 0), as astWCS.WCS.isFlipped."""
+        return 1 if self._cdelt1 > 0 else 0
+
+    def getFullSizeSkyDeg(self):
+        """(width, height) of the map on the sky in degrees, along its central row and column."""
+        W, H = self.header['NAXIS1'], self.header['NAXIS2']
+        ra0, dec0 = self.pix2wcs(0, H / 2.0)
+        ra1, dec1 = self.pix2wcs(W - 1, H / 2.0)
+        _, decB = self.pix2wcs(W / 2.0, 0)
+        _, decT = self.pix2wcs(W / 2.0, H - 1)
+        width = abs(self._cdelt1) * (W - 1) * np.cos(np.radians(dec0))
+        return float(width), float(abs(decT - decB))
+
     def getXPixelSizeDeg(self):
         return abs(self._cdelt1)
 

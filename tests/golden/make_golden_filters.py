@@ -537,7 +537,33 @@ def run_rms_tab():
     np.savez_compressed(os.path.join(HERE, 'rms_tab.npz'), **out)
 
 
+def autotiler_mask(shape):
+    """A survey mask in two pieces with ragged edges (and a stray speck, which the tiler must skip)."""
+    mask = np.zeros(shape, dtype=np.uint8)
+    yy, xx = np.mgrid[0:shape[0], 0:shape[1]]
+    mask[(yy > 150) & (yy < 2350) & (xx > 200 + 0.05 * yy) & (xx < 2900 - 0.03 * yy)] = 1
+    mask[(yy > 400) & (yy < 1900) & (xx > 3300) & (xx < 4700 + 0.02 * yy)] = 1
+    mask[50:60, 4900:4910] = 1
+    return mask
+
+
+def run_autotiler():
+    """maps.autotiler (nemo/maps.py:700-825) as it is, on a CAR map of 2500 x 5000 half-arcmin pixels."""
+    from nemo import maps
+    shape = (2500, 5000)
+    wcs = CARWCS.make(shape, RADeg=40.0, decDeg=-10.0)
+    tiles = maps.autotiler(autotiler_mask(shape).copy(), wcs, 10.0, 5.0)
+    with open(os.path.join(HERE, 'autotiler.json'), 'w') as f:
+        json.dump({'shape': list(shape), 'RADeg': 40.0, 'decDeg': -10.0, 'targetTileWidth': 10.0, 'targetTileHeight': 5.0,
+                   'tiles': tiles}, f, indent=1)
+    print("autotiler: %d tiles" % (len(tiles)), tiles[:2])
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == 'autotiler':
+        install_reference()
+        run_autotiler()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == 'rms_tab':
         install_reference()
         run_rms_tab()
@@ -553,6 +579,7 @@ def main():
     run_fluxes()
     run_find_objects()
     run_rms_tab()
+    run_autotiler()
     print("golden vectors written to", HERE)
 
 

@@ -1,5 +1,7 @@
 """GPU tests of the driver level (nemo/pipelines.py:35-398): multi-scale run against the oracle, asynchronous vs
 synchronous detection, the cached-filter + cached-RMS re-filter mode used by source-injection runs, forced photometry."""
+import os
+
 import numpy as np
 import pytest
 
@@ -150,3 +152,33 @@ def test_fitQ_against_the_oracle():
     assert np.abs(np.asarray(QTab['theta500Arcmin']) - np.array(theta)).max() < 1e-12
     assert np.abs(np.asarray(QTab['Q']) / np.array([want[k] for k in theta]) - 1).max() < 2e-5
     assert abs(float(np.asarray(QTab['Q'])[np.asarray(QTab['z']) == z][0]) - 1) < 1e-6
+
+
+def test_driver_writes_the_tile_products(tmp_path):
+    """With an output directory the pass ends as the reference's does (nemo/pipelines.py:338-396): area / flag masks and the
+    reference filter's RMS map as multi-extension files under selFn/, stitched images of those and of the filtered and S/N
+    maps; the catalogue goes out through catalogs.writeCatalog and reads back row for row."""
+    from nemo_amd import fitsio
+    mapsL, wcs, truth = helpers.make_tile(SHAPE, seed=8, numSources=5, kind='clusters', holes=True)
+    config = _config(helpers.product_maps(mapsL), outputDir=str(tmp_path / "run"))
+    for f in config.parDict['mapFilters']:
+        if f['label'] == config.parDict['photFilter']:
+            f['params']['saveFilteredMaps'] = True
+    cat = pipelines.filterMapsAndMakeCatalogs(config, verbose=False, writeAreaMask=True, writeFlagMask=True)
+    phot = config.parDict['photFilter']
+    sel, fm = config.selFnDir, config.filteredMapsDir
+    for path in (sel + "/areaMask.fits", sel + "/flagMask.fits", sel + "/RMSMap_%s.fits" % phot, sel + "/stitched_areaMask.fits",
+                 sel + "/stitched_RMSMap_%s.fits" % phot, fm + "/stitched_%s_filteredMap.fits" % phot, fm + "/stitched_%s_SNMap.fits" % phot):
+        assert os.path.exists(path), path
+    hdus = fitsio.readHDUs(sel + "/RMSMap_%s.fits" % phot)
+    assert hdus[1][0] == 'PRIMARY' or hdus[1][0] == config.tileNames[0]
+    assert np.array_equal(hdus[1][1], config.stitchedRMSMapDict['PRIMARY'].cpu().numpy())
+    area = fitsio.readHDUs(sel + "/areaMask.fits")[1][1]
+    assert area.dtype == np.uint8 and np.array_equal(area, config.areaMaskDict['PRIMARY'].cpu().numpy())
+    sn, header = fitsio.readFITS(fm + "/stitched_%s_SNMap.fits" % phot)
+    assert sn.dtype == np.float32 and np.array_equal(sn, config.stitchedSNMapDict['PRIMARY'].cpu().numpy()) and header['CTYPE1'] == 'RA---CAR'
+    out = str(tmp_path / "cat.fits")
+    catalogs.writeCatalog(cat, out)
+    back = catalogs.readCatalog(out)
+    assert len(back) == len(cat) and list(np.asarray(back['name'])) == list(np.asarray(cat['name']))
+    assert np.array_equal(np.asarray(back['SNR']), np.asarray(cat['SNR']))

@@ -44,16 +44,36 @@ dec0, dec1 = wcs.pix2wcs(0, 0)[1], wcs.pix2wcs(0, SHAPE[0] - 1)[1]
 tileDefs = [{'tileName': 'T%%d' %% i, 'RADecSection': [ra[i + 1], ra[i], dec0, dec1]} for i in range(3)]
 SCALES = [('Arnaud_M2e14_z0p4', 2e14, 0.4), ('Arnaud_M4e14_z0p2', 4e14, 0.2)]
 base = {'noiseParams': {'method': 'dataMap', 'noiseGridArcmin': 20.0}, 'outputUnits': 'yc', 'edgeTrimArcmin': 0.0}
-filt = [{'label': lab, 'class': 'ArnaudModelMatchedFilter', 'params': dict(base, M500MSun=m, z=z)} for lab, m, z in SCALES]
+filt = [{'label': lab, 'class': 'ArnaudModelMatchedFilter', 'params': dict(base, M500MSun=m, z=z, saveFilteredMaps=(lab == SCALES[0][0]))}
+        for lab, m, z in SCALES]
 parDict = {'unfilteredMaps': [dict(m) for m in mapsL], 'thresholdSigma': 4.0, 'minObjPix': 1, 'photFilter': SCALES[0][0],
-           'mapFilters': filt, 'useTiling': True, 'tileDefinitions': tileDefs, 'tileOverlapDeg': 1.0, 'outputDir': None}
+           'mapFilters': filt, 'useTiling': True, 'tileDefinitions': tileDefs, 'tileOverlapDeg': 1.0, 'outputDir': os.environ['NF_TEST_OUT']}
 config = startUp.NemoConfig(parDict, makeOutputDirs=False, verbose=False, MPIEnabled=True)
 assert config.allTileNames == ['T0', 'T1', 'T2'] and len(config.tileNames) in (1, 2)
 mine = list(config.tileNames)
 both = [None, None]
 dist.all_gather_object(both, mine)
 assert sorted(both[0] + both[1]) == ['T0', 'T1', 'T2'] and not set(both[0]) & set(both[1])      # every tile on exactly one rank
-cat = pipelines.filterMapsAndMakeCatalogs(config, verbose=False)
+cat = pipelines.filterMapsAndMakeCatalogs(config, verbose=False, writeAreaMask=True)
+# the tile products of BOTH ranks reach rank 0's files (nemo/pipelines.py:338-396): three extensions, and a stitched S/N map
+# whose every tile area holds that tile's map
+rmsTab = pipelines.makeRMSTables(config)
+assert set(np.unique(rmsTab['tileName'])) == {'T0', 'T1', 'T2'}            # rows of every rank's tiles, on every rank
+if rank == 0:
+    from nemo_amd import fitsio
+    hdus = fitsio.readHDUs(config.selFnDir + "/RMSMap_%%s.fits" %% SCALES[0][0])
+    assert sorted(h[0] for h in hdus[1:]) == ['T0', 'T1', 'T2']
+    sn, hdr = fitsio.readFITS(config.filteredMapsDir + "/stitched_%%s_SNMap.fits" %% SCALES[0][0])
+    assert sn.shape == SHAPE
+    for tileName in config.tileNames:
+        x0, x1, y0, y1 = config.tileCoordsDict[tileName]['clippedSection']
+        ax0, ax1, ay0, ay1 = config.tileCoordsDict[tileName]['areaMaskInClipSection']
+        mine = config.stitchedSNMapDict[tileName].cpu().numpy()
+        assert np.array_equal(sn[y0 + ay0:y0 + ay1, x0 + ax0:x0 + ax1], mine[ay0:ay1, ax0:ax1])
+    for tileName in config.allTileNames:                                  # the other rank's tiles arrived too
+        x0, x1, y0, y1 = config.tileCoordsDict[tileName]['clippedSection']
+        ax0, ax1, ay0, ay1 = config.tileCoordsDict[tileName]['areaMaskInClipSection']
+        assert (sn[y0 + ay0:y0 + ay1, x0 + ax0:x0 + ax1] != 0).mean() > 0.5, tileName
 # every rank holds the same merged catalogue
 sig = [None, None]
 dist.all_gather_object(sig, (len(cat), float(np.sum(cat['RADeg'])), float(np.sum(cat['SNR']))))
@@ -116,7 +136,7 @@ def test_tiled_two_rank_run_matches_the_oracle(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(_WORKER % {'root': ROOT})
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29653", HSA_ENABLE_IPC_MODE_LEGACY="0",
-               NEMO_AMD_DIST_BACKEND="gloo", OMP_NUM_THREADS="4")
+               NEMO_AMD_DIST_BACKEND="gloo", OMP_NUM_THREADS="4", NF_TEST_OUT=str(tmp_path / "run"))
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
                         "--master-port", "29653", str(script)], env=env, capture_output=True, text=True, timeout=280)
     assert r.returncode == 0 and "tiled ok" in r.stdout, r.stdout[-3000:] + r.stderr[-5000:]

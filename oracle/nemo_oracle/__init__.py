@@ -5,15 +5,17 @@ TEST INFRASTRUCTURE ONLY.  This package is a numpy/scipy restatement of the refe
 ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` - never by the product
 package ``nemo_amd`` (which must fail loudly when its HIP library is missing).
 
-Pinning status (see DESIGN.md §Oracle):
+Pinning status (see DESIGN.md section 4):
 
-* numpy/scipy-only reference functions (``photometry.getObjectPositions``, ``MapFilter.makeNoiseMap``,
-  ``RealSpaceMatchedFilter.applyFilter`` without bckSub) are pinned against the reference itself, run in
-  the build container through a stub importer (``tests/golden/make_golden.py``), with the vectors
-  committed under ``tests/golden/``.
-* everything that goes through pixell / astLib / pyccl in the reference (FFT normalisation, apodisation,
-  pixel window, template painter, WCS) is restated from the published behaviour of those packages:
-  PARITY UNPINNED for those pieces (none of them is available offline, and the reference holds no
-  golden vectors).
+* the reference's own classes and functions - ``filters.filterMaps`` / ``MatchedFilter.buildAndApply``,
+  ``RealSpaceMatchedFilter.buildKernel / buildAndApply / applyFilter``, ``MapFilter.makeNoiseMap``,
+  ``photometry.getObjectPositions / findObjects / measureFluxes / getSNRValues``, ``completeness.getRMSTab``,
+  ``maps.getPixelAreaArcmin2Map``, ``gnfw`` - were run unmodified in the build container through a stub importer
+  (``tests/golden/make_golden.py``, ``make_golden_filters.py``) with only their third-party calls served from outside;
+  the vectors are committed under ``tests/golden/`` and this package reproduces them bit for bit
+  (``tests/test_cpu_oracle_golden.py``, ``tests/test_cpu_reference_filters.py``).
+* what the reference delegates to pixell / astLib / pyccl (FFT normalisation, apodisation, pixel window, template painter,
+  WCS, cosmology) is restated from the published behaviour of those packages: PARITY UNPINNED for those calls only (none
+  of them is available offline, and the reference holds no golden vectors).
 """
 from . import pixell_restated, painter, filters, photometry, maps, completeness  # noqa: F401

@@ -274,6 +274,19 @@ int nf_label_components(int vtype, const void* sn_d, double threshold, int negat
 int nf_object_stats(int vtype, const void* sn_d, int negate, const int* labels_d, int H, int W, int numObjects,
                     double* stats_d, void* stream);
 
+/* The two calls above for a caller that labels map after map of one shape (nemo/pipelines.py:267-289: every filter scale of
+ * every tile) and at a threshold where almost no pixel is foreground:
+ *   nf_label_components_kept   labels_d is KEPT by the caller between calls, together with dirty_d (one int per 1024-pixel
+ *       chunk, nf_div_up(H*W, 1024) of them; both zero before the first call): the call clears only the chunks the previous
+ *       call wrote and writes only the chunks that hold foreground now - same labels as nf_label_components;
+ *   nf_object_stats_chunks     chunkFlags_d = work_d + nf_label_chunk_flags_offset(H, W) of the labelling call that made
+ *       labels_d: chunks without foreground are skipped after one flag - same records as nf_object_stats. */
+long long nf_label_chunk_flags_offset(int H, int W);
+int nf_label_components_kept(int vtype, const void* sn_d, double threshold, int negate, int* labels_d, int H, int W,
+                             int* work_d, int* dirty_d, int* numObjects, void* stream);
+int nf_object_stats_chunks(int vtype, const void* sn_d, int negate, const int* labels_d, int H, int W, int numObjects,
+                           double* stats_d, const int* chunkFlags_d, void* stream);
+
 /* The segment moments behind measureShapes (photometry.findObjects, nemo/photometry.py:136-150): per label id 0..numObjects
  * a record of 10 doubles {xMin, yMin, xMax, yMax, S, Sx, Sy, Sxx, Syy, Sxy} with S = sum v, Sx = sum v*(x - xMin),
  * Sxx = sum v*(x - xMin)^2 ... over the segment's pixels (v as in nf_object_stats: exact integer sums of v * 2^40).

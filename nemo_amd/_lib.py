@@ -82,6 +82,9 @@ SIGNATURES = {
     'nf_label_components': (c_int, [c_int, c_void_p, c_double, c_int, c_void_p, c_int, c_int, c_void_p,
                                     ctypes.POINTER(c_int), c_void_p]),
     'nf_object_stats': (c_int, [c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'nf_label_chunk_flags_offset': (ctypes.c_longlong, [c_int, c_int]),
+    'nf_label_components_kept': (c_int, [c_int, c_void_p, c_double, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'nf_object_stats_chunks': (c_int, [c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'nf_object_shapes': (c_int, [c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     'nf_resample_bilinear': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'nf_rms_table': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,

@@ -639,7 +639,7 @@ int nf_label_components(int vtype, const void* sn, double threshold, int negate,
         return NF_ERR_ARG;
     }
     nf::ProfScope ps(nf::PT_LABEL, S(stream), (double)H * W * ((vtype == NF_F32 ? 4.0 : 8.0) + 4.0));
-    return nf::label_components(vtype, sn, threshold, negate, labels, H, W, work, numObjects, S(stream));
+    return nf::label_components(vtype, sn, threshold, negate, labels, H, W, work, numObjects, nullptr, S(stream));
 }
 
 int nf_object_stats(int vtype, const void* sn, int negate, const int* labels, int H, int W, int numObjects, double* stats,
@@ -649,7 +649,29 @@ int nf_object_stats(int vtype, const void* sn, int negate, const int* labels, in
         return NF_ERR_ARG;
     }
     nf::ProfScope ps(nf::PT_OBJECT_STATS, S(stream), (double)H * W * ((vtype == NF_F32 ? 4.0 : 8.0) + 4.0));
-    return nf::object_stats(vtype, sn, negate, labels, H, W, numObjects, stats, S(stream));
+    return nf::object_stats(vtype, sn, negate, labels, H, W, numObjects, stats, nullptr, S(stream));
+}
+
+long long nf_label_chunk_flags_offset(int H, int W) { return nf::label_chunk_flags_offset(H, W); }
+
+int nf_label_components_kept(int vtype, const void* sn, double threshold, int negate, int* labels, int H, int W, int* work,
+                             int* dirty, int* numObjects, void* stream) {
+    if (!sn || !labels || !work || !dirty || !numObjects || H < 1 || W < 1) {
+        nf_set_error("nf_label_components_kept: bad arguments");
+        return NF_ERR_ARG;
+    }
+    nf::ProfScope ps(nf::PT_LABEL, S(stream), (double)H * W * (vtype == NF_F32 ? 4.0 : 8.0));
+    return nf::label_components(vtype, sn, threshold, negate, labels, H, W, work, numObjects, dirty, S(stream));
+}
+
+int nf_object_stats_chunks(int vtype, const void* sn, int negate, const int* labels, int H, int W, int numObjects, double* stats,
+                           const int* chunkFlags, void* stream) {
+    if (!sn || !labels || !stats || !chunkFlags || H < 1 || W < 1 || numObjects < 0) {
+        nf_set_error("nf_object_stats_chunks: bad arguments");
+        return NF_ERR_ARG;
+    }
+    nf::ProfScope ps(nf::PT_OBJECT_STATS, S(stream), (double)H * W * 4.0 / 1024.0);
+    return nf::object_stats(vtype, sn, negate, labels, H, W, numObjects, stats, chunkFlags, S(stream));
 }
 
 int nf_object_shapes(int vtype, const void* sn, int negate, const int* labels, int H, int W, int numObjects, double* shapes,

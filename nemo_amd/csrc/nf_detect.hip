@@ -46,17 +46,21 @@ __global__ void __launch_bounds__(256) k_ccl_init(const VT* __restrict__ sn, VT 
                                                   long long n, int* __restrict__ chunkFG) {
     const long long base = (long long)blockIdx.x * NF_SCAN_CHUNK;
     int any = 0;
+    bool fg[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const long long p = base + j * 256 + threadIdx.x;
-        if (p < n) {
-            const bool fg = is_fg<VT>(sn, p, thr, negate);
-            parent[p] = fg ? (int)p : -1;
-            any |= fg ? 1 : 0;
-        }
+        fg[j] = p < n && is_fg<VT>(sn, p, thr, negate);
+        any |= fg[j] ? 1 : 0;
     }
     any = __syncthreads_or(any);
     if (threadIdx.x == 0) chunkFG[blockIdx.x] = any;
+    if (!any) return;            // nobody reads `parent` inside a chunk without foreground (every pass asks chunkFG first)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const long long p = base + j * 256 + threadIdx.x;
+        if (p < n) parent[p] = fg[j] ? (int)p : -1;
+    }
 }
 
 __device__ __forceinline__ int uf_find(const int* parent, int x) {
@@ -91,8 +95,9 @@ __global__ void __launch_bounds__(256) k_ccl_merge(int* __restrict__ parent, int
         const long long p = base + j * 256 + threadIdx.x;
         if (p >= n || parent[p] < 0) continue;
         int x = (int)(p % W);
-        if (x > 0 && parent[p - 1] >= 0) uf_union(parent, (int)p, (int)(p - 1));
-        if (p >= W && parent[p - W] >= 0) uf_union(parent, (int)p, (int)(p - W));
+        // (a neighbour in a chunk without foreground is background: its `parent` entry was never written)
+        if (x > 0 && chunkFG[(p - 1) / NF_SCAN_CHUNK] && parent[p - 1] >= 0) uf_union(parent, (int)p, (int)(p - 1));
+        if (p >= W && chunkFG[(p - W) / NF_SCAN_CHUNK] && parent[p - W] >= 0) uf_union(parent, (int)p, (int)(p - W));
     }
 }
 
@@ -196,17 +201,24 @@ __global__ void __launch_bounds__(256) k_number_roots(const int* __restrict__ pa
     }
 }
 
+// `dirty` (optional): the caller keeps `labels` between calls - zero everywhere except in chunks whose dirty flag is set (they
+// held foreground in the previous call).  A chunk without foreground is then cleared only if it is dirty, and the flags are
+// brought up to date: the pass writes what the foreground touches, not the whole map.
 __global__ void __launch_bounds__(256) k_relabel(const int* __restrict__ parent, int* __restrict__ labels, long long n,
-                                                 const int* __restrict__ chunkFG) {
+                                                 const int* __restrict__ chunkFG, int* __restrict__ dirty) {
     const long long base = (long long)blockIdx.x * NF_SCAN_CHUNK;
     if (!chunkFG[blockIdx.x]) {
+        if (dirty == nullptr || dirty[blockIdx.x]) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const long long p = base + j * 256 + threadIdx.x;
-            if (p < n) labels[p] = 0;
+            for (int j = 0; j < 4; ++j) {
+                const long long p = base + j * 256 + threadIdx.x;
+                if (p < n) labels[p] = 0;
+            }
         }
+        if (dirty != nullptr && threadIdx.x == 0) dirty[blockIdx.x] = 0;
         return;
     }
+    if (dirty != nullptr && threadIdx.x == 0) dirty[blockIdx.x] = 1;
     for (int j = 0; j < 4; ++j) {
         const long long p = base + j * 256 + threadIdx.x;
         if (p >= n) continue;
@@ -218,8 +230,13 @@ __global__ void __launch_bounds__(256) k_relabel(const int* __restrict__ parent,
     }
 }
 
+long long label_chunk_flags_offset(int H, int W) {
+    const long long n = (long long)H * W;
+    return n + nf_div_up(n, NF_SCAN_CHUNK) + 1;
+}
+
 int label_components(int vtype, const void* sn, double threshold, int negate, int* labels, int H, int W, int* work,
-                     int* numObjects, hipStream_t s) {
+                     int* numObjects, int* dirty, hipStream_t s) {
     const long long n = (long long)H * W;
     if (n >= 2147483647LL) {
         nf_set_error("label_components: map too large for 32-bit pixel indices");
@@ -238,7 +255,7 @@ int label_components(int vtype, const void* sn, double threshold, int negate, in
     hipLaunchKernelGGL(k_ccl_flatten_count, g, b, 0, s, parent, n, chunkFG, blockCounts);
     hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, s, blockCounts, nblocks);
     hipLaunchKernelGGL(k_number_roots, g, b, 0, s, parent, n, blockCounts, chunkFG, labels);
-    hipLaunchKernelGGL(k_relabel, g, b, 0, s, parent, labels, n, chunkFG);
+    hipLaunchKernelGGL(k_relabel, g, b, 0, s, parent, labels, n, chunkFG, dirty);
     NF_CHECK_LAUNCH("label_components");
     NF_HIP(hipMemcpyAsync(numObjects, blockCounts + nblocks, sizeof(int), hipMemcpyDeviceToHost, s));
     NF_HIP(hipStreamSynchronize(s));
@@ -281,53 +298,62 @@ __device__ __forceinline__ unsigned long long ordered_key(double v) {
     return (b & 0x8000000000000000ULL) ? ~b : (b | 0x8000000000000000ULL);
 }
 
+// One workgroup per 1024-pixel chunk (chunkFG, from the labelling pass, when the caller has it: a chunk without foreground
+// costs one flag); a thread takes 4 consecutive pixels and flushes one entry per run of equal labels within a row.
 template <typename VT>
-__global__ void k_object_sums(const VT* __restrict__ sn, int negate, const int* __restrict__ labels, int H, int W,
-                              double* __restrict__ stats, unsigned long long* __restrict__ limbs,
-                              unsigned long long* __restrict__ maxKey) {
-    const int segsPerRow = (W + NF_RUN - 1) / NF_RUN;
-    const long long nseg = (long long)H * segsPerRow;
-    for (long long sidx = blockIdx.x * (long long)blockDim.x + threadIdx.x; sidx < nseg; sidx += (long long)gridDim.x * blockDim.x) {
-        int y = (int)(sidx / segsPerRow);
-        int x0 = (int)(sidx % segsPerRow) * NF_RUN;
-        int cur = 0;
-        double cnt = 0, mx = 0;
-        unsigned __int128 sv = 0, svy = 0, svx = 0;
-        for (int j = 0; j < NF_RUN && x0 + j < W; ++j) {
-            long long p = (long long)y * W + x0 + j;
-            int id = labels[p];
-            if (id != cur) {
-                if (cur > 0) {
-                    flush_run(stats, limbs, cur, cnt, sv, svy, svx);
-                    atomicMax(&maxKey[cur], ordered_key(mx));
-                }
-                cur = id;
-                cnt = 0;
-                sv = svy = svx = 0;
-                mx = -INFINITY;
+__global__ void __launch_bounds__(256) k_object_sums(const VT* __restrict__ sn, int negate, const int* __restrict__ labels, int H, int W,
+                                                     double* __restrict__ stats, unsigned long long* __restrict__ limbs,
+                                                     unsigned long long* __restrict__ maxKey, const int* __restrict__ chunkFG) {
+    if (chunkFG != nullptr && !chunkFG[blockIdx.x]) return;
+    const long long n = (long long)H * W, p0 = (long long)blockIdx.x * NF_SCAN_CHUNK + threadIdx.x * 4;
+    if (p0 >= n) return;
+    int y = (int)(p0 / W), x = (int)(p0 - (long long)y * W);
+    int cur = 0;
+    double cnt = 0, mx = 0;
+    unsigned __int128 sv = 0, svy = 0, svx = 0;
+    for (int j = 0; j < 4 && p0 + j < n; ++j) {
+        const int id = labels[p0 + j];
+        if (id != cur) {
+            if (cur > 0) {
+                flush_run(stats, limbs, cur, cnt, sv, svy, svx);
+                atomicMax(&maxKey[cur], ordered_key(mx));
             }
-            if (id > 0) {
-                double v = (double)sn[p];
-                if (negate) v = -v;
-                const unsigned long long iv = (unsigned long long)rint(fmin(fmax(v, 0.0), NF_FIX_VMAX) * (double)(1ULL << NF_FIX_SHIFT));
-                cnt += 1.0;
-                sv += iv;
-                svy += (unsigned __int128)iv * (unsigned)y;
-                svx += (unsigned __int128)iv * (unsigned)(x0 + j);
-                mx = fmax(mx, v);
-            }
+            cur = id;
+            cnt = 0;
+            sv = svy = svx = 0;
+            mx = -INFINITY;
         }
-        if (cur > 0) {
-            flush_run(stats, limbs, cur, cnt, sv, svy, svx);
-            atomicMax(&maxKey[cur], ordered_key(mx));
+        if (id > 0) {
+            double v = (double)sn[p0 + j];
+            if (negate) v = -v;
+            const unsigned long long iv = (unsigned long long)rint(fmin(fmax(v, 0.0), NF_FIX_VMAX) * (double)(1ULL << NF_FIX_SHIFT));
+            cnt += 1.0;
+            sv += iv;
+            svy += (unsigned __int128)iv * (unsigned)y;
+            svx += (unsigned __int128)iv * (unsigned)x;
+            mx = fmax(mx, v);
         }
+        if (++x == W) {
+            x = 0;
+            ++y;
+        }
+    }
+    if (cur > 0) {
+        flush_run(stats, limbs, cur, cnt, sv, svy, svx);
+        atomicMax(&maxKey[cur], ordered_key(mx));
     }
 }
 
 template <typename VT>
-__global__ void k_object_argmax(const VT* __restrict__ sn, int negate, const int* __restrict__ labels, long long n,
-                                const unsigned long long* __restrict__ maxKey, unsigned long long* __restrict__ argmax) {
-    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x) {
+__global__ void __launch_bounds__(256) k_object_argmax(const VT* __restrict__ sn, int negate, const int* __restrict__ labels, long long n,
+                                                       const unsigned long long* __restrict__ maxKey, unsigned long long* __restrict__ argmax,
+                                                       const int* __restrict__ chunkFG) {
+    if (chunkFG != nullptr && !chunkFG[blockIdx.x]) return;
+    const long long base = (long long)blockIdx.x * NF_SCAN_CHUNK;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const long long p = base + j * 256 + threadIdx.x;
+        if (p >= n) continue;
         int id = labels[p];
         if (id <= 0) continue;
         double v = (double)sn[p];
@@ -361,7 +387,7 @@ __global__ void k_stats_finish(double* __restrict__ stats, const unsigned long l
 // `stats` must hold (numObjects+1) * 17 doubles: 6 per record, then scratch - the 9 integer limbs, the maximum key and the
 // argmax of every label
 int object_stats(int vtype, const void* sn, int negate, const int* labels, int H, int W, int numObjects, double* stats,
-                 hipStream_t s) {
+                 const int* chunkFG, hipStream_t s) {
     const long long n = (long long)H * W;
     const size_t nrec = (size_t)numObjects + 1;
     unsigned long long* limbs = (unsigned long long*)(stats + nrec * NF_STAT_STRIDE);
@@ -369,14 +395,13 @@ int object_stats(int vtype, const void* sn, int negate, const int* labels, int H
     unsigned long long* argmax = maxKey + nrec;
     NF_HIP(hipMemsetAsync(stats, 0, nrec * (NF_STAT_STRIDE + NF_LIMB_WORDS + 1) * sizeof(double), s));
     NF_HIP(hipMemsetAsync(argmax, 0xFF, nrec * sizeof(unsigned long long), s));
-    const long long nseg = (long long)H * ((W + NF_RUN - 1) / NF_RUN);
-    dim3 g(grid_for(nseg, 256)), b(256), gp(grid_for(n, 256));
+    dim3 g(nf_div_up(n, NF_SCAN_CHUNK)), b(256);
     if (vtype == NF_F64) {
-        hipLaunchKernelGGL(k_object_sums<double>, g, b, 0, s, (const double*)sn, negate, labels, H, W, stats, limbs, maxKey);
-        hipLaunchKernelGGL(k_object_argmax<double>, gp, b, 0, s, (const double*)sn, negate, labels, n, maxKey, argmax);
+        hipLaunchKernelGGL(k_object_sums<double>, g, b, 0, s, (const double*)sn, negate, labels, H, W, stats, limbs, maxKey, chunkFG);
+        hipLaunchKernelGGL(k_object_argmax<double>, g, b, 0, s, (const double*)sn, negate, labels, n, maxKey, argmax, chunkFG);
     } else {
-        hipLaunchKernelGGL(k_object_sums<float>, g, b, 0, s, (const float*)sn, negate, labels, H, W, stats, limbs, maxKey);
-        hipLaunchKernelGGL(k_object_argmax<float>, gp, b, 0, s, (const float*)sn, negate, labels, n, maxKey, argmax);
+        hipLaunchKernelGGL(k_object_sums<float>, g, b, 0, s, (const float*)sn, negate, labels, H, W, stats, limbs, maxKey, chunkFG);
+        hipLaunchKernelGGL(k_object_argmax<float>, g, b, 0, s, (const float*)sn, negate, labels, n, maxKey, argmax, chunkFG);
     }
     hipLaunchKernelGGL(k_stats_finish, dim3(grid_for(nrec, 256)), dim3(256), 0, s, stats, limbs, maxKey, argmax, numObjects);
     NF_CHECK_LAUNCH("object_stats");

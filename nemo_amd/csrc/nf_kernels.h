@@ -75,10 +75,11 @@ int noise_map_smart(int vtype, const void* filtered, const void* weights, int wt
 int median_stack(int rtype, const void* in, void* out, int N, long long n, hipStream_t s);
 
 // nf_detect.hip
+long long label_chunk_flags_offset(int H, int W);
 int label_components(int vtype, const void* sn, double threshold, int negate, int* labels, int H, int W, int* work,
-                     int* numObjects, hipStream_t s);
+                     int* numObjects, int* dirty, hipStream_t s);
 int object_stats(int vtype, const void* sn, int negate, const int* labels, int H, int W, int numObjects, double* stats,
-                 hipStream_t s);
+                 const int* chunkFG, hipStream_t s);
 int object_shapes(int vtype, const void* sn, int negate, const int* labels, int H, int W, int numObjects, double* shapes, hipStream_t s);
 int resample_bilinear(const float* in, float* out, int N, int H, int W, int H2, int W2, const double* yIdx, const double* xIdx,
                       hipStream_t s);

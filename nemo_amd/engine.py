@@ -6,6 +6,7 @@ and exposes one thin method per C-ABI entry point.  Nothing here computes on the
 """
 import ctypes
 import os
+import threading
 
 import numpy as np
 
@@ -211,6 +212,8 @@ class TileEngine(object):
         self.apodY, self.apodX = tabs
         self._win = {}
         self._axisWin = {}
+        self._keptLabels = {}       # (thread, slot) -> (labels, dirty flags) kept between label() calls
+        self._chunkFlags = {}       # labels.data_ptr() -> foreground flags per chunk of the call that made them
         self._gauss = {}
         self._geom = {}
         self._geomLast = None
@@ -424,9 +427,11 @@ class TileEngine(object):
             raise NemoFiltError("apply_window: zero_ref must be one contiguous map of the map's dtype")
         out = t.empty_like(m3)
         ty = 1 if m.dtype == t.float64 else 2
-        check(self.lib.nf_axis_filter(self.plan, prec, 0, ptr(m3), ty, ptr(out), ty, m3.shape[0], ptr(tabs[0]), None, stream_ptr()),
+        # columns first: the rows pass (two workgroups per CU, contiguous runs) is the one that can afford the extra read of
+        # the zero reference
+        check(self.lib.nf_axis_filter(self.plan, prec, 1, ptr(m3), ty, ptr(out), ty, m3.shape[0], ptr(tabs[1]), None, stream_ptr()),
               "nf_axis_filter")
-        check(self.lib.nf_axis_filter(self.plan, prec, 1, ptr(out), ty, ptr(out), ty, m3.shape[0], ptr(tabs[1]), ptr(zero_ref),
+        check(self.lib.nf_axis_filter(self.plan, prec, 0, ptr(out), ty, ptr(out), ty, m3.shape[0], ptr(tabs[0]), ptr(zero_ref),
                                       stream_ptr()), "nf_axis_filter")
         return out.reshape(m.shape)
 
@@ -736,20 +741,43 @@ class TileEngine(object):
         return data
 
     # ---- detection -----------------------------------------------------------------------------------------
-    def label(self, sn, threshold, negate=False):
+    def label(self, sn, threshold, negate=False, slot=None):
+        """scipy.ndimage.label numbering of (map > threshold): (labels tensor, number of objects).  ``slot`` (any hashable):
+        the labels live in a buffer the engine keeps for this thread and slot - valid until the next call with the same slot
+        - which is cleared and written only where foreground was / is (nf_label_components_kept); without it a new tensor."""
         t = self.t
-        labels = t.empty((self.H, self.W), dtype=t.int32, device=self.dev)
-        work = t.empty(self.npix + 2 * (self.npix // 1024) + 16, dtype=t.int32, device=self.dev)
+        nchunks = (self.npix + 1023) // 1024
+        work = t.empty(self.npix + 2 * nchunks + 16, dtype=t.int32, device=self.dev)
         n = ctypes.c_int(0)
-        check(self.lib.nf_label_components(prec_of(sn), ptr(sn), float(threshold), 1 if negate else 0, ptr(labels), self.H,
-                                           self.W, ptr(work), ctypes.byref(n), stream_ptr()), "nf_label_components")
+        if slot is None:
+            labels = t.empty((self.H, self.W), dtype=t.int32, device=self.dev)
+            check(self.lib.nf_label_components(prec_of(sn), ptr(sn), float(threshold), 1 if negate else 0, ptr(labels), self.H,
+                                               self.W, ptr(work), ctypes.byref(n), stream_ptr()), "nf_label_components")
+        else:
+            key = (threading.get_ident(), slot)
+            if key not in self._keptLabels:
+                self._keptLabels[key] = (t.zeros((self.H, self.W), dtype=t.int32, device=self.dev),
+                                         t.zeros(nchunks, dtype=t.int32, device=self.dev))
+            labels, dirty = self._keptLabels[key]
+            check(self.lib.nf_label_components_kept(prec_of(sn), ptr(sn), float(threshold), 1 if negate else 0, ptr(labels), self.H,
+                                                    self.W, ptr(work), ptr(dirty), ctypes.byref(n), stream_ptr()),
+                  "nf_label_components_kept")
+        off = int(self.lib.nf_label_chunk_flags_offset(self.H, self.W))
+        if len(self._chunkFlags) > 16:
+            self._chunkFlags.clear()         # (labels whose statistics were never asked for)
+        self._chunkFlags[labels.data_ptr()] = work[off:off + nchunks]        # (keeps `work` alive for object_stats)
         return labels, n.value
 
     def object_stats(self, sn, labels, numObjects, negate=False):
         t = self.t
         stats = t.empty((numObjects + 1) * 17, dtype=t.float64, device=self.dev)      # NF_OBJECT_STATS_DOUBLES
-        check(self.lib.nf_object_stats(prec_of(sn), ptr(sn), 1 if negate else 0, ptr(labels), self.H, self.W, numObjects,
-                                       ptr(stats), stream_ptr()), "nf_object_stats")
+        flags = self._chunkFlags.pop(labels.data_ptr(), None)        # the foreground flags of the call that made these labels
+        if flags is not None:
+            check(self.lib.nf_object_stats_chunks(prec_of(sn), ptr(sn), 1 if negate else 0, ptr(labels), self.H, self.W, numObjects,
+                                                  ptr(stats), ptr(flags), stream_ptr()), "nf_object_stats_chunks")
+        else:
+            check(self.lib.nf_object_stats(prec_of(sn), ptr(sn), 1 if negate else 0, ptr(labels), self.H, self.W, numObjects,
+                                           ptr(stats), stream_ptr()), "nf_object_stats")
         return stats[:(numObjects + 1) * 6].reshape(numObjects + 1, 6)
 
     def object_shapes(self, sn, labels, numObjects, negate=False):

@@ -41,9 +41,10 @@ def _mark(key, t0):
     return t0
 
 
-def _segment(eng, dMap, threshold, findCenterOfMass=True, negate=False):
-    """Device part of getObjectPositions; returns (numObjects, labels tensor, stats tensor [n+1, 6])."""
-    labels, numObjects = eng.label(dMap, threshold, negate=negate)
+def _segment(eng, dMap, threshold, findCenterOfMass=True, negate=False, slot=None):
+    """Device part of getObjectPositions; returns (numObjects, labels tensor, stats tensor [n+1, 6]).  ``slot``: the labels
+    may live in the engine's kept buffer of that name (they are not handed to the caller)."""
+    labels, numObjects = eng.label(dMap, threshold, negate=negate, slot=slot)
     stats = eng.object_stats(dMap, labels, numObjects, negate=negate)
     return numObjects, labels, stats
 
@@ -139,7 +140,7 @@ def findObjects(filteredMapDict, threshold=3.0, minObjPix=3, rejectBorder=10, fi
 
     import time
     tm = time.perf_counter() if _TIMING else 0.0
-    numObjects, labels, stats = _segment(eng, dSN, threshold, findCenterOfMass, negate=invertMap)   # :59
+    numObjects, labels, stats = _segment(eng, dSN, threshold, findCenterOfMass, negate=invertMap, slot='objects')   # :59
     if numObjects == 0:
         return []
     tm = _mark('label+stats enqueue', tm)
@@ -148,7 +149,7 @@ def findObjects(filteredMapDict, threshold=3.0, minObjPix=3, rejectBorder=10, fi
 
     ringLabels = isRing = None
     if flagRings == True:                                                         # :65-75
-        numRing, ringLabels, ringStats = _segment(eng, dSN, ringThresholdSigma, True, negate=invertMap)
+        numRing, ringLabels, ringStats = _segment(eng, dSN, ringThresholdSigma, True, negate=invertMap, slot='rings')
         isRing = eng.ring_flags(ringLabels, ringStats, numRing, minRingPix=30)
     tm = _mark('ring label', tm)
 

@@ -36,7 +36,8 @@ int g_profUsed = 0;
 const char* kProfNames[nf::PT_COUNT] = {
     "fft_rows_f64", "fft_cols_f64", "fft_rows_f32", "fft_cols_f32", "cross_power", "gaussian_filter", "build_filter",
     "apply_filter", "window_mul", "paint_radial", "scale_mask", "noise_map", "median_stack", "edge_check", "finalize",
-    "restore_zeros", "subtract", "convolve2d", "label_components", "object_stats", "map_max", "ring_flags", "spline_eval"};
+    "restore_zeros", "subtract", "convolve2d", "label_components", "object_stats", "map_max", "ring_flags", "spline_eval",
+    "axis_filter_rows", "axis_filter_cols"};
 }  // namespace
 
 nf::ProfScope::ProfScope(int tag, hipStream_t s, double bytes) : slot(-1), stream(s) {

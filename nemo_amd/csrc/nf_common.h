@@ -106,6 +106,8 @@ enum ProfTag {
     PT_MAP_MAX,
     PT_RING_FLAGS,
     PT_SPLINE,
+    PT_AXIS_FILTER_ROWS,
+    PT_AXIS_FILTER_COLS,
     PT_COUNT
 };
 // Records an event pair around the work enqueued on `s` during its lifetime when profiling is on (no-op otherwise).

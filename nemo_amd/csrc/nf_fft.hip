@@ -1650,7 +1650,7 @@ int Plan2D<T>::axis_filter(int axis, const void* in, int inType, void* out, int 
         a.linesPerWG = rowsPerWG;
         a.tb = tbRow;
         const size_t lds = (size_t)lp.mPad * a.linesPerWG * sizeof(cpx<T>);
-        ProfScope ps(sizeof(T) == 8 ? PT_FFT_ROWS_F64 : PT_FFT_ROWS_F32, stream, bytes);
+        ProfScope ps(PT_AXIS_FILTER_ROWS, stream, bytes);
         dim3 grid(nf_div_up(a.nLines, a.linesPerWG), batch);
         if (mode == 0)
             hipLaunchKernelGGL((k_line_filter<T, false, 0>), grid, dim3(threadsRow), lds, stream, a);
@@ -1661,7 +1661,7 @@ int Plan2D<T>::axis_filter(int axis, const void* in, int inType, void* out, int 
         a.linesPerWG = colsPerWG;
         a.nTiles = nf_div_up(a.nLines, colsPerWG);
         const size_t lds = (size_t)lp.mPad * a.linesPerWG * sizeof(cpx<T>);
-        ProfScope ps(sizeof(T) == 8 ? PT_FFT_COLS_F64 : PT_FFT_COLS_F32, stream, bytes);
+        ProfScope ps(PT_AXIS_FILTER_COLS, stream, bytes);
         dim3 grid(((a.nTiles + 7) / 8) * 8, batch);
         if (mode == 0)
             hipLaunchKernelGGL((k_line_filter<T, true, 0>), grid, dim3(threadsCol), lds, stream, a);

@@ -1,12 +1,14 @@
-"""Builds profiles/r01_pmc_traffic.json from two rocprofv3 PMC passes over `bench.py --steps 1 --warmup 1`
+"""Builds profiles/rNN_pmc_traffic.json from two rocprofv3 PMC passes over `bench.py --steps 1 --warmup 1`
 (one with --pmc FETCH_SIZE, one with --pmc WRITE_SIZE): HBM bytes per C-ABI entry-point call, by bench.py's profile tag.
     python tools/mkpmc.py <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass> <out.json>
 FETCH_SIZE is doubled (gfx950 tallies 128-byte read requests at 64 B, MI355X_MICROARCH.md, HBM section); WRITE_SIZE is
 used as reported.  Counters report KiB."""
-import csv, glob, json, sys, collections
+import csv, glob, json, re, sys, collections
 
 TAGS = [('fft_cols_f64', ['k_fft_cols<double'], None), ('fft_rows_f64', ['k_fft_rows<double'], None),
         ('fft_cols_f32', ['k_fft_cols<float'], None), ('fft_rows_f32', ['k_fft_rows<float'], None),
+        # the pixel-window undo as two 1-D circular filters (nf_axis_filter): one kernel per axis
+        ('axis_filter_cols', [r'k_line_filter<\w+, ?(true|1)'], None), ('axis_filter_rows', [r'k_line_filter<\w+, ?(false|0)'], None),
         # one nf_noise_map call = breaks + block_stats + window_rms0 + block_core + block_classes + windows + paint_blocks
         ('noise_map', ['k_noise_'], 'k_noise_breaks')]
 
@@ -23,7 +25,7 @@ def load(d, counter):
 fetch, write = load(sys.argv[1], 'FETCH_SIZE'), load(sys.argv[2], 'WRITE_SIZE')
 res = {}
 for tag, pats, callKernel in TAGS:
-    names = sorted(k for k in fetch if any(p in k for p in pats))
+    names = sorted(k for k in fetch if any(re.search(p, k) for p in pats))
     if not names:
         continue
     if callKernel is None:

@@ -287,6 +287,16 @@ int nf_label_components_kept(int vtype, const void* sn_d, double threshold, int 
 int nf_object_stats_chunks(int vtype, const void* sn_d, int negate, const int* labels_d, int H, int W, int numObjects,
                            double* stats_d, const int* chunkFlags_d, void* stream);
 
+/* nf_label_components(_kept) and nf_object_stats_chunks as ONE enqueue without the host round trip for the object count: the
+ * record table stats_d has room for maxObjects labels ((maxObjects + 1) * NF_OBJECT_STATS_DOUBLES doubles, records as
+ * nf_object_stats writes them); the number of labels found stays on the device and comes back in stats_d[0] (the count field
+ * of the background record, which is otherwise zero).  If it exceeds maxObjects the records are incomplete (labels above
+ * maxObjects were skipped): repeat with room for that many.  dirty_d as nf_label_components_kept (NULL: labels_d is written
+ * everywhere).  The call does not wait for the GPU: several maps' detections can be enqueued and their records fetched in
+ * one transfer (photometry.findObjectsGroup). */
+int nf_label_and_stats(int vtype, const void* sn_d, double threshold, int negate, int* labels_d, int H, int W, int* work_d,
+                       int* dirty_d, int maxObjects, double* stats_d, void* stream);
+
 /* The segment moments behind measureShapes (photometry.findObjects, nemo/photometry.py:136-150): per label id 0..numObjects
  * a record of 10 doubles {xMin, yMin, xMax, yMax, S, Sx, Sy, Sxx, Syy, Sxy} with S = sum v, Sx = sum v*(x - xMin),
  * Sxx = sum v*(x - xMin)^2 ... over the segment's pixels (v as in nf_object_stats: exact integer sums of v * 2^40).
@@ -359,6 +369,88 @@ int nf_spline_eval(int vtype, const void* map_d, int negate, int H, int W, const
 int nf_spline_eval_batch(int vtype, int nJobs, const void* const* maps_d, const int* negate, const double* const* yx_d,
                          const int* nPts, const int* const* edgeSel_d, const int* nEdge, double* const* out_d, int H, int W,
                          int halfWin, void* stream);
+
+/* One matched-filter scale of a tile from template to filtered map, enqueued by ONE call: the body of
+ * MatchedFilter.buildAndApply (nemo/filters.py:521-777, noise method 'dataMap', no background subtraction) and the pixel-window
+ * undo of filterMaps (nemo/filters.py:98-101), expressed as the entry points above in the order the reference runs its
+ * statements.  The reference (and this library's Python host layer) walks that sequence statement by statement from the
+ * interpreter, once per scale; on 1-2 Mpix tiles the interpreter then costs more than the kernels do.  Same kernels, same
+ * results bit for bit (tests/test_gpu_scale_entry.py).
+ *
+ * nf_mf_tile: what the scales of one tile share.  nf_mf_scale: the radial tables of one scale's templates and its outputs.
+ *   outputUnits 0 ('yc', nemo/filters.py:632-668): per map the unit template and the y0-scaled one are painted (nf_paint_radial2),
+ *       all 2N planes transformed at once, filter built (:621-627) and symmetrised, the scaled templates filtered with the pixel
+ *       window (:644-647), signalNorm = y0 / (spline value at centreYX_d) (:654-659); for N > 1 the map maximum and the N filtered
+ *       planes' values at its position go to relWeights_d (N values, then the maximum: fRelWeights of :661-667 are their float32
+ *       ratios); data maps come out in float64.
+ *   outputUnits 1 ('uK', :669-685): unit templates only, signalNorm = 1 / max of the filtered template in float32 arithmetic;
+ *       data maps come out in float32.
+ *   Then :696-756: inverse transform of the data spectra times the filter with the float32 cast, signalNorm and point-source
+ *   mask applied at the store, noise map (grid mode), optional edge trim, nf_finalize; and, if axisWinY_d / axisWinX_d are given,
+ *   the pixel-window undo as two nf_axis_filter passes (tables for pow = -1 as that entry point wants them).
+ * Scales are dealt round-robin to nLanes lanes; lane 0 runs on `stream`, the others on streams the library keeps per device,
+ * forked from and joined back into `stream` with events - so for the caller the whole call is ordinary work on `stream`.
+ * work_d: nLanes device buffers of nf_matched_filter_workspace_bytes(tile) bytes each (256-byte aligned). */
+#define NF_MF_MAXFREQ 8
+typedef struct nf_mf_tile {
+    int H, W, N;                       /* map shape, number of frequency maps (<= NF_MF_MAXFREQ) */
+    int prec;                          /* NF_F32 / NF_F64: precision of fMaps_d */
+    int covType;                       /* NF_F32 / NF_F64: type of noiseCov_d */
+    int outputUnits;                   /* 0 = yc, 1 = uK */
+    const void* fMaps_d;               /* [N][H][W] complex, half-stored: spectra of the apodised maps (nf_fft2_forward_half) */
+    const void* noiseCov_d;            /* [N][N][H][W] smoothed noise covariance (nf_cross_power_half + nf_gaussian_filter) */
+    double w[NF_MF_MAXFREQ];           /* frequency weights (nemo/filters.py:587-608) */
+    const double* A_d;                 /* painter geometry, as nf_paint_radial takes it */
+    const double* B_d;
+    const double* C_d;
+    const unsigned char* psMask_d;     /* point-source mask, survey mask (may be NULL = all ones) */
+    const unsigned char* surveyMask_d;
+    const void* medWeights_d;          /* median weight map for the noise map */
+    int wtype;                         /* NF_F32 / NF_F64 of medWeights_d */
+    int ny, nx;                        /* noise grid (nf_noise_map) */
+    const int* yEdges_d;
+    const int* xEdges_d;
+    int overlap, numBins, estimator;
+    const double* quantiles;           /* numBins HOST doubles */
+    int trimSizePix;                   /* edge trim (nf_edge_check size), 0 = none */
+    int apodPix;
+    double y0;                         /* yc: amplitude of the normalisation template (2e-4 in the reference) */
+    const double* centreYX_d;          /* yc: (y, x) of the tile centre, 2 device doubles */
+    int centreClass;                   /* yc: pointsClass of that point for nf_spline_eval */
+    int halfWin;
+    const double* winY_d;              /* yc: pixel-window tables for pow = +1 (nf_fft2_inverse_half) */
+    const double* winX_d;
+    const double* axisWinY_d;          /* pixel-window undo (both or neither): nf_axis_filter tables for axis 1 and axis 0 */
+    const double* axisWinX_d;
+} nf_mf_tile;
+
+typedef struct nf_mf_scale {
+    /* per map: log-uniform radial tables of the unit template (prof, slope, amp, sign) and - yc - of the scaled one */
+    const double* r_d[NF_MF_MAXFREQ];
+    const double* prof_d[NF_MF_MAXFREQ];
+    const double* slope_d[NF_MF_MAXFREQ];
+    const double* prof2_d[NF_MF_MAXFREQ];
+    const double* slope2_d[NF_MF_MAXFREQ];
+    int ntab[NF_MF_MAXFREQ];
+    double r0[NF_MF_MAXFREQ], dlnr[NF_MF_MAXFREQ];
+    double amp[NF_MF_MAXFREQ], sign[NF_MF_MAXFREQ], amp2[NF_MF_MAXFREQ], sign2[NF_MF_MAXFREQ];
+    /* outputs */
+    float* filt_d;                     /* [N][H][W] the filter */
+    double* signalNorm_d;              /* 1 double (uK: the float32 value, widened) */
+    double* relWeights_d;              /* yc, N > 1: N + 1 doubles (see above); else unused, may be NULL */
+    void* data_d;                      /* [H][W] filtered map; yc float64, uK float32 */
+    void* sn_d;                        /* [H][W] S/N map, type of data_d */
+    float* rms_d;                      /* [H][W] noise map */
+    unsigned char* mask_d;             /* [H][W] survey mask after edge trim / apodisation border */
+} nf_mf_scale;
+
+size_t nf_matched_filter_workspace_bytes(const nf_mf_tile* tile);
+/* The scalar step between the filtered template and the filtered map, on the device so that the host does not wait for it:
+ * outputUnits 0: out_d[0] = y0 / src_d[0] in float64 (nemo/filters.py:659, src_d = spline value of the filtered template at the
+ * tile centre); 1: out_d[0] = 1 / float32(src_d[0]) in float32 arithmetic, widened (:684, src_d = nf_map_max result). */
+int nf_signal_norm(int outputUnits, const double* src_d, double y0, double* out_d, void* stream);
+int nf_matched_filter_scales(nf_plan* plan, const nf_mf_tile* tile, const nf_mf_scale* scales, int nScales,
+                             void* const* work_d, int nLanes, void* stream);
 
 /* Instrumentation (no counterpart in the reference; used by bench.py): when enabled, every entry point above brackets
  * the work it enqueues with a HIP event pair on the caller's stream.  nf_profile_enable(on) switches recording and

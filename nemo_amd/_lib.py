@@ -26,6 +26,31 @@ c_ll = ctypes.c_longlong
 c_double = ctypes.c_double
 c_size_t = ctypes.c_size_t
 
+NF_MF_MAXFREQ = 8
+_PD8 = c_void_p * NF_MF_MAXFREQ
+_D8 = c_double * NF_MF_MAXFREQ
+
+
+class MfTile(ctypes.Structure):
+    """nf_mf_tile (include/nemofilt.h): what the filter scales of one tile share."""
+    _fields_ = [('H', c_int), ('W', c_int), ('N', c_int), ('prec', c_int), ('covType', c_int), ('outputUnits', c_int),
+                ('fMaps_d', c_void_p), ('noiseCov_d', c_void_p), ('w', _D8),
+                ('A_d', c_void_p), ('B_d', c_void_p), ('C_d', c_void_p), ('psMask_d', c_void_p), ('surveyMask_d', c_void_p),
+                ('medWeights_d', c_void_p), ('wtype', c_int), ('ny', c_int), ('nx', c_int), ('yEdges_d', c_void_p),
+                ('xEdges_d', c_void_p), ('overlap', c_int), ('numBins', c_int), ('estimator', c_int),
+                ('quantiles', ctypes.POINTER(c_double)), ('trimSizePix', c_int), ('apodPix', c_int), ('y0', c_double),
+                ('centreYX_d', c_void_p), ('centreClass', c_int), ('halfWin', c_int), ('winY_d', c_void_p), ('winX_d', c_void_p),
+                ('axisWinY_d', c_void_p), ('axisWinX_d', c_void_p)]
+
+
+class MfScale(ctypes.Structure):
+    """nf_mf_scale (include/nemofilt.h): one scale's template tables and output buffers."""
+    _fields_ = [('r_d', _PD8), ('prof_d', _PD8), ('slope_d', _PD8), ('prof2_d', _PD8), ('slope2_d', _PD8),
+                ('ntab', c_int * NF_MF_MAXFREQ), ('r0', _D8), ('dlnr', _D8), ('amp', _D8), ('sign', _D8), ('amp2', _D8),
+                ('sign2', _D8), ('filt_d', c_void_p), ('signalNorm_d', c_void_p), ('relWeights_d', c_void_p), ('data_d', c_void_p),
+                ('sn_d', c_void_p), ('rms_d', c_void_p), ('mask_d', c_void_p)]
+
+
 # name -> (restype, argtypes); every symbol include/nemofilt.h declares
 SIGNATURES = {
     'nf_version': (c_int, []),
@@ -85,6 +110,7 @@ SIGNATURES = {
     'nf_label_chunk_flags_offset': (ctypes.c_longlong, [c_int, c_int]),
     'nf_label_components_kept': (c_int, [c_int, c_void_p, c_double, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     'nf_object_stats_chunks': (c_int, [c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    'nf_label_and_stats': (c_int, [c_int, c_void_p, c_double, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     'nf_object_shapes': (c_int, [c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     'nf_resample_bilinear': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'nf_rms_table': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
@@ -106,6 +132,10 @@ SIGNATURES = {
     'nf_spline_eval_batch': (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                      c_void_p]),
     'nf_spline_eval': (c_int, [c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+    'nf_signal_norm': (c_int, [c_int, c_void_p, c_double, c_void_p, c_void_p]),
+    'nf_matched_filter_workspace_bytes': (c_size_t, [ctypes.POINTER(MfTile)]),
+    'nf_matched_filter_scales': (c_int, [c_void_p, ctypes.POINTER(MfTile), ctypes.POINTER(MfScale), c_int, ctypes.POINTER(c_void_p),
+                                         c_int, c_void_p]),
 }
 
 

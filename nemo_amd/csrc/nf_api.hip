@@ -675,6 +675,16 @@ int nf_object_stats_chunks(int vtype, const void* sn, int negate, const int* lab
     return nf::object_stats(vtype, sn, negate, labels, H, W, numObjects, stats, chunkFlags, S(stream));
 }
 
+int nf_label_and_stats(int vtype, const void* sn, double threshold, int negate, int* labels, int H, int W, int* work, int* dirty,
+                       int maxObjects, double* stats, void* stream) {
+    if (!sn || !labels || !work || !stats || H < 1 || W < 1 || maxObjects < 0 || (vtype != NF_F32 && vtype != NF_F64)) {
+        nf_set_error("nf_label_and_stats: bad arguments");
+        return NF_ERR_ARG;
+    }
+    nf::ProfScope ps(nf::PT_LABEL, S(stream), (double)H * W * (vtype == NF_F32 ? 4.0 : 8.0));
+    return nf::label_and_stats(vtype, sn, threshold, negate, labels, H, W, work, dirty, maxObjects, stats, S(stream));
+}
+
 int nf_object_shapes(int vtype, const void* sn, int negate, const int* labels, int H, int W, int numObjects, double* shapes,
                      void* stream) {
     if (!sn || !labels || !shapes || H < 1 || W < 1 || numObjects < 0 || (vtype != NF_F32 && vtype != NF_F64)) {

@@ -257,8 +257,10 @@ int label_components(int vtype, const void* sn, double threshold, int negate, in
     hipLaunchKernelGGL(k_number_roots, g, b, 0, s, parent, n, blockCounts, chunkFG, labels);
     hipLaunchKernelGGL(k_relabel, g, b, 0, s, parent, labels, n, chunkFG, dirty);
     NF_CHECK_LAUNCH("label_components");
-    NF_HIP(hipMemcpyAsync(numObjects, blockCounts + nblocks, sizeof(int), hipMemcpyDeviceToHost, s));
-    NF_HIP(hipStreamSynchronize(s));
+    if (numObjects != nullptr) {        // (NULL: the count stays on the device, work[n + nblocks] - label_and_stats)
+        NF_HIP(hipMemcpyAsync(numObjects, blockCounts + nblocks, sizeof(int), hipMemcpyDeviceToHost, s));
+        NF_HIP(hipStreamSynchronize(s));
+    }
     return NF_OK;
 }
 
@@ -303,7 +305,8 @@ __device__ __forceinline__ unsigned long long ordered_key(double v) {
 template <typename VT>
 __global__ void __launch_bounds__(256) k_object_sums(const VT* __restrict__ sn, int negate, const int* __restrict__ labels, int H, int W,
                                                      double* __restrict__ stats, unsigned long long* __restrict__ limbs,
-                                                     unsigned long long* __restrict__ maxKey, const int* __restrict__ chunkFG) {
+                                                     unsigned long long* __restrict__ maxKey, const int* __restrict__ chunkFG,
+                                                     int maxId) {
     if (chunkFG != nullptr && !chunkFG[blockIdx.x]) return;
     const long long n = (long long)H * W, p0 = (long long)blockIdx.x * NF_SCAN_CHUNK + threadIdx.x * 4;
     if (p0 >= n) return;
@@ -312,7 +315,8 @@ __global__ void __launch_bounds__(256) k_object_sums(const VT* __restrict__ sn, 
     double cnt = 0, mx = 0;
     unsigned __int128 sv = 0, svy = 0, svx = 0;
     for (int j = 0; j < 4 && p0 + j < n; ++j) {
-        const int id = labels[p0 + j];
+        int id = labels[p0 + j];
+        if (id > maxId) id = 0;        // (a record table with room for maxId labels: the caller repeats with more room)
         if (id != cur) {
             if (cur > 0) {
                 flush_run(stats, limbs, cur, cnt, sv, svy, svx);
@@ -347,7 +351,7 @@ __global__ void __launch_bounds__(256) k_object_sums(const VT* __restrict__ sn, 
 template <typename VT>
 __global__ void __launch_bounds__(256) k_object_argmax(const VT* __restrict__ sn, int negate, const int* __restrict__ labels, long long n,
                                                        const unsigned long long* __restrict__ maxKey, unsigned long long* __restrict__ argmax,
-                                                       const int* __restrict__ chunkFG) {
+                                                       const int* __restrict__ chunkFG, int maxId) {
     if (chunkFG != nullptr && !chunkFG[blockIdx.x]) return;
     const long long base = (long long)blockIdx.x * NF_SCAN_CHUNK;
 #pragma unroll
@@ -355,7 +359,7 @@ __global__ void __launch_bounds__(256) k_object_argmax(const VT* __restrict__ sn
         const long long p = base + j * 256 + threadIdx.x;
         if (p >= n) continue;
         int id = labels[p];
-        if (id <= 0) continue;
+        if (id <= 0 || id > maxId) continue;
         double v = (double)sn[p];
         if (negate) v = -v;
         if (ordered_key(v) == maxKey[id]) atomicMin(&argmax[id], (unsigned long long)p);
@@ -370,7 +374,7 @@ __device__ __forceinline__ double limbs_to_double(const unsigned long long* w) {
 
 __global__ void k_stats_finish(double* __restrict__ stats, const unsigned long long* __restrict__ limbs,
                                const unsigned long long* __restrict__ maxKey, const unsigned long long* __restrict__ argmax,
-                               int numObjects) {
+                               int numObjects, const int* __restrict__ count) {
     for (int id = blockIdx.x * blockDim.x + threadIdx.x; id <= numObjects; id += gridDim.x * blockDim.x) {
         const unsigned long long* w = limbs + (long long)id * NF_LIMB_WORDS;
         double* r = stats + (long long)id * NF_STAT_STRIDE;
@@ -381,13 +385,15 @@ __global__ void k_stats_finish(double* __restrict__ stats, const unsigned long l
         unsigned long long b = (k & 0x8000000000000000ULL) ? (k & 0x7FFFFFFFFFFFFFFFULL) : ~k;
         r[4] = __longlong_as_double((long long)b);
         r[5] = (double)argmax[id];
+        // label_and_stats: the number of labels found travels in the (otherwise empty) background record
+        if (id == 0 && count != nullptr) r[0] = (double)count[0];
     }
 }
 
 // `stats` must hold (numObjects+1) * 17 doubles: 6 per record, then scratch - the 9 integer limbs, the maximum key and the
 // argmax of every label
 int object_stats(int vtype, const void* sn, int negate, const int* labels, int H, int W, int numObjects, double* stats,
-                 const int* chunkFG, hipStream_t s) {
+                 const int* chunkFG, hipStream_t s, const int* count) {
     const long long n = (long long)H * W;
     const size_t nrec = (size_t)numObjects + 1;
     unsigned long long* limbs = (unsigned long long*)(stats + nrec * NF_STAT_STRIDE);
@@ -397,15 +403,28 @@ int object_stats(int vtype, const void* sn, int negate, const int* labels, int H
     NF_HIP(hipMemsetAsync(argmax, 0xFF, nrec * sizeof(unsigned long long), s));
     dim3 g(nf_div_up(n, NF_SCAN_CHUNK)), b(256);
     if (vtype == NF_F64) {
-        hipLaunchKernelGGL(k_object_sums<double>, g, b, 0, s, (const double*)sn, negate, labels, H, W, stats, limbs, maxKey, chunkFG);
-        hipLaunchKernelGGL(k_object_argmax<double>, g, b, 0, s, (const double*)sn, negate, labels, n, maxKey, argmax, chunkFG);
+        hipLaunchKernelGGL(k_object_sums<double>, g, b, 0, s, (const double*)sn, negate, labels, H, W, stats, limbs, maxKey, chunkFG, numObjects);
+        hipLaunchKernelGGL(k_object_argmax<double>, g, b, 0, s, (const double*)sn, negate, labels, n, maxKey, argmax, chunkFG, numObjects);
     } else {
-        hipLaunchKernelGGL(k_object_sums<float>, g, b, 0, s, (const float*)sn, negate, labels, H, W, stats, limbs, maxKey, chunkFG);
-        hipLaunchKernelGGL(k_object_argmax<float>, g, b, 0, s, (const float*)sn, negate, labels, n, maxKey, argmax, chunkFG);
+        hipLaunchKernelGGL(k_object_sums<float>, g, b, 0, s, (const float*)sn, negate, labels, H, W, stats, limbs, maxKey, chunkFG, numObjects);
+        hipLaunchKernelGGL(k_object_argmax<float>, g, b, 0, s, (const float*)sn, negate, labels, n, maxKey, argmax, chunkFG, numObjects);
     }
-    hipLaunchKernelGGL(k_stats_finish, dim3(grid_for(nrec, 256)), dim3(256), 0, s, stats, limbs, maxKey, argmax, numObjects);
+    hipLaunchKernelGGL(k_stats_finish, dim3(grid_for(nrec, 256)), dim3(256), 0, s, stats, limbs, maxKey, argmax, numObjects, count);
     NF_CHECK_LAUNCH("object_stats");
     return NF_OK;
+}
+
+// Labelling and the per-label sums without a host round trip in between: the record table has room for maxObjects labels,
+// the number found stays on the device and comes back in stats[0] (the background record's count, otherwise unused).
+int label_and_stats(int vtype, const void* sn, double threshold, int negate, int* labels, int H, int W, int* work, int* dirty,
+                    int maxObjects, double* stats, hipStream_t s) {
+    int rc = label_components(vtype, sn, threshold, negate, labels, H, W, work, nullptr, dirty, s);
+    if (rc != NF_OK) return rc;
+    const long long n = (long long)H * W;
+    const int nblocks = nf_div_up(n, NF_SCAN_CHUNK);
+    const int* count = work + n + nblocks;
+    const int* chunkFG = work + n + nblocks + 1;
+    return object_stats(vtype, sn, negate, labels, H, W, maxObjects, stats, chunkFG, s, count);
 }
 
 // ---------------------------------------------------------------------------------------------------

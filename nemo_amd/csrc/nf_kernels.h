@@ -79,7 +79,9 @@ long long label_chunk_flags_offset(int H, int W);
 int label_components(int vtype, const void* sn, double threshold, int negate, int* labels, int H, int W, int* work,
                      int* numObjects, int* dirty, hipStream_t s);
 int object_stats(int vtype, const void* sn, int negate, const int* labels, int H, int W, int numObjects, double* stats,
-                 const int* chunkFG, hipStream_t s);
+                 const int* chunkFG, hipStream_t s, const int* count = nullptr);
+int label_and_stats(int vtype, const void* sn, double threshold, int negate, int* labels, int H, int W, int* work, int* dirty,
+                    int maxObjects, double* stats, hipStream_t s);
 int object_shapes(int vtype, const void* sn, int negate, const int* labels, int H, int W, int numObjects, double* shapes, hipStream_t s);
 int resample_bilinear(const float* in, float* out, int N, int H, int W, int H2, int W2, const double* yIdx, const double* xIdx,
                       hipStream_t s);

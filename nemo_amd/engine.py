@@ -218,6 +218,8 @@ class TileEngine(object):
         self._geom = {}
         self._geomLast = None
         self._geom2 = {}
+        self.statsCap = 2048        # room (labels) of the record table of label_and_stats; grows when a map has more
+        self._scaleWork = {}        # workspace bytes -> per-lane buffers of nf_matched_filter_scales
 
     # ---- tables --------------------------------------------------------------------------------------------
     def window(self, pow):
@@ -481,6 +483,33 @@ class TileEngine(object):
                                        table.r0, table.dlnr, table.amp, table.sign, stream_ptr()), "nf_paint_radial")
         return out
 
+    # ---- one call per filter scale (nf_matched_filter_scales) ------------------------------------------------------
+    def signal_norm(self, outputUnits, src, y0=0.0):
+        """DeviceScalar of the filter normalisation: 'yc' y0 / src[0] in float64 (nemo/filters.py:659), 'uK' 1 / src[0] in
+        float32 arithmetic (:684); ``src`` is a float64 device tensor, nobody waits for it."""
+        t = self.t
+        out = t.empty(1, dtype=t.float64, device=self.dev)
+        check(self.lib.nf_signal_norm(0 if outputUnits == 'yc' else 1, ptr(src), float(y0), ptr(out), stream_ptr()), "nf_signal_norm")
+        return DeviceScalar(out, wide=outputUnits == 'yc')
+
+    def matched_filter_scales(self, tile, scales, lanes):
+        """nf_matched_filter_scales: ``tile`` an _lib.MfTile, ``scales`` a ctypes array of _lib.MfScale.  The lanes' workspaces
+        are kept by the engine (one set per size) and reused call after call: calls are ordered by the stream they are made
+        on."""
+        t = self.t
+        n = len(scales)
+        lanes = max(1, min(int(lanes), n))
+        nbytes = int(self.lib.nf_matched_filter_workspace_bytes(ctypes.byref(tile)))
+        if nbytes == 0:
+            check(-1, "nf_matched_filter_workspace_bytes")
+        work = self._scaleWork.get(nbytes, [])
+        while len(work) < lanes:
+            work.append(t.empty(nbytes, dtype=t.uint8, device=self.dev))
+        self._scaleWork = {nbytes: work}          # one size at a time: another configuration of the same shape replaces it
+        ptrs = (ctypes.c_void_p * lanes)(*[w.data_ptr() for w in work[:lanes]])
+        check(self.lib.nf_matched_filter_scales(self.plan, ctypes.byref(tile), scales, n, ptrs, lanes, stream_ptr()),
+              "nf_matched_filter_scales")
+
     # ---- real-space tail -----------------------------------------------------------------------------------
     def scale_mask(self, m32, signalNorm, psMask):
         t = self.t
@@ -508,6 +537,32 @@ class TileEngine(object):
               "nf_median_stack")
         return out
 
+    def noise_grid(self, noiseParams, pixSizeDeg):
+        """Grid-mode cells of MapFilter.makeNoiseMap (nemo/filters.py:407-420) as nf_noise_map takes them: (ny, nx, yEdges
+        and xEdges on the device, overlap, numBins, quantiles (host doubles), estimator flag), or None when there is no
+        cell (the RMS map then stays zero)."""
+        if 'noiseGridArcmin' not in noiseParams or noiseParams['noiseGridArcmin'] is None:
+            overlap, nx, ny = 0, 1, 1
+        else:
+            grid = int(round((noiseParams['noiseGridArcmin'] / 60.) / pixSizeDeg))
+            overlap = int(grid / 2)
+            nx = self.W / grid
+            ny = self.H / grid
+        yEdges = np.linspace(0, self.H, int(ny + 1), dtype=int).astype(np.int32)
+        xEdges = np.linspace(0, self.W, int(nx + 1), dtype=int).astype(np.int32)
+        numBins = noiseParams.get('numNoiseBins', 1)
+        percentiles = np.arange(0, 100, 100 / numBins)
+        nb = len(percentiles)
+        quant = (ctypes.c_double * nb)(*[float(np.true_divide(p, 100)) for p in percentiles])
+        ncy, ncx = len(yEdges) - 1, len(xEdges) - 1
+        if ncy < 1 or ncx < 1:
+            return None
+        key = ('noiseEdges', yEdges.tobytes(), xEdges.tobytes())
+        if key not in self._geom2:
+            self._geom2[key] = (to_dev(yEdges), to_dev(xEdges))
+        yE, xE = self._geom2[key]
+        return ncy, ncx, yE, xE, overlap, nb, quant, 1 if noiseParams.get('RMSEstimator', None) == 'percentile' else 0
+
     def noise_map(self, filtered, medWeights, noiseParams, pixSizeDeg):
         """MapFilter.makeNoiseMap, grid mode (nemo/filters.py:407-478)."""
         t = self.t
@@ -530,32 +585,16 @@ class TileEngine(object):
             check(self.lib.nf_noise_map_smart(prec_of(filtered), ptr(filtered), ptr(medWeights), prec_of(medWeights), ptr(rms),
                                               self.npix, numBins, ptr(work), work.numel() * 8, stream_ptr()), "nf_noise_map_smart")
             return rms
-        if 'noiseGridArcmin' not in noiseParams or noiseParams['noiseGridArcmin'] is None:
-            overlap, nx, ny = 0, 1, 1
-        else:
-            grid = int(round((noiseParams['noiseGridArcmin'] / 60.) / pixSizeDeg))
-            overlap = int(grid / 2)
-            nx = self.W / grid
-            ny = self.H / grid
-        yEdges = np.linspace(0, self.H, int(ny + 1), dtype=int).astype(np.int32)
-        xEdges = np.linspace(0, self.W, int(nx + 1), dtype=int).astype(np.int32)
-        numBins = noiseParams.get('numNoiseBins', 1)
-        percentiles = np.arange(0, 100, 100 / numBins)
-        nb = len(percentiles)
-        quant = (ctypes.c_double * nb)(*[float(np.true_divide(p, 100)) for p in percentiles])
-        ncy, ncx = len(yEdges) - 1, len(xEdges) - 1
+        grid = self.noise_grid(noiseParams, pixSizeDeg)
         rms = t.empty((self.H, self.W), dtype=t.float32, device=self.dev)
-        if ncy < 1 or ncx < 1:
+        if grid is None:
             rms.zero_()
             return rms
+        ncy, ncx, yE, xE, overlap, nb, quant, est = grid
         wbytes = self.lib.nf_noise_workspace_bytes(self.H, self.W, ncy, ncx, nb)
         work = t.empty(wbytes // 8 + 1, dtype=t.float64, device=self.dev)
-        key = ('noiseEdges', yEdges.tobytes(), xEdges.tobytes())
-        if key not in self._geom2:
-            self._geom2[key] = (to_dev(yEdges), to_dev(xEdges))
-        yE, xE = self._geom2[key]
         check(self.lib.nf_noise_map(prec_of(filtered), ptr(filtered), ptr(medWeights), prec_of(medWeights), ptr(rms),
-                                    self.H, self.W, ncy, ncx, ptr(yE), ptr(xE), overlap, nb, quant, 1 if estimator == 'percentile' else 0, ptr(work),
+                                    self.H, self.W, ncy, ncx, ptr(yE), ptr(xE), overlap, nb, quant, est, ptr(work),
                                     work.numel() * 8, stream_ptr()), "nf_noise_map")
         self._lastNoiseWork = (work, ncy, ncx, nb)       # diagnostics (tools/noisedbg.py)
         return rms
@@ -767,6 +806,27 @@ class TileEngine(object):
             self._chunkFlags.clear()         # (labels whose statistics were never asked for)
         self._chunkFlags[labels.data_ptr()] = work[off:off + nchunks]        # (keeps `work` alive for object_stats)
         return labels, n.value
+
+    def label_and_stats(self, sn, threshold, negate=False, slot=None, cap=4096):
+        """label() and object_stats() as one enqueue that does not wait for the GPU (nf_label_and_stats): (labels, records)
+        with records a float64 device tensor [(cap + 1), 6]; once fetched, records[0, 0] is the number of objects found - if
+        it exceeds ``cap`` the records are incomplete and the call must be repeated with room for that many."""
+        t = self.t
+        nchunks = (self.npix + 1023) // 1024
+        work = t.empty(self.npix + 2 * nchunks + 16, dtype=t.int32, device=self.dev)
+        dirty = None
+        if slot is None:
+            labels = t.empty((self.H, self.W), dtype=t.int32, device=self.dev)
+        else:
+            key = (threading.get_ident(), slot)
+            if key not in self._keptLabels:
+                self._keptLabels[key] = (t.zeros((self.H, self.W), dtype=t.int32, device=self.dev),
+                                         t.zeros(nchunks, dtype=t.int32, device=self.dev))
+            labels, dirty = self._keptLabels[key]
+        stats = t.empty((cap + 1) * 17, dtype=t.float64, device=self.dev)             # NF_OBJECT_STATS_DOUBLES
+        check(self.lib.nf_label_and_stats(prec_of(sn), ptr(sn), float(threshold), 1 if negate else 0, ptr(labels), self.H, self.W,
+                                          ptr(work), ptr(dirty), int(cap), ptr(stats), stream_ptr()), "nf_label_and_stats")
+        return labels, stats[:(cap + 1) * 6].reshape(cap + 1, 6)
 
     def object_stats(self, sn, labels, numObjects, negate=False):
         t = self.t

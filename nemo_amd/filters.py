@@ -19,11 +19,17 @@ import os
 
 import numpy as np
 
-from . import engine, maps, signals, fitsio
+import ctypes
+
+from . import engine, maps, signals, fitsio, _lib
 from ._lib import NF_F32, NF_F64, NemoFiltError
 from .wcs import calcAngSepDeg
 
 RETURN_DEVICE_ARRAYS = False
+# One library call per filter scale (nf_matched_filter_scales) where the configuration allows it; 0 = every statement of
+# buildAndApply enqueued from here (same kernels, same results - tests/test_gpu_scale_entry.py compares the two)
+_SCALE_ENTRY = os.environ.get('NEMO_AMD_SCALE_ENTRY', '1') != '0'
+_scaleEntryStats = {'calls': 0, 'scales': 0}      # library calls made / scales they carried (tests, diagnostics)
 
 
 def _asnumpy(x, dtype=None):
@@ -42,32 +48,61 @@ def filterMaps(unfilteredMapsDictList, filterParams, tileName, diagnosticsDir='.
     ``tileCache`` (extension; a dict owned by the caller, one per tile) lets the filter scales of one tile share what does
     not depend on the template: the preprocessed maps / weights / masks in HBM, the apodised data FFTs and the smoothed noise
     covariance.  The reference recomputes those identically for every scale (SURVEY.md headline facts)."""
-    f = filterParams
-    label = f['label'] + "#" + tileName
-    if verbose:
-        print("... making filtered map %s" % (label))
-    filterClass = _FILTER_CLASSES[f['class']]
-    filterObj = filterClass(f['label'], unfilteredMapsDictList, f['params'], tileName=tileName,
-                            diagnosticsDir=diagnosticsDir, selFnDir=selFnDir, tileCache=tileCache)
-    filteredMapDict = filterObj.buildAndApply(useCachedFilter=useCachedFilter)
-
-    filteredMapDict['wcs'].header['BUNIT'] = filteredMapDict['mapUnits']
-    if 'beamSolidAngle_nsr' in filteredMapDict.keys() and filteredMapDict['beamSolidAngle_nsr'] > 0:
-        filteredMapDict['wcs'].header['BEAMNSR'] = filteredMapDict['beamSolidAngle_nsr']
-        filteredMapDict['wcs'].header['FREQGHZ'] = filteredMapDict['obsFreqGHz']
-    filteredMapDict['wcs'].updateFromHeader()
-
-    # Undo the pixel window (FFT . W^-1 . IFFT), restoring exact zeros (nemo/filters.py:98-101)
-    if undoPixelWindow == True:
-        data = filteredMapDict['data']
-        eng = filterObj.engine
-        d = engine.to_dev(data)
-        out = eng.undo_pixel_window(d)
-        filteredMapDict['data'] = out if RETURN_DEVICE_ARRAYS else _asnumpy(out)
-
+    filteredMapDict, filterObj = filterMapsGroup(unfilteredMapsDictList, [filterParams], tileName, diagnosticsDir=diagnosticsDir,
+                                                 selFnDir=selFnDir, verbose=verbose, undoPixelWindow=undoPixelWindow,
+                                                 useCachedFilter=useCachedFilter, tileCache=tileCache)[0]
     if returnFilter == True:
         return filteredMapDict, filterObj
     return filteredMapDict
+
+
+def filterMapsGroup(unfilteredMapsDictList, filterParamsList, tileName, diagnosticsDir='.', selFnDir='.', verbose=True,
+                    undoPixelWindow=True, useCachedFilter=False, tileCache=None, lanes=1):
+    """filterMaps for several filters of one tile: [(filteredMapDict, filterObj), ...] in the order given.  Consecutive
+    matched filters that share their maps and their noise / trim settings (the scales of a filter bank) go to the library in
+    one call, dealt to ``lanes`` HIP streams that run side by side (nf_matched_filter_scales); everything else runs filter
+    by filter exactly as filterMaps does."""
+    if tileCache is None:
+        tileCache = {}          # what the filters of this call share (maps in HBM, data spectra, noise covariance)
+    objs = []
+    for f in filterParamsList:
+        if verbose:
+            print("... making filtered map %s" % (f['label'] + "#" + tileName))
+        filterClass = _FILTER_CLASSES[f['class']]
+        objs.append(filterClass(f['label'], unfilteredMapsDictList, f['params'], tileName=tileName,
+                                diagnosticsDir=diagnosticsDir, selFnDir=selFnDir, tileCache=tileCache))
+    results = [None] * len(objs)
+    k = 0
+    while k < len(objs):
+        key = objs[k]._scaleKey(useCachedFilter) if isinstance(objs[k], MatchedFilter) else None
+        run = [k]
+        if key is not None:
+            while run[-1] + 1 < len(objs) and isinstance(objs[run[-1] + 1], MatchedFilter) and \
+                    objs[run[-1] + 1]._scaleKey(useCachedFilter) == key:
+                run.append(run[-1] + 1)
+            dicts = MatchedFilter._runScales([objs[i] for i in run], undoPixelWindow, lanes)
+        else:
+            dicts = None
+        if dicts is None:
+            run = [k]
+            dicts = [objs[k].buildAndApply(useCachedFilter=useCachedFilter)]
+            windowDone = False
+        else:
+            dicts, windowDone = dicts
+        for i, filteredMapDict in zip(run, dicts):
+            filteredMapDict['wcs'].header['BUNIT'] = filteredMapDict['mapUnits']
+            if 'beamSolidAngle_nsr' in filteredMapDict.keys() and filteredMapDict['beamSolidAngle_nsr'] > 0:
+                filteredMapDict['wcs'].header['BEAMNSR'] = filteredMapDict['beamSolidAngle_nsr']
+                filteredMapDict['wcs'].header['FREQGHZ'] = filteredMapDict['obsFreqGHz']
+            filteredMapDict['wcs'].updateFromHeader()
+            # Undo the pixel window (FFT . W^-1 . IFFT), restoring exact zeros (nemo/filters.py:98-101)
+            if undoPixelWindow == True and not windowDone:
+                d = engine.to_dev(filteredMapDict['data'])
+                out = objs[i].engine.undo_pixel_window(d)
+                filteredMapDict['data'] = out if RETURN_DEVICE_ARRAYS else _asnumpy(out)
+            results[i] = (filteredMapDict, objs[i])
+        k = run[-1] + 1
+    return results
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -320,14 +355,16 @@ class MapFilter(object):
         rms = self._noiseMapDevice(d)
         return rms if hasattr(mapData, 'is_cuda') else _asnumpy(rms)
 
-    def _noiseMapDevice(self, dMap):
+    def _medWeights(self):
         if self._shared is not None and 'medWeights' in self._shared:
-            medWeights = self._shared['medWeights']
-        else:
-            medWeights = self.engine.median_weights(self._dWeights)
-            if self._shared is not None:
-                self._shared['medWeights'] = medWeights
-        return self.engine.noise_map(dMap, medWeights, self.params['noiseParams'], self.wcs.getPixelSizeDeg())
+            return self._shared['medWeights']
+        medWeights = self.engine.median_weights(self._dWeights)
+        if self._shared is not None:
+            self._shared['medWeights'] = medWeights
+        return medWeights
+
+    def _noiseMapDevice(self, dMap):
+        return self.engine.noise_map(dMap, self._medWeights(), self.params['noiseParams'], self.wcs.getPixelSizeDeg())
 
     def makeRealSpaceFilterProfile(self):
         """nemo/filters.py:279-301: 1-D real-space profile of the Fourier filter along +x from the centre."""
@@ -404,19 +441,212 @@ class MatchedFilter(MapFilter):
         t = engine.torch()
         return NF_F64 if self._dData[0].dtype == t.float64 else NF_F32
 
-    def buildAndApply(self, useCachedFilter=False):
-        eng = self.engine
+    def _dataSpectra(self):
+        """Half-stored spectra of the apodised maps (nemo/filters.py:523-526), shared by the scales of a tile."""
         t = engine.torch()
         N = len(self.unfilteredMapsDictList)
         shared = self._shared
         if shared is not None and 'fMapsToFilter' in shared:
-            fMapsToFilter = shared['fMapsToFilter']
-        else:
-            dCube = t.stack(self._dData).contiguous() if N > 1 else self._dData[0].reshape(1, *self.shape)
-            fMapsToFilter = eng.fft(dCube, apod=True, half=True)                          # :523-526  K1+K2
-            del dCube
-            if shared is not None:
-                shared['fMapsToFilter'] = fMapsToFilter
+            return shared['fMapsToFilter']
+        dCube = t.stack(self._dData).contiguous() if N > 1 else self._dData[0].reshape(1, *self.shape)
+        fMapsToFilter = self.engine.fft(dCube, apod=True, half=True)                      # :523-526  K1+K2
+        if shared is not None:
+            shared['fMapsToFilter'] = fMapsToFilter
+        return fMapsToFilter
+
+    def _noiseCovariance(self, fMapsToFilter):
+        """Smoothed noise covariance of the maps (nemo/filters.py:539-580, method 'dataMap'), shared by the scales of a tile."""
+        eng = self.engine
+        t = engine.torch()
+        shared = self._shared
+        method = self.params['noiseParams']['method']
+        if method != 'dataMap':
+            if method == 'model':
+                raise NotImplementedError("noise method 'model' (simulated CMB + white noise) is not part of this build yet")
+            # 'max(dataMap,CMB)' included: the reference's branch for it (nemo/filters.py:574-577) is unreachable, its
+            # loop over the maps raises this for every method but 'dataMap' and 'model' (:539-561; pinned by
+            # tests/golden/matched_filter.npz 'maxDataMapCMB_raises')
+            raise Exception("'%s' is not a valid filter noise method name - fix the .yml config file" % (method))
+        noiseCats = self.params.get('noiseModelCatalog', None)
+        covKey = ('noiseCov', method, None if noiseCats is None else id(noiseCats))
+        if shared is not None and covKey in shared:
+            return shared[covKey]
+        fMapsForNoise = fMapsToFilter                                     # identical to :548 without a catalog
+        if noiseCats is not None:                                         # :540-547
+            assert(type(noiseCats) == list)
+            planes = []
+            for i, mapDict in enumerate(self.unfilteredMapsDictList):
+                d = self._dData[i]
+                for noiseModelCatalog in noiseCats:
+                    model = maps.makeModelImage(self.shape, self.wcs, noiseModelCatalog, mapDict['beamFileName'],
+                                                obsFreqGHz=mapDict['obsFreqGHz'])
+                    if model is not None:
+                        d = d - model
+                planes.append(d)
+            fMapsForNoise = eng.fft(t.stack(planes).contiguous(), apod=True, half=True)
+            del planes
+        NP = eng.cross_power(fMapsForNoise, half=True)                            # :573  K4
+        noiseCov = eng.gaussian_filter(NP, (3, 3))                        # :580  K5
+        del NP, fMapsForNoise
+        if shared is not None:
+            shared[covKey] = noiseCov
+        return noiseCov
+
+    # -- one library call per scale (nf_matched_filter_scales) -------------------------------------------------------
+    def _trimSizePix(self):
+        if 'edgeTrimArcmin' in self.params.keys() and self.params['edgeTrimArcmin'] > 0:      # :725-733
+            return int(round((self.params['edgeTrimArcmin'] / 60.) / self.wcs.getPixelSizeDeg()))
+        return 0
+
+    def _scaleKey(self, useCachedFilter):
+        """Hashable description of everything but the template that a library-side run of buildAndApply depends on - filters
+        with equal keys can share one nf_matched_filter_scales call - or None if this configuration is enqueued statement by
+        statement (cached filters, background subtraction, 'smart' noise grid ...)."""
+        p = self.params
+        if not _SCALE_ENTRY or self.templateKind is None or self._shared is None or useCachedFilter != False:
+            return None
+        if self.filterFileName is not None and os.path.exists(self.filterFileName):
+            return None
+        npar = p.get('noiseParams', {})
+        if npar.get('method', None) != 'dataMap' or p.get('outputUnits', None) not in ('yc', 'uK'):
+            return None
+        if 'bckSub' in p.keys() and 'bckSubScaleArcmin' in p.keys() and p['bckSub'] == True:
+            return None
+        if npar.get('noiseGridArcmin', None) == 'smart' or npar.get('RMSEstimator', None) not in (None, 'percentile'):
+            return None
+        if len(self.unfilteredMapsDictList) > _lib.NF_MF_MAXFREQ:
+            return None
+        noiseCats = p.get('noiseModelCatalog', None)
+        return (id(self._shared), type(self).templateKind, p['outputUnits'], npar.get('noiseGridArcmin', None), npar.get('numNoiseBins', 1),
+                npar.get('RMSEstimator', None), self._trimSizePix(), None if noiseCats is None else id(noiseCats),
+                tuple(float(v) for v in self._frequencyWeights()))
+
+    @staticmethod
+    def _runScales(objs, undoPixelWindow, lanes):
+        """buildAndApply of every filter in ``objs`` (equal _scaleKey) through nf_matched_filter_scales.  Returns
+        ([filteredMapDict, ...], pixel window undone?) or None if the tile has no noise cell (the caller falls back)."""
+        first = objs[0]
+        eng = first.engine
+        t = engine.torch()
+        H, W = first.shape
+        N = len(first.unfilteredMapsDictList)
+        yc = first.params['outputUnits'] == 'yc'
+        y0 = 2e-4
+        grid = eng.noise_grid(first.params['noiseParams'], first.wcs.getPixelSizeDeg())
+        if grid is None:
+            return None
+        ncy, ncx, yE, xE, overlap, nb, quant, est = grid
+        fMaps = first._dataSpectra()
+        noiseCov = first._noiseCovariance(fMaps)
+        medWeights = first._medWeights()
+        first._ensureGeom()
+        A, B, C = eng._geomDev(first._geom)
+        tile = _lib.MfTile()
+        tile.H, tile.W, tile.N = H, W, N
+        tile.prec = engine.prec_of(fMaps)
+        tile.covType = engine.prec_of(noiseCov)
+        tile.outputUnits = 0 if yc else 1
+        tile.fMaps_d, tile.noiseCov_d = fMaps.data_ptr(), noiseCov.data_ptr()
+        for i, v in enumerate(first._frequencyWeights()):
+            tile.w[i] = float(v)
+        tile.A_d, tile.B_d, tile.C_d = A.data_ptr(), B.data_ptr(), C.data_ptr()
+        tile.psMask_d = engine.ptr(first._dPSMask)
+        tile.surveyMask_d = engine.ptr(first._dSurveyMask)
+        tile.medWeights_d, tile.wtype = medWeights.data_ptr(), engine.prec_of(medWeights)
+        tile.ny, tile.nx, tile.yEdges_d, tile.xEdges_d = ncy, ncx, yE.data_ptr(), xE.data_ptr()
+        tile.overlap, tile.numBins, tile.estimator = overlap, nb, est
+        tile.quantiles = ctypes.cast(quant, ctypes.POINTER(ctypes.c_double))
+        tile.trimSizePix = first._trimSizePix()
+        tile.apodPix = eng.APOD_PIX
+        tile.y0 = y0
+        tile.halfWin = 32
+        keep = [quant]
+        if yc:
+            shared = first._shared
+            if 'centrePoint' not in shared:
+                cRADeg, cDecDeg = first.wcs.getCentreWCSCoords()
+                cx, cy = first.wcs.wcs2pix(cRADeg, cDecDeg)
+                shared['centrePoint'] = eng.spline_points([[cy, cx]], halfWin=32)
+            pts = shared['centrePoint']
+            tile.centreYX_d, tile.centreClass = pts.dev.data_ptr(), pts.pointsClass
+            wy, wx = eng.window(1.0)
+            tile.winY_d, tile.winX_d = wy.data_ptr(), wx.data_ptr()
+        windowDone = False
+        if undoPixelWindow == True:
+            tabs = eng._axis_window(-1.0, NF_F64 if yc else NF_F32) if engine._AXIS_WINDOW else None
+            if tabs is not None:
+                tile.axisWinX_d, tile.axisWinY_d = tabs[0].data_ptr(), tabs[1].data_ptr()
+                windowDone = True
+
+        G = len(objs)
+        odt = t.float64 if yc else t.float32
+        filt = t.empty((G, N, H, W), dtype=t.float32, device=eng.dev)
+        data = t.empty((G, H, W), dtype=odt, device=eng.dev)
+        sn = t.empty((G, H, W), dtype=odt, device=eng.dev)
+        rms = t.empty((G, H, W), dtype=t.float32, device=eng.dev)
+        mask = t.empty((G, H, W), dtype=t.uint8, device=eng.dev)
+        scal = t.empty((G, N + 2), dtype=t.float64, device=eng.dev)       # per scale: signalNorm, then the N + 1 weight operands
+        scales = (_lib.MfScale * G)()
+        es = data.element_size()
+        for g, obj in enumerate(objs):
+            sc = scales[g]
+            for i, mapDict in enumerate(obj.unfilteredMapsDictList):
+                beam = obj._beamOf(mapDict['beamFileName'])
+                t1 = signals.templateTables(obj.templateKind, beam, obj.params, amplitude=None)
+                r, prof, slope = eng._tableDev(t1)
+                sc.r_d[i], sc.prof_d[i], sc.slope_d[i] = r.data_ptr(), prof.data_ptr(), slope.data_ptr()
+                sc.ntab[i], sc.r0[i], sc.dlnr[i], sc.amp[i], sc.sign[i] = len(t1.r), t1.r0, t1.dlnr, t1.amp, t1.sign
+                if yc:
+                    amp = y0 if mapDict['units'] == 'yc' else maps.convertToDeltaT(y0, mapDict['obsFreqGHz'])
+                    t2 = signals.templateTables(obj.templateKind, beam, obj.params, amplitude=amp)
+                    if len(t1.r) != len(t2.r) or t1.r0 != t2.r0 or t1.dlnr != t2.dlnr:
+                        raise NemoFiltError("the unit and the scaled template must share their radii")
+                    r2, prof2, slope2 = eng._tableDev(t2)
+                    sc.prof2_d[i], sc.slope2_d[i], sc.amp2[i], sc.sign2[i] = prof2.data_ptr(), slope2.data_ptr(), t2.amp, t2.sign
+            sc.filt_d = filt.data_ptr() + g * N * H * W * 4
+            sc.signalNorm_d = scal.data_ptr() + g * (N + 2) * 8
+            sc.relWeights_d = scal.data_ptr() + (g * (N + 2) + 1) * 8
+            sc.data_d = data.data_ptr() + g * H * W * es
+            sc.sn_d = sn.data_ptr() + g * H * W * es
+            sc.rms_d = rms.data_ptr() + g * H * W * 4
+            sc.mask_d = mask.data_ptr() + g * H * W
+        eng.matched_filter_scales(tile, scales, lanes)
+        del keep
+        _scaleEntryStats['calls'] += 1
+        _scaleEntryStats['scales'] += G
+
+        out = []
+        for g, obj in enumerate(objs):
+            obj._dFilt = filt[g]
+            obj._signalNorm = engine.DeviceScalar(scal[g, 0:1], wide=yc)
+            obj.fRelWeights = {}
+            if yc:
+                if N == 1:
+                    obj.fRelWeights[obj.unfilteredMapsDictList[0]['obsFreqGHz']] = np.float32(1.0)
+                else:
+                    obj.fRelWeights = _DeviceWeights([m['obsFreqGHz'] for m in obj.unfilteredMapsDictList], scal[g, 1:N + 2])
+            mapUnits, combinedObsFreqGHz, beamSolidAngle_nsr = obj._unitsInfo()
+            obj._saveFilterIfAsked()
+            out.append(obj._packResult(data[g], sn[g], rms[g], mask[g], tile.trimSizePix > 0, True, mapUnits, combinedObsFreqGHz,
+                                       beamSolidAngle_nsr))
+        return out, windowDone
+
+    def _saveFilterIfAsked(self):
+        if 'saveFilter' in self.params and self.params['saveFilter'] == True and self.filterFileName is not None:
+            header = {'SIGNORM': float(self.signalNorm)}                          # :761-772
+            count = 0
+            for key in list(self.fRelWeights.keys()):
+                count = count + 1
+                header['RW%d_GHZ' % (count)] = key
+                header['RW%d' % (count)] = float(self.fRelWeights[key])
+            os.makedirs(os.path.split(self.filterFileName)[0], exist_ok=True)
+            fitsio.writeFITS(self.filterFileName, self.filt, header)
+
+    def buildAndApply(self, useCachedFilter=False):
+        eng = self.engine
+        t = engine.torch()
+        N = len(self.unfilteredMapsDictList)
+        fMapsToFilter = self._dataSpectra()
 
         haveFile = self.filterFileName is not None and os.path.exists(self.filterFileName)
         if useCachedFilter == True and haveFile == False and self._dFilt is None and self._tileCache is not None:
@@ -424,38 +654,7 @@ class MatchedFilter(MapFilter):
             if cached is not None and tuple(cached.shape) == tuple(self.shape):
                 self._dFilt, self._signalNorm, self.fRelWeights = cached._dFilt, cached._signalNorm, dict(cached.fRelWeights.items())
         if haveFile == False and useCachedFilter == False:
-            method = self.params['noiseParams']['method']
-            if method != 'dataMap':
-                if method == 'model':
-                    raise NotImplementedError("noise method 'model' (simulated CMB + white noise) is not part of this build yet")
-                # 'max(dataMap,CMB)' included: the reference's branch for it (nemo/filters.py:574-577) is unreachable, its
-                # loop over the maps raises this for every method but 'dataMap' and 'model' (:539-561; pinned by
-                # tests/golden/matched_filter.npz 'maxDataMapCMB_raises')
-                raise Exception("'%s' is not a valid filter noise method name - fix the .yml config file" % (method))
-            noiseCats = self.params.get('noiseModelCatalog', None)
-            covKey = ('noiseCov', method, None if noiseCats is None else id(noiseCats))
-            if shared is not None and covKey in shared:
-                noiseCov = shared[covKey]
-            else:
-                fMapsForNoise = fMapsToFilter                                     # identical to :548 without a catalog
-                if noiseCats is not None:                                         # :540-547
-                    assert(type(noiseCats) == list)
-                    planes = []
-                    for i, mapDict in enumerate(self.unfilteredMapsDictList):
-                        d = self._dData[i]
-                        for noiseModelCatalog in noiseCats:
-                            model = maps.makeModelImage(self.shape, self.wcs, noiseModelCatalog, mapDict['beamFileName'],
-                                                        obsFreqGHz=mapDict['obsFreqGHz'])
-                            if model is not None:
-                                d = d - model
-                        planes.append(d)
-                    fMapsForNoise = eng.fft(t.stack(planes).contiguous(), apod=True, half=True)
-                    del planes
-                NP = eng.cross_power(fMapsForNoise, half=True)                            # :573  K4
-                noiseCov = eng.gaussian_filter(NP, (3, 3))                        # :580  K5
-                del NP, fMapsForNoise
-                if shared is not None:
-                    shared[covKey] = noiseCov
+            noiseCov = self._noiseCovariance(fMapsToFilter)
 
             w = self._frequencyWeights()                                          # :587-608
             y0 = 2e-4
@@ -486,7 +685,7 @@ class MatchedFilter(MapFilter):
                 cx, cy = self.wcs.wcs2pix(cRADeg, cDecDeg)
                 # signalNorm = y0 / peak stays on the device (float64 division there): the host goes on enqueueing
                 peak = eng.spline_eval(filteredSignal, [[cy, cx]], to_host=False)                # :654-657  K9
-                self._signalNorm = engine.DeviceScalar(float(y0) / peak.to(t.float64), wide=True)   # :659
+                self._signalNorm = eng.signal_norm('yc', peak, y0)                # :659
                 self.fRelWeights = {}
                 bckSub = 'bckSub' in self.params.keys() and 'bckSubScaleArcmin' in self.params.keys() and self.params['bckSub'] == True
                 if N == 1 and not bckSub:
@@ -506,7 +705,7 @@ class MatchedFilter(MapFilter):
                 # the reference paints and transforms the unit templates a second time (:672-679): same values as fSignals
                 filteredSignal = self._applyFilterDevice(fSignals, half=True)
                 mm = eng.map_max(filteredSignal, to_host=False)                   # :684, float32 arithmetic, on the device
-                self._signalNorm = engine.DeviceScalar((1.0 / mm[:1].to(t.float32)).to(t.float64), wide=False)
+                self._signalNorm = eng.signal_norm('uK', mm)
             else:
                 raise Exception('need to specify "outputUnits" ("yc" or "uK") in filter params')
             del fSignals
@@ -530,21 +729,9 @@ class MatchedFilter(MapFilter):
         del fMapsToFilter
         mapUnits, combinedObsFreqGHz, beamSolidAngle_nsr = self._unitsInfo()
 
-        if 'edgeTrimArcmin' in self.params.keys() and self.params['edgeTrimArcmin'] > 0:      # :725-733
-            trimSizePix = int(round((self.params['edgeTrimArcmin'] / 60.) / self.wcs.getPixelSizeDeg()))
-        else:
-            trimSizePix = 0
+        trimSizePix = self._trimSizePix()
         data, sn, rms, mask, trimmed = self._finish(dFiltered, trimSizePix, True)
-
-        if 'saveFilter' in self.params and self.params['saveFilter'] == True and self.filterFileName is not None:
-            header = {'SIGNORM': float(self.signalNorm)}                          # :761-772
-            count = 0
-            for key in list(self.fRelWeights.keys()):
-                count = count + 1
-                header['RW%d_GHZ' % (count)] = key
-                header['RW%d' % (count)] = float(self.fRelWeights[key])
-            os.makedirs(os.path.split(self.filterFileName)[0], exist_ok=True)
-            fitsio.writeFITS(self.filterFileName, self.filt, header)
+        self._saveFilterIfAsked()
 
         return self._packResult(data, sn, rms, mask, trimmed, True, mapUnits, combinedObsFreqGHz, beamSolidAngle_nsr)
 

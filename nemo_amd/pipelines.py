@@ -217,10 +217,33 @@ class _WorkerStreams(object):
         return s
 
 
-def _detectAndMeasure(config, job, stream, invertMap, measureFluxes, photFilter, verbose):
-    """photometry.findObjects + measureFluxes for one (filter, tile) - nemo/pipelines.py:267-311.  With ``stream`` the
-    work is enqueued on that HIP stream (called from the detection worker thread) after the filtered maps are complete."""
-    label, f, filteredMapDict, photFilteredMapDict, ready = job
+def _scaleGrouping(config, tileName, numFilters):
+    """(lanes, filters per library call) for the filter scales of one tile.  A kernel over a 1-2 Mpix tile leaves most of the
+    chip idle, so the scales of a small tile are handed over together and run on several HIP streams side by side
+    (filters.filterMapsGroup); at 4096^2 every kernel fills the chip and one scale at a time keeps the detection stream fed
+    scale by scale.  ``scaleLanes`` / ``scaleGroup`` in the config (or NEMO_AMD_SCALE_LANES / _GROUP) override."""
+    lanes = int(os.environ.get('NEMO_AMD_SCALE_LANES', config.parDict.get('scaleLanes', 0)))
+    group = int(os.environ.get('NEMO_AMD_SCALE_GROUP', config.parDict.get('scaleGroup', 0)))
+    if lanes <= 0 or group <= 0:
+        npix = None
+        try:
+            cs = config.tileCoordsDict[tileName]['clippedSection']
+            npix = (cs[3] - cs[2]) * (cs[1] - cs[0])
+        except Exception:
+            pass
+        small = npix is not None and npix * max(1, len(config.unfilteredMapsDictList)) < 6e6
+        if lanes <= 0:
+            lanes = 4 if small else 1
+        if group <= 0:
+            group = 16 if small else 1
+    return max(1, lanes), max(1, min(group, numFilters))
+
+
+def _detectAndMeasure(config, jobs, stream, invertMap, measureFluxes, photFilter, verbose):
+    """photometry.findObjects + measureFluxes for the (filter, tile) jobs of one group - nemo/pipelines.py:267-311; returns
+    their catalogues in order.  With ``stream`` the work is enqueued on that HIP stream (called from the detection worker
+    thread) after the filtered maps are complete.  The detections of a group go through photometry.findObjectsGroup: all
+    maps are enqueued before anything is fetched."""
     t = engine.torch()
     engine.require_gpu()        # (this may be a worker thread: same GPU as the thread that filtered the maps)
     if isinstance(stream, _WorkerStreams):
@@ -228,42 +251,47 @@ def _detectAndMeasure(config, job, stream, invertMap, measureFluxes, photFilter,
     ctx = t.cuda.stream(stream) if stream is not None else contextlib.nullcontext()
     with ctx:
         if stream is not None:
-            stream.wait_event(ready)
+            stream.wait_event(jobs[-1][4])          # (the events of a group are recorded in order on one stream)
         if config.parDict.get('forcedPhotometryCatalog', None) is not None:       # nemo/pipelines.py:267-274
-            catalog = photometry.makeForcedPhotometryCatalog(filteredMapDict, config.parDict['forcedPhotometryCatalog'],
-                                                             useInterpolator=config.parDict['useInterpolator'])
+            cats = [photometry.makeForcedPhotometryCatalog(job[2], config.parDict['forcedPhotometryCatalog'],
+                                                           useInterpolator=config.parDict['useInterpolator']) for job in jobs]
         else:
             # what measureFluxes / getSNRValues will read at the object positions: fetched with findObjects' own results
-            prefetch = []
+            prefetches = []
+            for label, f, filteredMapDict, photFilteredMapDict, ready in jobs:
+                prefetch = []
+                if measureFluxes == True:
+                    if photFilteredMapDict is not None:
+                        prefetch.append((photFilteredMapDict['SNMap'], False))
+                    prefetch.append((filteredMapDict['data'], False))
+                    if photFilteredMapDict is not None:
+                        prefetch.append((photFilteredMapDict['data'], False))
+                elif photFilter is not None:
+                    prefetch.append((photFilteredMapDict['SNMap'], invertMap))
+                prefetches.append(prefetch)
+            cats = photometry.findObjectsGroup([job[2] for job in jobs], _prefetch=prefetches,
+                                               threshold=config.parDict['thresholdSigma'],
+                                               minObjPix=config.parDict['minObjPix'],
+                                               findCenterOfMass=config.parDict['findCenterOfMass'],
+                                               flagRings=config.parDict['flagRings'],
+                                               ringFlagDistArcmin=config.parDict['ringFlagDistArcmin'],
+                                               ringFlagMinRingerSNR=config.parDict['ringFlagMinRingerSNR'],
+                                               ringThresholdSigma=config.parDict['ringThresholdSigma'],
+                                               rejectBorder=config.parDict['rejectBorder'],
+                                               objIdent=config.parDict['objIdent'], longNames=config.parDict['longNames'],
+                                               useInterpolator=config.parDict['useInterpolator'],
+                                               measureShapes=config.parDict['measureShapes'], invertMap=invertMap,
+                                               verbose=verbose)
+        for catalog, (label, f, filteredMapDict, photFilteredMapDict, ready) in zip(cats, jobs):
             if measureFluxes == True:
-                if photFilteredMapDict is not None:
-                    prefetch.append((photFilteredMapDict['SNMap'], False))
-                prefetch.append((filteredMapDict['data'], False))
-                if photFilteredMapDict is not None:
-                    prefetch.append((photFilteredMapDict['data'], False))
+                photometry.measureFluxes(catalog, filteredMapDict, config.diagnosticsDir, photFilteredMapDict=photFilteredMapDict,
+                                         useInterpolator=config.parDict['useInterpolator'])
             elif photFilter is not None:
-                prefetch.append((photFilteredMapDict['SNMap'], invertMap))
-            catalog = photometry.findObjects(filteredMapDict, threshold=config.parDict['thresholdSigma'], _prefetch=prefetch,
-                                             minObjPix=config.parDict['minObjPix'],
-                                             findCenterOfMass=config.parDict['findCenterOfMass'],
-                                             flagRings=config.parDict['flagRings'],
-                                             ringFlagDistArcmin=config.parDict['ringFlagDistArcmin'],
-                                             ringFlagMinRingerSNR=config.parDict['ringFlagMinRingerSNR'],
-                                             ringThresholdSigma=config.parDict['ringThresholdSigma'],
-                                             rejectBorder=config.parDict['rejectBorder'],
-                                             objIdent=config.parDict['objIdent'], longNames=config.parDict['longNames'],
-                                             useInterpolator=config.parDict['useInterpolator'],
-                                             measureShapes=config.parDict['measureShapes'], invertMap=invertMap,
-                                             verbose=verbose)
-        if measureFluxes == True:
-            photometry.measureFluxes(catalog, filteredMapDict, config.diagnosticsDir, photFilteredMapDict=photFilteredMapDict,
-                                     useInterpolator=config.parDict['useInterpolator'])
-        elif photFilter is not None:
-            photometry.getSNRValues(catalog, photFilteredMapDict['SNMap'], filteredMapDict['wcs'], prefix='fixed_',
-                                    useInterpolator=config.parDict['useInterpolator'], invertMap=invertMap)
+                photometry.getSNRValues(catalog, photFilteredMapDict['SNMap'], filteredMapDict['wcs'], prefix='fixed_',
+                                        useInterpolator=config.parDict['useInterpolator'], invertMap=invertMap)
         if stream is not None:
             stream.synchronize()      # everything that reads the maps has finished before their memory can be reused
-    return catalog
+    return cats
 
 
 def filterMapsAndMakeCatalogs(config, rootOutDir=None, useCachedFilters=False, useCachedRMSMap=False,
@@ -357,19 +385,23 @@ def _filterMapsAndMakeCatalogs(config, rootOutDir=None, useCachedFilters=False, 
                 # the reference filter object of an earlier pass, still holding its cube in HBM (the reference rereads
                 # diagnostics/<tile>/filter_<label>#<tile>.fits; that file is used when present)
                 tileCache[('cachedFilter', config.cachedFilters[tileName].label)] = config.cachedFilters[tileName]
-            for f in filtersList:
+            lanes, groupSize = _scaleGrouping(config, tileName, len(filtersList))
+            def filteredScales():
+                # the filters of this tile, `groupSize` of them per library call (filters.filterMapsGroup)
+                for g0 in range(0, len(filtersList), groupSize):
+                    group = filtersList[g0:g0 + groupSize]
+                    res = filters.filterMapsGroup(config.unfilteredMapsDictList, group, tileName, diagnosticsDir=diagnosticsDir,
+                                                  selFnDir=config.selFnDir, verbose=verbose, undoPixelWindow=undoPixelWindow,
+                                                  useCachedFilter=useCachedFilters, tileCache=tileCache, lanes=lanes)
+                    for f in group:
+                        yield (f,) + res.pop(0) + (len(res) == 0,)
+
+            groupJobs = []
+            for f, filteredMapDict, filterObj, lastOfGroup in filteredScales():
                 label = f['label'] + "#" + tileName
                 catalogDict[label] = {}
-                returnFilter = f['label'] == photFilter
-                filterResults = filters.filterMaps(config.unfilteredMapsDictList, f, tileName, diagnosticsDir=diagnosticsDir,
-                                                   selFnDir=config.selFnDir, verbose=verbose,
-                                                   undoPixelWindow=undoPixelWindow,
-                                                   useCachedFilter=useCachedFilters, returnFilter=returnFilter,
-                                                   tileCache=tileCache)
-                if returnFilter == False:
-                    filteredMapDict = filterResults
-                else:
-                    filteredMapDict, config.cachedFilters[tileName] = filterResults[0], filterResults[1]
+                if f['label'] == photFilter:
+                    config.cachedFilters[tileName] = filterObj
                 if f['label'] == photFilter and useCachedRMSMap == False:
                     # kept in HBM for later passes with useCachedRMSMap (the reference reloads selFn/RMSMap_<photFilter>.fits,
                     # nemo/completeness.py:1070-1088); also written there when saveRMSMap is set and there is a selFnDir
@@ -399,29 +431,35 @@ def _filterMapsAndMakeCatalogs(config, rootOutDir=None, useCachedFilters=False, 
                     config.flagMaskDict[tileName] = filteredMapDict['flagMask']
                 ready = t.cuda.Event()
                 ready.record(t.cuda.current_stream())
-                job = (label, f, filteredMapDict, photFilteredMapDict, ready)
-                del filteredMapDict
+                groupJobs.append((label, f, filteredMapDict, photFilteredMapDict, ready))
+                del filteredMapDict, filterObj
+                if not lastOfGroup:
+                    continue
+                # the detections of the group go out together (photometry.findObjectsGroup)
+                labels = [job[0] for job in groupJobs]
                 if pool is not None:
-                    pending.append((label, pool.submit(_detectAndMeasure, config, job, detStream, invertMap, measureFluxes,
-                                                       photFilter, verbose)))
+                    pending.append((labels, pool.submit(_detectAndMeasure, config, groupJobs, detStream, invertMap, measureFluxes,
+                                                        photFilter, verbose)))
                 else:
-                    catalogDict[label]['catalog'] = _detectAndMeasure(config, job, None, invertMap, measureFluxes, photFilter,
-                                                                      verbose)
-                del job
-                # bound the maps kept alive for the worker to a few scales (≈0.7 GB each at 4096^2); deep enough that the
+                    for lab, cat in zip(labels, _detectAndMeasure(config, groupJobs, None, invertMap, measureFluxes, photFilter,
+                                                                  verbose)):
+                        catalogDict[lab]['catalog'] = cat
+                groupJobs = []
+                # bound the maps kept alive for the worker to a few groups (≈0.7 GB per scale at 4096^2); deep enough that the
                 # enqueueing thread is not put to sleep while the GPU still has less than a scale of work queued
                 depth = int(os.environ.get('NEMO_AMD_ASYNC_DEPTH', config.parDict.get('asyncDepth', 2)))
                 if len(pending) > depth:
                     pending[-depth - 1][1].result()
-            marks.append(('filters enqueued', time.perf_counter()))
-            for label, fut in pending:
-                catalogDict[label]['catalog'] = fut.result()
-            pending = []
-            marks.append(('detection done', time.perf_counter()))
             del tileCache
+        marks.append(('filters enqueued', time.perf_counter()))
+        for labels, fut in pending:
+            for lab, cat in zip(labels, fut.result()):
+                catalogDict[lab]['catalog'] = cat
+        pending = []
+        marks.append(('detection done', time.perf_counter()))
     finally:
         filters.RETURN_DEVICE_ARRAYS = keepDevice
-        for label, fut in pending:        # (only after an exception: let the worker finish with the maps it holds)
+        for labels, fut in pending:       # (only after an exception: let the worker finish with the maps it holds)
             fut.cancel()
 
     marks.append(('pool closed', time.perf_counter()))

@@ -40,6 +40,27 @@ def test_library_exports_every_declared_symbol():
     assert b"nf_plan_create" in loaded.nf_last_error()
 
 
+def test_struct_layouts_match_the_header(tmp_path):
+    """The ctypes mirrors of nf_mf_tile / nf_mf_scale have the C compiler's size and field offsets."""
+    from nemo_amd import _lib
+    fields = {'nf_mf_tile': [f[0] for f in _lib.MfTile._fields_], 'nf_mf_scale': [f[0] for f in _lib.MfScale._fields_]}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "nemofilt.h"', 'int main(void) {']
+    for name, fl in fields.items():
+        lines.append('printf("%s %%zu\\n", sizeof(%s));' % (name, name))
+        for f in fl:
+            lines.append('printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (name, f, name, f))
+    lines += ['return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for name, cls in (('nf_mf_tile', _lib.MfTile), ('nf_mf_scale', _lib.MfScale)):
+        assert int(out[name]) == ctypes.sizeof(cls)
+        for f in fields[name]:
+            assert int(out["%s.%s" % (name, f)]) == getattr(cls, f).offset, (name, f)
+
+
 def test_product_never_imports_the_oracle():
     """Nothing under nemo_amd/ or bench.py's GPU path may import the oracle (it is the checker, not the product)."""
     pkg = os.path.join(ROOT, "nemo_amd")

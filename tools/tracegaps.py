@@ -4,7 +4,7 @@ fn = glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True)[0]
 rows = list(csv.DictReader(open(fn)))
 ev = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Queue_Id'], r['Kernel_Name'][:60]) for r in rows)
 starts = [e[0] for e in ev if 'cross_power' in e[3]]
-s0 = starts[-1]
+s0 = starts[-(int(sys.argv[2]) if len(sys.argv) > 2 else 1)]       # argv[2]: tiles per step (one cross_power per tile)
 sel = [e for e in ev if e[0] >= s0]
 span = (max(e[1] for e in sel) - s0) / 1e6
 byq = collections.defaultdict(float)

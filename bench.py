@@ -282,11 +282,20 @@ def main():
     for k in range(args.warmup):
         cat = run_step(config)
     if not args.no_profile:
-        # the SURVEY step: one more untimed step after the warm-up in which every entry point records its event pair
+        # the SURVEY step: one more untimed step after the warm-up in which every entry point records its event pair.  It runs
+        # one scale at a time on one stream (scaleLanes / scaleGroup 1), so that an event pair brackets that entry point's
+        # kernels alone; the timed steps run the product's default schedule, in which two scales share the chip.
         barrier()
         lib.nf_profile_select(ctypes.c_ulonglong(0xFFFFFFFFFFFFFFFF))
         lib.nf_profile_enable(1)
+        keepSched = {k: config.parDict.get(k, None) for k in ('scaleLanes', 'scaleGroup')}
+        config.parDict['scaleLanes'], config.parDict['scaleGroup'] = 1, (1 if not tiled else 16)
         cat = run_step(config)
+        for k, v in keepSched.items():
+            if v is None:
+                config.parDict.pop(k, None)
+            else:
+                config.parDict[k] = v
         barrier()
         survey = read_profile()
         lib.nf_profile_enable(0)
@@ -333,18 +342,27 @@ def main():
             devMs = sum(k['ms_total'] for k in kernels.values())
             algGB = sum(k['alg_GB_per_call'] * k['calls'] for k in kernels.values())
             d = timed.get(dom, kernels[dom])      # the dominant entry point, timed over the K timed steps
+            lanes, group = pipelines._scaleGrouping(config, config.tileNames[0], S)
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": d['GBps'], "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": round(d['GBps'] / HBM_PEAK_GBS, 4),
                                "traffic": pmc_traffic(dom, shape, S, args.dtype),
                                "traffic_unit": "GB per launch (rocprofv3 PMC, profiles/r02_pmc_traffic.json)",
                                "avg_us": d['avg_us'], "launches_timed": d['calls'], "alg_GB_per_launch": d['alg_GB_per_call'],
-                               "share_of_device_time": round(kernels[dom]['ms_total'] / devMs, 3)}
+                               "share_of_device_time": round(kernels[dom]['ms_total'] / devMs, 3),
+                               "lanes": lanes,
+                               "solo": {"avg_us": kernels[dom]['avg_us'], "achieved": kernels[dom]['GBps'],
+                                        "frac": round(kernels[dom]['GBps'] / HBM_PEAK_GBS, 4)},
+                               "note": "achieved / avg_us: this entry point's launches in the timed steps, where %d filter scale(s) run "
+                                       "side by side on %d HIP stream(s) - a launch then shares the chip's bandwidth with the other "
+                                       "lane's kernel, so its duration is not its own; 'solo': the same launches in the survey "
+                                       "step (one scale at a time).  The chip-wide figure is pipeline.hbm_frac_wall." % (lanes, lanes)}
             out["pipeline"] = {"device_ms_per_step": round(devMs / surveySteps, 2),
                                "alg_GB_per_step": round(algGB / surveySteps, 3),
                                "hbm_frac_device_time": round(algGB / (devMs / 1e3) / HBM_PEAK_GBS, 4),
                                "hbm_frac_wall": round(algGB / surveySteps / (elapsed / args.steps) / HBM_PEAK_GBS, 4),
-                               "note": "per-entry-point table from one untimed survey step after the warm-up (all entry points "
-                                       "record events there; in the timed region only the dominant one does)"}
+                               "note": "per-entry-point table from one untimed survey step after the warm-up, run one scale at a time "
+                                       "on one stream (all entry points record events there; in the timed region only the dominant "
+                                       "one does); hbm_frac_wall = algorithmic GB per step / timed wall per step / peak"}
             out["kernels"] = kernels
         if cpu is not None:
             out["cpu_baseline"] = cpu

@@ -218,10 +218,12 @@ class _WorkerStreams(object):
 
 
 def _scaleGrouping(config, tileName, numFilters):
-    """(lanes, filters per library call) for the filter scales of one tile.  A kernel over a 1-2 Mpix tile leaves most of the
-    chip idle, so the scales of a small tile are handed over together and run on several HIP streams side by side
-    (filters.filterMapsGroup); at 4096^2 every kernel fills the chip and one scale at a time keeps the detection stream fed
-    scale by scale.  ``scaleLanes`` / ``scaleGroup`` in the config (or NEMO_AMD_SCALE_LANES / _GROUP) override."""
+    """(lanes, filters per library call) for the filter scales of one tile (filters.filterMapsGroup).  Measured on MI355X:
+    at 4096^2 two scales side by side on two HIP streams fill the gaps that one scale's small kernels (spline, map maximum,
+    noise-grid set-up) and kernel tails leave - 26.5 -> 24.8 ms per 15-scale step; more lanes lose to cache and CU sharing
+    (4 lanes: 29.7 ms), and larger groups delay the detection stream.  A 1-2 Mpix tile hands over all its scales at once: the
+    cost there is the host's per call and per fetch, not the kernels'.  ``scaleLanes`` / ``scaleGroup`` in the config (or
+    NEMO_AMD_SCALE_LANES / _GROUP) override."""
     lanes = int(os.environ.get('NEMO_AMD_SCALE_LANES', config.parDict.get('scaleLanes', 0)))
     group = int(os.environ.get('NEMO_AMD_SCALE_GROUP', config.parDict.get('scaleGroup', 0)))
     if lanes <= 0 or group <= 0:
@@ -233,9 +235,9 @@ def _scaleGrouping(config, tileName, numFilters):
             pass
         small = npix is not None and npix * max(1, len(config.unfilteredMapsDictList)) < 6e6
         if lanes <= 0:
-            lanes = 4 if small else 1
+            lanes = 2
         if group <= 0:
-            group = 16 if small else 1
+            group = 16 if small else 2
     return max(1, lanes), max(1, min(group, numFilters))
 
 

@@ -96,15 +96,17 @@ int nf_cross_power(int prec, const void* F_d, void* NP_d, int N, long long npix,
  *                           real(ifft2(F * filt)) = ifft2(F * filtSym) for the spectrum F of a real map
  *   nf_fft2_inverse_half  = nf_fft2_inverse_fused with real output of half-stored input planes and the symmetrised filter
  *                           (NULL = none); the window tables must be even, wy[H-y] == wy[y], as enmap.apply_window's
- *                           sinc(fftfreq) tables are
+ *                           sinc(fftfreq) tables are.  planeScale (HOST doubles, or NULL): one more real factor per plane of
+ *                           the sum (nSum > 1: nSum entries) or per batch entry (nSum == 1: batch entries), at most 8 -
+ *                           the amplitude of a template whose spectrum is given for unit amplitude (nemo/filters.py:639-646)
  *   nf_cross_power_half, nf_build_filter_half = nf_cross_power / nf_build_filter reading half-stored F_d / S_d and writing
  *                           full planes */
 int nf_fft2_forward_half(nf_plan* plan, int prec, const void* in_d, int inType, void* out_d, int batch,
                          const double* apodY_d, const double* apodX_d, int unitary, void* stream);
 int nf_symmetrise_filter(const float* filt_d, double* filtSym_d, int N, int H, int W, void* stream);
 int nf_fft2_inverse_half(nf_plan* plan, int prec, const void* in_d, const double* filtSym_d, int nSum, int filtPerBatch,
-                         const double* wy_d, const double* wx_d, void* work_d, void* out_d, int outType, int batch,
-                         int unitary, void* stream);
+                         const double* wy_d, const double* wx_d, const double* planeScale, void* work_d, void* out_d,
+                         int outType, int batch, int unitary, void* stream);
 /* nf_fft2_inverse_half of ONE map (nSum planes summed, or one plane) with the pointwise steps that follow it on the path
  * applied while the real rows are stored (they would otherwise re-read and re-write the map):
  *   scale_d (device scalar) [+ mask_d]: out = float32(value) * scale [* mask], in the output type - the cast of
@@ -378,11 +380,13 @@ int nf_spline_eval_batch(int vtype, int nJobs, const void* const* maps_d, const 
  * results bit for bit (tests/test_gpu_scale_entry.py).
  *
  * nf_mf_tile: what the scales of one tile share.  nf_mf_scale: the radial tables of one scale's templates and its outputs.
- *   outputUnits 0 ('yc', nemo/filters.py:632-668): per map the unit template and the y0-scaled one are painted (nf_paint_radial2),
- *       all 2N planes transformed at once, filter built (:621-627) and symmetrised, the scaled templates filtered with the pixel
- *       window (:644-647), signalNorm = y0 / (spline value at centreYX_d) (:654-659); for N > 1 the map maximum and the N filtered
- *       planes' values at its position go to relWeights_d (N values, then the maximum: fRelWeights of :661-667 are their float32
- *       ratios); data maps come out in float64.
+ *   outputUnits 0 ('yc', nemo/filters.py:632-668): per map the unit template is painted, all N planes transformed at once,
+ *       filter built (:621-627) and symmetrised.  The y0-scaled templates of the normalisation (:639-646) are the unit
+ *       templates times templateScale[i] (same profile, another amplitude: equal up to the float32 rounding of the painted
+ *       pixels, 6e-8), so their spectra are not computed again: the factor rides on the inverse transform's load.  Filtered
+ *       with the pixel window (:644-647), signalNorm = y0 / (spline value at centreYX_d) (:654-659); for N > 1 the map maximum
+ *       and the N filtered planes' values at its position go to relWeights_d (N values, then the maximum: fRelWeights of
+ *       :661-667 are their float32 ratios); data maps come out in float64.
  *   outputUnits 1 ('uK', :669-685): unit templates only, signalNorm = 1 / max of the filtered template in float32 arithmetic;
  *       data maps come out in float32.
  *   Then :696-756: inverse transform of the data spectra times the filter with the float32 cast, signalNorm and point-source
@@ -425,15 +429,14 @@ typedef struct nf_mf_tile {
 } nf_mf_tile;
 
 typedef struct nf_mf_scale {
-    /* per map: log-uniform radial tables of the unit template (prof, slope, amp, sign) and - yc - of the scaled one */
+    /* per map: log-uniform radial table of the unit template (as nf_paint_radial takes it) and - yc - the factor that turns
+     * it into the y0-scaled template of the normalisation (templateScale) */
     const double* r_d[NF_MF_MAXFREQ];
     const double* prof_d[NF_MF_MAXFREQ];
     const double* slope_d[NF_MF_MAXFREQ];
-    const double* prof2_d[NF_MF_MAXFREQ];
-    const double* slope2_d[NF_MF_MAXFREQ];
     int ntab[NF_MF_MAXFREQ];
     double r0[NF_MF_MAXFREQ], dlnr[NF_MF_MAXFREQ];
-    double amp[NF_MF_MAXFREQ], sign[NF_MF_MAXFREQ], amp2[NF_MF_MAXFREQ], sign2[NF_MF_MAXFREQ];
+    double amp[NF_MF_MAXFREQ], sign[NF_MF_MAXFREQ], templateScale[NF_MF_MAXFREQ];
     /* outputs */
     float* filt_d;                     /* [N][H][W] the filter */
     double* signalNorm_d;              /* 1 double (uK: the float32 value, widened) */

@@ -45,9 +45,9 @@ class MfTile(ctypes.Structure):
 
 class MfScale(ctypes.Structure):
     """nf_mf_scale (include/nemofilt.h): one scale's template tables and output buffers."""
-    _fields_ = [('r_d', _PD8), ('prof_d', _PD8), ('slope_d', _PD8), ('prof2_d', _PD8), ('slope2_d', _PD8),
-                ('ntab', c_int * NF_MF_MAXFREQ), ('r0', _D8), ('dlnr', _D8), ('amp', _D8), ('sign', _D8), ('amp2', _D8),
-                ('sign2', _D8), ('filt_d', c_void_p), ('signalNorm_d', c_void_p), ('relWeights_d', c_void_p), ('data_d', c_void_p),
+    _fields_ = [('r_d', _PD8), ('prof_d', _PD8), ('slope_d', _PD8),
+                ('ntab', c_int * NF_MF_MAXFREQ), ('r0', _D8), ('dlnr', _D8), ('amp', _D8), ('sign', _D8), ('templateScale', _D8),
+                ('filt_d', c_void_p), ('signalNorm_d', c_void_p), ('relWeights_d', c_void_p), ('data_d', c_void_p),
                 ('sn_d', c_void_p), ('rms_d', c_void_p), ('mask_d', c_void_p)]
 
 
@@ -64,8 +64,8 @@ SIGNATURES = {
                                       c_int, c_int, c_int, c_void_p]),
     'nf_cross_power': (c_int, [c_int, c_void_p, c_void_p, c_int, c_ll, c_void_p]),
     'nf_fft2_forward_half': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p]),
-    'nf_fft2_inverse_half': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
-                                     c_int, c_int, c_int, c_void_p]),
+    'nf_fft2_inverse_half': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, ctypes.POINTER(c_double),
+                                     c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'nf_fft2_inverse_half_epi': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                          c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     'nf_symmetrise_filter': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),

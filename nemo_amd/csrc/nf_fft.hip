@@ -256,7 +256,8 @@ __device__ __forceinline__ cpx<T> fused_ops_herm(const nf::LineArgs<T>& a, const
                 f = ((const cpx<T>*)G.inP)[(size_t)pl * (size_t)a.sumStride + off];
                 f.y *= (T)a.conjInSign;
             }
-            const double g = ms ? ms[(size_t)pl * (size_t)a.sumStride + off] : 1.0;
+            double g = ms ? ms[(size_t)pl * (size_t)a.sumStride + off] : 1.0;
+            if (a.usePlaneScale) g *= a.planeScale[a.nSum > 1 ? pl : (int)(blockIdx.y & 7)];
             re += (double)f.x * g;
             im += (double)f.y * g;
         }
@@ -363,6 +364,11 @@ __device__ __forceinline__ void fft_stage(cpx<T>* __restrict__ buf, const nf::Li
                     } else {
 #pragma unroll
                         for (int k = 0; k < R; ++k) f[k] = 1.0;
+                    }
+                    if (a.usePlaneScale) {
+                        const double ps = a.planeScale[blockIdx.y & 7];
+#pragma unroll
+                        for (int k = 0; k < R; ++k) f[k] *= ps;
                     }
                     if (a.winElem != nullptr) {
                         const double wl = a.winLine[col];
@@ -1571,7 +1577,8 @@ int Plan2D<T>::inverse(const void* in, void* work, void* out, int outType, int b
 template <typename T>
 int Plan2D<T>::inverse_half(const void* in, void* work, void* out, int outType, int batch, int scaleDiv, double scale,
                             hipStream_t stream, const double* filtSym, int nSum, long long filtBatchStride, const double* winY,
-                            const double* winX, const double* epiScale, const unsigned char* epiMask, const void* epiZeroRef) {
+                            const double* winX, const double* epiScale, const unsigned char* epiMask, const void* epiZeroRef,
+                            const double* planeScale) {
     if (outType == 0) {
         nf_set_error("a half-stored spectrum has a real inverse transform: ask for real output");
         return NF_ERR_ARG;
@@ -1587,6 +1594,15 @@ int Plan2D<T>::inverse_half(const void* in, void* work, void* out, int outType, 
     c.herm = 1;
     c.halfIn = 1;
     c.fused = 1;
+    if (planeScale != nullptr) {
+        const int np_ = nSum > 1 ? nSum : batch;
+        if (np_ > 8) {
+            nf_set_error("inverse_half: at most 8 plane factors");
+            return NF_ERR_ARG;
+        }
+        c.usePlaneScale = 1;
+        for (int i = 0; i < np_; ++i) c.planeScale[i] = planeScale[i];
+    }
     c.nLines = W / 2 + 1;
     c.nTiles = nf_div_up(c.nLines, colsPerWG);
     LineArgs<T> a = row_args<T>(*this, work, out, 0, outType);

@@ -45,7 +45,7 @@ Layout layout_of(const nf_mf_tile& t) {
     const size_t npix = (size_t)t.H * (size_t)t.W;
     const size_t N = (size_t)t.N;
     const bool yc = t.outputUnits == 0;
-    const size_t nT = yc ? 2 * N : N;
+    const size_t nT = N;
     const size_t outB = yc ? 8 : 4;
     size_t off = 0;
     auto take = [&off](size_t bytes) {
@@ -126,7 +126,6 @@ int run_scale(nf_plan* plan, const nf_mf_tile& t, const nf_mf_scale& sc, const L
     const int H = t.H, W = t.W, N = t.N;
     const long long npix = (long long)H * W;
     const bool yc = t.outputUnits == 0;
-    const int nT = yc ? 2 * N : N;
     const int outPrec = yc ? NF_F64 : NF_F32;
     const int outType = yc ? NF_IN_REAL64 : NF_IN_REAL32;
     float* T = (float*)(ws + L.T);
@@ -145,35 +144,31 @@ int run_scale(nf_plan* plan, const nf_mf_tile& t, const nf_mf_scale& sc, const L
         nf_set_error("nf_matched_filter_scales: a scale lacks an output buffer");
         return NF_ERR_ARG;
     }
-    // templates (nemo/filters.py:611-618, 639-646) and their spectra, all planes in one transform
-    for (int i = 0; i < N; ++i) {
-        if (yc)
-            NF_TRY(nf_paint_radial2(T + (size_t)i * npix, T + (size_t)(N + i) * npix, H, W, t.A_d, t.B_d, t.C_d, sc.r_d[i], sc.prof_d[i],
-                                    sc.slope_d[i], sc.prof2_d[i], sc.slope2_d[i], sc.ntab[i], sc.r0[i], sc.dlnr[i], sc.amp[i],
-                                    sc.sign[i], sc.amp2[i], sc.sign2[i], S));
-        else
-            NF_TRY(nf_paint_radial(T + (size_t)i * npix, H, W, t.A_d, t.B_d, t.C_d, sc.r_d[i], sc.prof_d[i], sc.slope_d[i],
-                                   sc.ntab[i], sc.r0[i], sc.dlnr[i], sc.amp[i], sc.sign[i], S));
-    }
-    NF_TRY(nf_fft2_forward_half(plan, NF_F32, T, NF_IN_REAL32, F, nT, nullptr, nullptr, 1, S));
+    // unit templates (nemo/filters.py:611-618) and their spectra, all planes in one transform
+    for (int i = 0; i < N; ++i)
+        NF_TRY(nf_paint_radial(T + (size_t)i * npix, H, W, t.A_d, t.B_d, t.C_d, sc.r_d[i], sc.prof_d[i], sc.slope_d[i], sc.ntab[i],
+                               sc.r0[i], sc.dlnr[i], sc.amp[i], sc.sign[i], S));
+    NF_TRY(nf_fft2_forward_half(plan, NF_F32, T, NF_IN_REAL32, F, N, nullptr, nullptr, 1, S));
     // the filter (:621-627) and its symmetrised form for the half-spectrum inverse
     NF_TRY(nf_build_filter_half(t.covType, NF_F32, t.noiseCov_d, F, t.w, sc.filt_d, N, H, W, S));
     NF_TRY(nf_symmetrise_filter(sc.filt_d, filtSym, N, H, W, S));
     // normalisation
     if (yc) {
-        const char* Fmaps = F + (size_t)N * npix * 8;     // spectra of the y0-scaled templates
-        NF_TRY(nf_fft2_inverse_half(plan, NF_F32, Fmaps, filtSym, N, 0, t.winY_d, t.winX_d, work, sig, NF_IN_REAL32, 1, 0, S));
+        // the y0-scaled templates (:639-646) are the unit templates times templateScale: the factor rides on the load
+        NF_TRY(nf_fft2_inverse_half(plan, NF_F32, F, filtSym, N, 0, t.winY_d, t.winX_d, sc.templateScale, work, sig, NF_IN_REAL32, 1, 0,
+                                    S));
         NF_TRY(nf_spline_eval(NF_F32, sig, 0, H, W, t.centreYX_d, 1, t.halfWin, t.centreClass, nullptr, 0, peak, S));
         hipLaunchKernelGGL(k_signal_norm, dim3(1), dim3(64), 0, st, 0, peak, t.y0, sc.signalNorm_d);
         NF_CHECK_LAUNCH("k_signal_norm");
         if (N > 1) {
             NF_TRY(nf_map_max(NF_F32, sig, npix, mapMax, S));
-            NF_TRY(nf_fft2_inverse_half(plan, NF_F32, Fmaps, filtSym, 1, 1, t.winY_d, t.winX_d, work, planes, NF_IN_REAL32, N, 0, S));
+            NF_TRY(nf_fft2_inverse_half(plan, NF_F32, F, filtSym, 1, 1, t.winY_d, t.winX_d, sc.templateScale, work, planes,
+                                        NF_IN_REAL32, N, 0, S));
             hipLaunchKernelGGL(k_rel_weights, dim3(1), dim3(64), 0, st, planes, mapMax, N, npix, sc.relWeights_d);
             NF_CHECK_LAUNCH("k_rel_weights");
         }
     } else {
-        NF_TRY(nf_fft2_inverse_half(plan, NF_F32, F, filtSym, N, 0, nullptr, nullptr, work, sig, NF_IN_REAL32, 1, 0, S));
+        NF_TRY(nf_fft2_inverse_half(plan, NF_F32, F, filtSym, N, 0, nullptr, nullptr, nullptr, work, sig, NF_IN_REAL32, 1, 0, S));
         NF_TRY(nf_map_max(NF_F32, sig, npix, mapMax, S));
         hipLaunchKernelGGL(k_signal_norm, dim3(1), dim3(64), 0, st, 1, mapMax, 0.0, sc.signalNorm_d);
         NF_CHECK_LAUNCH("k_signal_norm");

@@ -261,19 +261,23 @@ class TileEngine(object):
                   1 if unitary else 0, stream_ptr()), "nf_fft2_forward")
         return out.reshape(x.shape)
 
-    def ifft(self, X, out='complex', unitary=False, clobber=False, filt=None, sum=False, window=None, half=False):
+    def ifft(self, X, out='complex', unitary=False, clobber=False, filt=None, sum=False, window=None, half=False, planeScale=None):
         """enmap.ifft; ``out`` in {'complex', 'f64', 'f32'} (the latter two keep the real part only).
 
         ``filt`` (float32 [N,H,W] or [H,W]) and ``window`` (power of the pixel window) are multiplied in while the
         transform loads its input (nemo/filters.py:847 and enmap.apply_window); with ``sum`` the N planes of X are summed
-        after the product and one map comes out.  ``half``: X holds half-stored spectra (fft(half=True)); real output only."""
+        after the product and one map comes out.  ``half``: X holds half-stored spectra (fft(half=True)); real output only.
+        ``planeScale`` (half only): one more real factor per plane - the amplitudes of templates whose spectra are given for
+        unit amplitude."""
         t = self.t
         X3 = X.reshape(-1, self.H, self.W)
         prec = prec_of(X3)
         if half and out == 'complex':
             raise NemoFiltError("the inverse transform of a half-stored spectrum is real")
+        if planeScale is not None and not half:
+            raise NemoFiltError("planeScale belongs to the inverse transform of half-stored spectra")
         if filt is not None or window is not None or half:
-            return self._ifft_fused(X3, X.shape, out, unitary, clobber, filt, sum, window, half)
+            return self._ifft_fused(X3, X.shape, out, unitary, clobber, filt, sum, window, half, planeScale)
         work = X3 if clobber else t.empty_like(X3)
         if out == 'complex':
             res = t.empty_like(X3)
@@ -288,7 +292,7 @@ class TileEngine(object):
                                        1 if unitary else 0, stream_ptr()), "nf_fft2_inverse")
         return res.reshape(X.shape)
 
-    def _ifft_fused(self, X3, shape, out, unitary, clobber, filt, sum, window, half=False):
+    def _ifft_fused(self, X3, shape, out, unitary, clobber, filt, sum, window, half=False, planeScale=None):
         t = self.t
         prec = prec_of(X3)
         N = X3.shape[0]
@@ -318,9 +322,17 @@ class TileEngine(object):
             res, outType = t.empty(outShape, dtype=t.float64, device=self.dev), IN_REAL64
         else:
             res, outType = t.empty(outShape, dtype=t.float32, device=self.dev), IN_REAL32
-        inv = self.lib.nf_fft2_inverse_half if half else self.lib.nf_fft2_inverse_fused
-        check(inv(self.plan, prec, ptr(X3), ptr(f3), nSum, perBatch, ptr(wy), ptr(wx), ptr(work),
-                  ptr(res), outType, batch, 1 if unitary else 0, stream_ptr()), "nf_fft2_inverse_fused")
+        if half:
+            ps = None
+            if planeScale is not None:
+                if len(planeScale) != N or N > 8:
+                    raise NemoFiltError("planeScale: one factor per plane, at most 8 planes")
+                ps = (ctypes.c_double * N)(*[float(v) for v in planeScale])
+            check(self.lib.nf_fft2_inverse_half(self.plan, prec, ptr(X3), ptr(f3), nSum, perBatch, ptr(wy), ptr(wx), ps, ptr(work),
+                                                ptr(res), outType, batch, 1 if unitary else 0, stream_ptr()), "nf_fft2_inverse_half")
+        else:
+            check(self.lib.nf_fft2_inverse_fused(self.plan, prec, ptr(X3), ptr(f3), nSum, perBatch, ptr(wy), ptr(wx), ptr(work),
+                                                 ptr(res), outType, batch, 1 if unitary else 0, stream_ptr()), "nf_fft2_inverse_fused")
         if sum:
             return res.reshape(self.H, self.W)
         return res.reshape(shape)
@@ -473,12 +485,15 @@ class TileEngine(object):
                                         table.sign, table2.amp, table2.sign, stream_ptr()), "nf_paint_radial2")
         return out
 
-    def paint(self, geom, table):
-        """float32 template from a signals.RadialTable and the (A, B, C) haversine tables."""
+    def paint(self, geom, table, out=None):
+        """float32 template from a signals.RadialTable and the (A, B, C) haversine tables (into ``out`` if given)."""
         t = self.t
         A, B, C = self._geomDev(geom)
         r, prof, slope = self._tableDev(table)
-        out = t.empty((self.H, self.W), dtype=t.float32, device=self.dev)
+        if out is None:
+            out = t.empty((self.H, self.W), dtype=t.float32, device=self.dev)
+        elif out.dtype != t.float32 or tuple(out.shape) != (self.H, self.W) or not out.is_contiguous():
+            raise NemoFiltError("paint: out must be a contiguous float32 map")
         check(self.lib.nf_paint_radial(ptr(out), self.H, self.W, ptr(A), ptr(B), ptr(C), ptr(r), ptr(prof), ptr(slope), len(table.r),
                                        table.r0, table.dlnr, table.amp, table.sign, stream_ptr()), "nf_paint_radial")
         return out

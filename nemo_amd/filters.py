@@ -334,15 +334,22 @@ class MapFilter(object):
                 if shared is not None:
                     shared['paintGeom'] = self._geom
 
-    def _paintTemplatePair(self, beamFileName, amplitude):
-        """The unit template and the amplitude-scaled one, float32 [2, H, W], painted in one pass."""
+    def _unitTemplate(self, mapDict, y0):
+        """The unit template's radial table for ``mapDict`` and - with ``y0`` - the factor that turns the painted unit
+        template into the y0-amplitude template of the normalisation (nemo/filters.py:639-646).  Both templates paint the same
+        beam-convolved profile: amp * prof(theta), once with amp = 1 on the profile as it is, once normalised to its central
+        value and multiplied by float32(centre * amplitude) (nemo/signals.py:662-664).  Pixel for pixel they differ by the
+        constant factor below up to the float32 rounding of the painted values (6e-8), so the scaled template's spectrum is
+        the unit template's times that factor and is not computed a second time."""
         if self.templateKind is None:
             raise Exception("Called a base filter class without a makeSignalTemplateMap() function implemented.")
-        self._ensureGeom()
-        beam = self._beamOf(beamFileName)
+        beam = self._beamOf(mapDict['beamFileName'])
         t1 = signals.templateTables(self.templateKind, beam, self.params, amplitude=None)
-        t2 = signals.templateTables(self.templateKind, beam, self.params, amplitude=amplitude)
-        return self.engine.paint2(self._geom, t1, t2)
+        if y0 is None:
+            return t1, 1.0
+        amp = y0 if mapDict['units'] == 'yc' else maps.convertToDeltaT(y0, mapDict['obsFreqGHz'])
+        t2 = signals.templateTables(self.templateKind, beam, self.params, amplitude=amp)
+        return t1, (t2.sign * t2.amp * t2.prof[0]) / (t1.sign * t1.amp * t1.prof[0])
 
     def makeSignalTemplateMap(self, beamFileName, amplitude=None):
         out = self._paintTemplate(beamFileName, amplitude=amplitude)
@@ -591,18 +598,11 @@ class MatchedFilter(MapFilter):
         for g, obj in enumerate(objs):
             sc = scales[g]
             for i, mapDict in enumerate(obj.unfilteredMapsDictList):
-                beam = obj._beamOf(mapDict['beamFileName'])
-                t1 = signals.templateTables(obj.templateKind, beam, obj.params, amplitude=None)
+                t1, scale = obj._unitTemplate(mapDict, y0 if yc else None)
                 r, prof, slope = eng._tableDev(t1)
                 sc.r_d[i], sc.prof_d[i], sc.slope_d[i] = r.data_ptr(), prof.data_ptr(), slope.data_ptr()
                 sc.ntab[i], sc.r0[i], sc.dlnr[i], sc.amp[i], sc.sign[i] = len(t1.r), t1.r0, t1.dlnr, t1.amp, t1.sign
-                if yc:
-                    amp = y0 if mapDict['units'] == 'yc' else maps.convertToDeltaT(y0, mapDict['obsFreqGHz'])
-                    t2 = signals.templateTables(obj.templateKind, beam, obj.params, amplitude=amp)
-                    if len(t1.r) != len(t2.r) or t1.r0 != t2.r0 or t1.dlnr != t2.dlnr:
-                        raise NemoFiltError("the unit and the scaled template must share their radii")
-                    r2, prof2, slope2 = eng._tableDev(t2)
-                    sc.prof2_d[i], sc.slope2_d[i], sc.amp2[i], sc.sign2[i] = prof2.data_ptr(), slope2.data_ptr(), t2.amp, t2.sign
+                sc.templateScale[i] = scale
             sc.filt_d = filt.data_ptr() + g * N * H * W * 4
             sc.signalNorm_d = scal.data_ptr() + g * (N + 2) * 8
             sc.relWeights_d = scal.data_ptr() + (g * (N + 2) + 1) * 8
@@ -658,20 +658,18 @@ class MatchedFilter(MapFilter):
 
             w = self._frequencyWeights()                                          # :587-608
             y0 = 2e-4
-            fSignalMaps = None
-            if self.params['outputUnits'] == 'yc':
-                # the unit templates (:611-618) and the amplitude-scaled ones of the normalisation (:639-646) are painted
-                # and transformed pairwise: one painter pass, one two-plane transform
-                fSignals, fSignalMaps = [], []
-                for mapDict in self.unfilteredMapsDictList:
-                    amp = y0 if mapDict['units'] == 'yc' else maps.convertToDeltaT(y0, mapDict['obsFreqGHz'])
-                    F2 = eng.fft(self._paintTemplatePair(mapDict['beamFileName'], amp), half=True)
-                    fSignals.append(F2[0])
-                    fSignalMaps.append(F2[1])
-                fSignalMaps = t.stack(fSignalMaps) if N > 1 else fSignalMaps[0].reshape(1, *self.shape)
-            else:
-                fSignals = [eng.fft(self._paintTemplate(m['beamFileName']), half=True) for m in self.unfilteredMapsDictList]   # :611-618
-            fSignals = t.stack(fSignals) if N > 1 else fSignals[0].reshape(1, *self.shape)
+            yc = self.params['outputUnits'] == 'yc'
+            # unit templates (:611-618), painted side by side and transformed together; in 'yc' mode the y0-scaled templates of
+            # the normalisation (:639-646) are these times a constant (see _unitTemplate): their spectra are not computed again
+            templates = t.empty((N,) + tuple(self.shape), dtype=t.float32, device=eng.dev)
+            self._ensureGeom()
+            templateScale = []
+            for i, mapDict in enumerate(self.unfilteredMapsDictList):
+                table, scale = self._unitTemplate(mapDict, y0 if yc else None)
+                eng.paint(self._geom, table, out=templates[i])
+                templateScale.append(scale)
+            fSignals = eng.fft(templates, half=True)
+            del templates
             self._dFilt = eng.build_filter(noiseCov, fSignals, w, half=True)              # :621-627  K6
             del noiseCov
 
@@ -680,7 +678,7 @@ class MatchedFilter(MapFilter):
                 # and transforms it again (:646).  FFT(template) . W is Hermitian, so that inverse / forward pair is the
                 # identity up to float32 round-off: here the window is multiplied into the spectrum directly, together
                 # with the filter, while the inverse transform of :847 loads it.
-                filteredSignal = self._applyFilterDevice(fSignalMaps, window=1.0, half=True)
+                filteredSignal = self._applyFilterDevice(fSignals, window=1.0, half=True, planeScale=templateScale)
                 cRADeg, cDecDeg = self.wcs.getCentreWCSCoords()
                 cx, cy = self.wcs.wcs2pix(cRADeg, cDecDeg)
                 # signalNorm = y0 / peak stays on the device (float64 division there): the host goes on enqueueing
@@ -696,11 +694,11 @@ class MatchedFilter(MapFilter):
                     # the peak and the planes' values there stay on the device; the float32 divisions of :667 are done on
                     # the host when somebody reads the weights (_DeviceWeights) - the enqueueing thread does not wait
                     mm = eng.map_max(filteredSignal, to_host=False)               # :661
-                    planes = eng.ifft(fSignalMaps, out='f32', filt=self._filtFor(True), window=1.0, half=True)       # :662-667
+                    planes = eng.ifft(fSignals, out='f32', filt=self._filtFor(True), window=1.0, half=True,
+                                      planeScale=templateScale)                                                      # :662-667
                     vals = planes.reshape(N, -1).index_select(1, mm[1:2].to(t.int64)).reshape(N)
                     self.fRelWeights = _DeviceWeights([m['obsFreqGHz'] for m in self.unfilteredMapsDictList],
                                                       t.cat([vals.to(t.float64), mm[:1]]))
-                del fSignalMaps
             elif self.params['outputUnits'] == 'uK':                              # :669-685
                 # the reference paints and transforms the unit templates a second time (:672-679): same values as fSignals
                 filteredSignal = self._applyFilterDevice(fSignals, half=True)
@@ -811,7 +809,7 @@ class MatchedFilter(MapFilter):
             self._dFiltSymOf = (self._dFilt, self.engine.symmetrise_filter(self._dFilt))
         return self._dFiltSymOf[1]
 
-    def _applyFilterDevice(self, cube, scale=True, window=None, half=False):
+    def _applyFilterDevice(self, cube, scale=True, window=None, half=False, planeScale=None):
         """Device form of applyFilter: complex (Fourier) or real [N,H,W] tensor in, float32 [H,W] map out (``half``: the
         complex cube holds half-stored spectra of real maps, as eng.fft(half=True) returns them); with
         ``scale`` the map is multiplied by signalNorm exactly as nemo/filters.py:853 does (numpy promotion).  The
@@ -844,7 +842,7 @@ class MatchedFilter(MapFilter):
             fMaps = eng.fft(cube, apod=True, half=True)                           # :845
             half = True
         out = eng.ifft(fMaps.reshape(-1, *self.shape), out='f32', unitary=False, filt=self._filtFor(half), sum=True,
-                       window=window, half=half)                                 # :847  K7 + K3
+                       window=window, half=half, planeScale=planeScale)          # :847  K7 + K3
         if 'bckSub' in self.params.keys() and 'bckSubScaleArcmin' in self.params.keys() and self.params['bckSub'] == True:
             out = maps.subtractBackground(out, self.wcs, smoothScaleDeg=self.params['bckSubScaleArcmin'] / 60.)   # :850-851
         if scale:

@@ -283,13 +283,15 @@ def main():
         cat = run_step(config)
     if not args.no_profile:
         # the SURVEY step: one more untimed step after the warm-up in which every entry point records its event pair.  It runs
-        # one scale at a time on one stream (scaleLanes / scaleGroup 1), so that an event pair brackets that entry point's
-        # kernels alone; the timed steps run the product's default schedule, in which two scales share the chip.
+        # one scale at a time on one stream, detection included (scaleLanes / scaleGroup 1, asyncDetection off), so that an
+        # event pair brackets that entry point's kernels alone; the timed steps run the product's default schedule, in which
+        # two scales and the detection stream share the chip.
         barrier()
         lib.nf_profile_select(ctypes.c_ulonglong(0xFFFFFFFFFFFFFFFF))
         lib.nf_profile_enable(1)
-        keepSched = {k: config.parDict.get(k, None) for k in ('scaleLanes', 'scaleGroup')}
+        keepSched = {k: config.parDict.get(k, None) for k in ('scaleLanes', 'scaleGroup', 'asyncDetection')}
         config.parDict['scaleLanes'], config.parDict['scaleGroup'] = 1, (1 if not tiled else 16)
+        config.parDict['asyncDetection'] = False
         cat = run_step(config)
         for k, v in keepSched.items():
             if v is None:
@@ -354,14 +356,15 @@ def main():
                                         "frac": round(kernels[dom]['GBps'] / HBM_PEAK_GBS, 4)},
                                "note": "achieved / avg_us: this entry point's launches in the timed steps, where %d filter scale(s) run "
                                        "side by side on %d HIP stream(s) - a launch then shares the chip's bandwidth with the other "
-                                       "lane's kernel, so its duration is not its own; 'solo': the same launches in the survey "
-                                       "step (one scale at a time).  The chip-wide figure is pipeline.hbm_frac_wall." % (lanes, lanes)}
+                                       "lane's kernel and with the detection stream, so its duration is not its own; 'solo': the same "
+                                       "launches in the survey step (one scale at a time, one stream).  The chip-wide figure is "
+                                       "pipeline.hbm_frac_wall." % (lanes, lanes)}
             out["pipeline"] = {"device_ms_per_step": round(devMs / surveySteps, 2),
                                "alg_GB_per_step": round(algGB / surveySteps, 3),
                                "hbm_frac_device_time": round(algGB / (devMs / 1e3) / HBM_PEAK_GBS, 4),
                                "hbm_frac_wall": round(algGB / surveySteps / (elapsed / args.steps) / HBM_PEAK_GBS, 4),
                                "note": "per-entry-point table from one untimed survey step after the warm-up, run one scale at a time "
-                                       "on one stream (all entry points record events there; in the timed region only the dominant "
+                                       "on one stream, detection included (all entry points record events there; in the timed region only the dominant "
                                        "one does); hbm_frac_wall = algorithmic GB per step / timed wall per step / peak"}
             out["kernels"] = kernels
         if cpu is not None:

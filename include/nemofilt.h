@@ -98,7 +98,10 @@ int nf_cross_power(int prec, const void* F_d, void* NP_d, int N, long long npix,
  *                           (NULL = none); the window tables must be even, wy[H-y] == wy[y], as enmap.apply_window's
  *                           sinc(fftfreq) tables are.  planeScale (HOST doubles, or NULL): one more real factor per plane of
  *                           the sum (nSum > 1: nSum entries) or per batch entry (nSum == 1: batch entries), at most 8 -
- *                           the amplitude of a template whose spectrum is given for unit amplitude (nemo/filters.py:639-646)
+ *                           the amplitude of a template whose spectrum is given for unit amplitude (nemo/filters.py:639-646).
+ *                           rowLo < rowHi: only the output rows rowLo .. rowHi - 1 (widened to whole row pairs) are
+ *                           computed, the rest of out_d is left as it was - nemo/filters.py:654-657 reads the filtered
+ *                           template only around the tile centre; both 0: the whole map
  *   nf_cross_power_half, nf_build_filter_half = nf_cross_power / nf_build_filter reading half-stored F_d / S_d and writing
  *                           full planes */
 int nf_fft2_forward_half(nf_plan* plan, int prec, const void* in_d, int inType, void* out_d, int batch,
@@ -106,7 +109,7 @@ int nf_fft2_forward_half(nf_plan* plan, int prec, const void* in_d, int inType, 
 int nf_symmetrise_filter(const float* filt_d, double* filtSym_d, int N, int H, int W, void* stream);
 int nf_fft2_inverse_half(nf_plan* plan, int prec, const void* in_d, const double* filtSym_d, int nSum, int filtPerBatch,
                          const double* wy_d, const double* wx_d, const double* planeScale, void* work_d, void* out_d,
-                         int outType, int batch, int unitary, void* stream);
+                         int outType, int batch, int rowLo, int rowHi, int unitary, void* stream);
 /* nf_fft2_inverse_half of ONE map (nSum planes summed, or one plane) with the pointwise steps that follow it on the path
  * applied while the real rows are stored (they would otherwise re-read and re-write the map):
  *   scale_d (device scalar) [+ mask_d]: out = float32(value) * scale [* mask], in the output type - the cast of
@@ -421,6 +424,7 @@ typedef struct nf_mf_tile {
     double y0;                         /* yc: amplitude of the normalisation template (2e-4 in the reference) */
     const double* centreYX_d;          /* yc: (y, x) of the tile centre, 2 device doubles */
     int centreClass;                   /* yc: pointsClass of that point for nf_spline_eval */
+    int centreRowLo, centreRowHi;      /* yc, N == 1: the rows of the filtered template that evaluation reads (0, 0: all) */
     int halfWin;
     const double* winY_d;              /* yc: pixel-window tables for pow = +1 (nf_fft2_inverse_half) */
     const double* winX_d;

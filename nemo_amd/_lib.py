@@ -39,7 +39,7 @@ class MfTile(ctypes.Structure):
                 ('medWeights_d', c_void_p), ('wtype', c_int), ('ny', c_int), ('nx', c_int), ('yEdges_d', c_void_p),
                 ('xEdges_d', c_void_p), ('overlap', c_int), ('numBins', c_int), ('estimator', c_int),
                 ('quantiles', ctypes.POINTER(c_double)), ('trimSizePix', c_int), ('apodPix', c_int), ('y0', c_double),
-                ('centreYX_d', c_void_p), ('centreClass', c_int), ('halfWin', c_int), ('winY_d', c_void_p), ('winX_d', c_void_p),
+                ('centreYX_d', c_void_p), ('centreClass', c_int), ('centreRowLo', c_int), ('centreRowHi', c_int), ('halfWin', c_int), ('winY_d', c_void_p), ('winX_d', c_void_p),
                 ('axisWinY_d', c_void_p), ('axisWinX_d', c_void_p)]
 
 
@@ -65,7 +65,7 @@ SIGNATURES = {
     'nf_cross_power': (c_int, [c_int, c_void_p, c_void_p, c_int, c_ll, c_void_p]),
     'nf_fft2_forward_half': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     'nf_fft2_inverse_half': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, ctypes.POINTER(c_double),
-                                     c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+                                     c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'nf_fft2_inverse_half_epi': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                          c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     'nf_symmetrise_filter': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),

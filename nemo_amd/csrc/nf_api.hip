@@ -275,7 +275,7 @@ int nf_fft2_inverse_fused(nf_plan* p, int prec, const void* in, const float* fil
 
 int nf_fft2_inverse_half(nf_plan* p, int prec, const void* in, const double* filtSym, int nSum, int filtPerBatch,
                          const double* wy, const double* wx, const double* planeScale, void* work, void* out, int outType, int batch,
-                         int unitary, void* stream) {
+                         int rowLo, int rowHi, int unitary, void* stream) {
     if (!p || !in || !work || !out || batch < 1 || (outType != NF_IN_REAL64 && outType != NF_IN_REAL32) || nSum < 1 ||
         (nSum > 1 && (!filtSym || batch != 1)) || ((wy == nullptr) != (wx == nullptr)) || (planeScale && (nSum > 1 ? nSum : batch) > 8)) {
         nf_set_error("nf_fft2_inverse_half: bad arguments (the output must be real)");
@@ -287,9 +287,9 @@ int nf_fft2_inverse_half(nf_plan* p, int prec, const void* in, const double* fil
     const long long fbs = (filtSym && filtPerBatch) ? (long long)p->H * p->W : 0;
     if (prec == NF_F32)
         return p->pf.inverse_half(in, work, out, outType, batch, unitary ? 1 : 0, scale, S(stream), filtSym, nSum, fbs, wy, wx, nullptr,
-                                  nullptr, nullptr, planeScale);
+                                  nullptr, nullptr, planeScale, rowLo, rowHi);
     return p->pd.inverse_half(in, work, out, outType, batch, unitary ? 1 : 0, scale, S(stream), filtSym, nSum, fbs, wy, wx, nullptr,
-                              nullptr, nullptr, planeScale);
+                              nullptr, nullptr, planeScale, rowLo, rowHi);
 }
 
 int nf_fft2_inverse_half_epi(nf_plan* p, int prec, const void* in, const double* filtSym, int nSum, const double* wy,

@@ -52,6 +52,8 @@ struct LineArgs {
     long long mulBatchStride;  // filter plane offset per batch entry (elements; 0 = the same filter for every batch entry)
     int nSum;                // planes summed as sum_i in_i * mul_i (1 = none)
     long long sumStride;     // plane pitch of in / mul for the sum (elements)
+    int storeLo, storeHi;    // columns kernel: only the elements (rows) storeLo <= e < storeHi are stored (storeHi == 0: all)
+    int lineBase;            // rows kernel: first line of this launch (lines lineBase .. nLines - 1)
     int usePlaneScale;       // halfIn: plane pl of the sum (nSum > 1) / batch entry b (nSum <= 1) is also multiplied by planeScale[pl / b]
     double planeScale[8];
     const double* winLine;   // pixel-window table along the line index (columns kernel: wx[col]) and
@@ -97,7 +99,7 @@ struct Plan2D {
     int inverse_half(const void* in, void* work, void* out, int outType, int batch, int scaleDiv, double scale,
                      hipStream_t stream, const double* filtSym, int nSum, long long filtBatchStride, const double* winY,
                      const double* winX, const double* epiScale = nullptr, const unsigned char* epiMask = nullptr,
-                     const void* epiZeroRef = nullptr, const double* planeScale = nullptr);
+                     const void* epiZeroRef = nullptr, const double* planeScale = nullptr, int rowLo = 0, int rowHi = 0);
 };
 
 }  // namespace nf

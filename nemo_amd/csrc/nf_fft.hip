@@ -399,7 +399,8 @@ __device__ __forceinline__ void fft_stage(cpx<T>* __restrict__ buf, const nf::Li
 #define NF_STORE_ALL(OT)                                                                                          \
     _Pragma("unroll") for (int k = 0; k < R; ++k) {                                                               \
         const unsigned e = base + (unsigned)k * L;                                                                \
-        if (!BLUE || e < (unsigned)p.n) store_elem<T, OT, BLUE>(a, G.outP, lo + e * (unsigned)a.outElemStride, (int)e, x[k]); \
+        if ((!BLUE || e < (unsigned)p.n) && (!COLS || a.storeHi == 0 || (e >= (unsigned)a.storeLo && e < (unsigned)a.storeHi))) \
+            store_elem<T, OT, BLUE>(a, G.outP, lo + e * (unsigned)a.outElemStride, (int)e, x[k]); \
     }
                 if (COLS && SPEC >= 2 && a.packNyq && G.line0 + line == 0) {
                     // inverse of the packed column: the two real columns come back as real and imaginary part
@@ -413,8 +414,10 @@ __device__ __forceinline__ void fft_stage(cpx<T>* __restrict__ buf, const nf::Li
                         v0.y = (T)0;
                         vN.x = x[k].y * ri;
                         vN.y = (T)0;
-                        ((cpx<T>*)G.outP)[e * (unsigned)a.outElemStride] = v0;
-                        ((cpx<T>*)G.outP)[e * (unsigned)a.outElemStride + colN] = vN;
+                        if (a.storeHi == 0 || (e >= (unsigned)a.storeLo && e < (unsigned)a.storeHi)) {
+                            ((cpx<T>*)G.outP)[e * (unsigned)a.outElemStride] = v0;
+                            ((cpx<T>*)G.outP)[e * (unsigned)a.outElemStride + colN] = vN;
+                        }
                     }
                 } else if (COLS && SPEC == 1) {
                     // spectrum of a real map: F[-y][-c] = conj F[y][c]; this tile holds columns c <= W/2 and writes both
@@ -816,7 +819,7 @@ __global__ void __launch_bounds__(512, (MODE == 0 ? 4 : 2)) k_fft_rows(nf::LineA
     cpx<T>* buf = (cpx<T>*)nf_smem;
     const nf::LinePlan<T>& p = a.plan;
     Geo G;
-    G.line0 = blockIdx.x * a.linesPerWG;
+    G.line0 = a.lineBase + blockIdx.x * a.linesPerWG;
     G.nl = min(a.linesPerWG, a.nLines - G.line0);
     G.TB = a.tb;
     G.TL = blockDim.x / a.tb;
@@ -1364,7 +1367,7 @@ int launch_lines(const LineArgs<T>& a, bool cols, int batch, int threads, hipStr
         nf_set_error("internal: Bluestein length with a radix above 8");
         return NF_ERR_SIZE;
     }
-    dim3 grid = cols ? dim3(((a.nTiles + 7) / 8) * 8, batch) : dim3(nf_div_up(a.nLines, a.linesPerWG), batch);
+    dim3 grid = cols ? dim3(((a.nTiles + 7) / 8) * 8, batch) : dim3(nf_div_up(a.nLines - a.lineBase, a.linesPerWG), batch);
     // 3: the fused load of ONE half-stored plane (batched form of 2)
     const int spec = cols ? (a.mirror ? 1 : (a.fused ? ((a.herm && a.halfIn && a.nSum <= 1) ? 3 : 2) : 0)) : a.pairMode;
 #define NF_LAUNCH2(K, M, SP) hipLaunchKernelGGL((K<T, M, SP>), grid, dim3(threads), lds, stream, a)
@@ -1578,7 +1581,7 @@ template <typename T>
 int Plan2D<T>::inverse_half(const void* in, void* work, void* out, int outType, int batch, int scaleDiv, double scale,
                             hipStream_t stream, const double* filtSym, int nSum, long long filtBatchStride, const double* winY,
                             const double* winX, const double* epiScale, const unsigned char* epiMask, const void* epiZeroRef,
-                            const double* planeScale) {
+                            const double* planeScale, int rowLo, int rowHi) {
     if (outType == 0) {
         nf_set_error("a half-stored spectrum has a real inverse transform: ask for real output");
         return NF_ERR_ARG;
@@ -1617,6 +1620,17 @@ int Plan2D<T>::inverse_half(const void* in, void* work, void* out, int outType, 
         c.packNyq = 1;
         c.nLines = W / 2;
         c.nTiles = nf_div_up(c.nLines, colsPerWG);
+    }
+    if (rowHi > rowLo) {
+        // only the output rows rowLo .. rowHi - 1 are wanted (whole row pairs): the column pass stores just those rows of the
+        // intermediate plane, the row pass runs on just those lines
+        const int lo = (rowLo < 0 ? 0 : rowLo) & ~1, hi = rowHi >= H ? H : ((rowHi + 1) & ~1);
+        if (lo < hi && (lo > 0 || hi < H)) {
+            c.storeLo = lo;
+            c.storeHi = hi;
+            a.lineBase = lo / 2;
+            a.nLines = (hi + 1) / 2;
+        }
     }
     int rc = launch_lines<T>(c, true, batch, threadsCol, stream);
     if (rc) return rc;

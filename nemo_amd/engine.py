@@ -261,23 +261,25 @@ class TileEngine(object):
                   1 if unitary else 0, stream_ptr()), "nf_fft2_forward")
         return out.reshape(x.shape)
 
-    def ifft(self, X, out='complex', unitary=False, clobber=False, filt=None, sum=False, window=None, half=False, planeScale=None):
+    def ifft(self, X, out='complex', unitary=False, clobber=False, filt=None, sum=False, window=None, half=False, planeScale=None,
+             rows=None):
         """enmap.ifft; ``out`` in {'complex', 'f64', 'f32'} (the latter two keep the real part only).
 
         ``filt`` (float32 [N,H,W] or [H,W]) and ``window`` (power of the pixel window) are multiplied in while the
         transform loads its input (nemo/filters.py:847 and enmap.apply_window); with ``sum`` the N planes of X are summed
         after the product and one map comes out.  ``half``: X holds half-stored spectra (fft(half=True)); real output only.
         ``planeScale`` (half only): one more real factor per plane - the amplitudes of templates whose spectra are given for
-        unit amplitude."""
+        unit amplitude; ``rows`` = (lo, hi) (half only): only the output rows lo .. hi - 1 are computed, the rest of the
+        returned map is uninitialised."""
         t = self.t
         X3 = X.reshape(-1, self.H, self.W)
         prec = prec_of(X3)
         if half and out == 'complex':
             raise NemoFiltError("the inverse transform of a half-stored spectrum is real")
-        if planeScale is not None and not half:
-            raise NemoFiltError("planeScale belongs to the inverse transform of half-stored spectra")
+        if (planeScale is not None or rows is not None) and not half:
+            raise NemoFiltError("planeScale / rows belong to the inverse transform of half-stored spectra")
         if filt is not None or window is not None or half:
-            return self._ifft_fused(X3, X.shape, out, unitary, clobber, filt, sum, window, half, planeScale)
+            return self._ifft_fused(X3, X.shape, out, unitary, clobber, filt, sum, window, half, planeScale, rows)
         work = X3 if clobber else t.empty_like(X3)
         if out == 'complex':
             res = t.empty_like(X3)
@@ -292,7 +294,7 @@ class TileEngine(object):
                                        1 if unitary else 0, stream_ptr()), "nf_fft2_inverse")
         return res.reshape(X.shape)
 
-    def _ifft_fused(self, X3, shape, out, unitary, clobber, filt, sum, window, half=False, planeScale=None):
+    def _ifft_fused(self, X3, shape, out, unitary, clobber, filt, sum, window, half=False, planeScale=None, rows=None):
         t = self.t
         prec = prec_of(X3)
         N = X3.shape[0]
@@ -328,8 +330,10 @@ class TileEngine(object):
                 if len(planeScale) != N or N > 8:
                     raise NemoFiltError("planeScale: one factor per plane, at most 8 planes")
                 ps = (ctypes.c_double * N)(*[float(v) for v in planeScale])
+            rowLo, rowHi = (0, 0) if rows is None else (int(rows[0]), int(rows[1]))
             check(self.lib.nf_fft2_inverse_half(self.plan, prec, ptr(X3), ptr(f3), nSum, perBatch, ptr(wy), ptr(wx), ps, ptr(work),
-                                                ptr(res), outType, batch, 1 if unitary else 0, stream_ptr()), "nf_fft2_inverse_half")
+                                                ptr(res), outType, batch, rowLo, rowHi, 1 if unitary else 0, stream_ptr()),
+                  "nf_fft2_inverse_half")
         else:
             check(self.lib.nf_fft2_inverse_fused(self.plan, prec, ptr(X3), ptr(f3), nSum, perBatch, ptr(wy), ptr(wx), ptr(work),
                                                  ptr(res), outType, batch, 1 if unitary else 0, stream_ptr()), "nf_fft2_inverse_fused")

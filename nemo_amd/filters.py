@@ -573,8 +573,8 @@ class MatchedFilter(MapFilter):
             if 'centrePoint' not in shared:
                 cRADeg, cDecDeg = first.wcs.getCentreWCSCoords()
                 cx, cy = first.wcs.wcs2pix(cRADeg, cDecDeg)
-                shared['centrePoint'] = eng.spline_points([[cy, cx]], halfWin=32)
-            pts = shared['centrePoint']
+                shared['centrePoint'] = (eng.spline_points([[cy, cx]], halfWin=32), first._centreRows(cy))
+            pts, (tile.centreRowLo, tile.centreRowHi) = shared['centrePoint']
             tile.centreYX_d, tile.centreClass = pts.dev.data_ptr(), pts.pointsClass
             wy, wx = eng.window(1.0)
             tile.winY_d, tile.winX_d = wy.data_ptr(), wx.data_ptr()
@@ -678,14 +678,16 @@ class MatchedFilter(MapFilter):
                 # and transforms it again (:646).  FFT(template) . W is Hermitian, so that inverse / forward pair is the
                 # identity up to float32 round-off: here the window is multiplied into the spectrum directly, together
                 # with the filter, while the inverse transform of :847 loads it.
-                filteredSignal = self._applyFilterDevice(fSignals, window=1.0, half=True, planeScale=templateScale)
                 cRADeg, cDecDeg = self.wcs.getCentreWCSCoords()
                 cx, cy = self.wcs.wcs2pix(cRADeg, cDecDeg)
+                bckSub = 'bckSub' in self.params.keys() and 'bckSubScaleArcmin' in self.params.keys() and self.params['bckSub'] == True
+                # one frequency: the filtered template is only read around the tile centre (:654-657) - only those rows are made
+                filteredSignal = self._applyFilterDevice(fSignals, window=1.0, half=True, planeScale=templateScale,
+                                                         rows=self._centreRows(cy) if (N == 1 and not bckSub) else None)
                 # signalNorm = y0 / peak stays on the device (float64 division there): the host goes on enqueueing
                 peak = eng.spline_eval(filteredSignal, [[cy, cx]], to_host=False)                # :654-657  K9
                 self._signalNorm = eng.signal_norm('yc', peak, y0)                # :659
                 self.fRelWeights = {}
-                bckSub = 'bckSub' in self.params.keys() and 'bckSubScaleArcmin' in self.params.keys() and self.params['bckSub'] == True
                 if N == 1 and not bckSub:
                     # one frequency, no background subtraction: the per-frequency plane of :662 is the filtered signal
                     # itself, so the relative weight is a float32 value divided by itself
@@ -809,7 +811,13 @@ class MatchedFilter(MapFilter):
             self._dFiltSymOf = (self._dFilt, self.engine.symmetrise_filter(self._dFilt))
         return self._dFiltSymOf[1]
 
-    def _applyFilterDevice(self, cube, scale=True, window=None, half=False, planeScale=None):
+    def _centreRows(self, cy, halfWin=32):
+        """The rows of a map that the spline evaluation at row position ``cy`` reads (nf_spline_eval's window, with a margin)."""
+        H = self.shape[0]
+        iy = int(np.floor(cy))
+        return max(0, iy - halfWin - 2), min(H, iy + halfWin + 4)
+
+    def _applyFilterDevice(self, cube, scale=True, window=None, half=False, planeScale=None, rows=None):
         """Device form of applyFilter: complex (Fourier) or real [N,H,W] tensor in, float32 [H,W] map out (``half``: the
         complex cube holds half-stored spectra of real maps, as eng.fft(half=True) returns them); with
         ``scale`` the map is multiplied by signalNorm exactly as nemo/filters.py:853 does (numpy promotion).  The
@@ -842,7 +850,7 @@ class MatchedFilter(MapFilter):
             fMaps = eng.fft(cube, apod=True, half=True)                           # :845
             half = True
         out = eng.ifft(fMaps.reshape(-1, *self.shape), out='f32', unitary=False, filt=self._filtFor(half), sum=True,
-                       window=window, half=half, planeScale=planeScale)          # :847  K7 + K3
+                       window=window, half=half, planeScale=planeScale, rows=rows)          # :847  K7 + K3
         if 'bckSub' in self.params.keys() and 'bckSubScaleArcmin' in self.params.keys() and self.params['bckSub'] == True:
             out = maps.subtractBackground(out, self.wcs, smoothScaleDeg=self.params['bckSubScaleArcmin'] / 60.)   # :850-851
         if scale:

@@ -190,6 +190,17 @@ def test_half_stored_spectra(shape, dtype, N):
     assert np.abs(got - enmap.apod(x, 20)).max() <= (1e-12 if dtype == np.float64 else 2e-5)
     with pytest.raises(Exception):
         eng.ifft(Fh, out='complex', half=True)
+    # per-plane factors (the amplitude of a template whose spectrum is given for unit amplitude) and a row range: the same
+    # transform of the scaled spectra, and - bit for bit - the rows lo .. hi - 1 of the whole-map result
+    ps = rng.uniform(-3, 3, N)
+    ref = np.real(enmap.ifft(Fd * win * filt * ps[:, None, None], normalize=False))
+    got = _np(eng.ifft(Fh, out=out, filt=dfilt, window=1.0, half=True, planeScale=ps))
+    assert np.abs(got - ref).max() <= tol * np.abs(ref).max()
+    gotSum = _np(eng.ifft(Fh, out=out, filt=dfilt, window=1.0, sum=True, half=True, planeScale=ps))
+    assert np.abs(gotSum - ref.sum(axis=0)).max() <= tol * np.abs(ref).max()
+    for lo, hi in ((H // 2 - 7, H // 2 + 9), (0, 5), (H - 3, H), (3, 4)):
+        part = _np(eng.ifft(Fh, out=out, filt=dfilt, window=1.0, sum=True, half=True, planeScale=ps, rows=(lo, hi)))
+        assert np.array_equal(part[lo:hi], gotSum[lo:hi]), (lo, hi)
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])

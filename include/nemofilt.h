@@ -198,7 +198,7 @@ int nf_edge_check(int vtype, const void* filtered_d, const unsigned char* psMask
 
 /* Tail of buildAndApply (nemo/filters.py:717-756 and :1112-1157): S/N map, survey/point-source/edge/apodisation
  * masks.  filtered_d is updated in place; mulSurvey != 0 for the Fourier-space variant (nemo/filters.py:741).
- * Mask inputs may be NULL (= all ones). */
+ * Mask inputs may be NULL (= all ones).  rmsOut_d may be rms_d (in place).  Values that do not change are not stored again. */
 int nf_finalize(int vtype, void* filtered_d, const float* rms_d, const unsigned char* surveyMask_d,
                 const unsigned char* psMask_d, const unsigned char* edgeCheck_d, void* sn_d, float* rmsOut_d,
                 unsigned char* maskOut_d, int H, int W, int apodPix, int mulSurvey, void* stream);

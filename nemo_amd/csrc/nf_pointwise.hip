@@ -431,14 +431,15 @@ int sn_cached(int vtype, const void* data, const float* rms, double* sn, long lo
 //   filtered' = filtered*edge [*surveyMask' if fourier variant];  surveyMask' = edge*surveyMask*psMask
 //   surveyMask'' = surveyMask' * apodMask;  SN' = SN*surveyMask'' (NaN -> 0);  RMS' = RMS*surveyMask''
 template <typename VT>
-__global__ void k_finalize(VT* __restrict__ filtered, const float* __restrict__ rms, const unsigned char* __restrict__ surveyMask,
+__global__ void k_finalize(VT* __restrict__ filtered, const float* rms, const unsigned char* __restrict__ surveyMask,
                            const unsigned char* __restrict__ psMask, const unsigned char* __restrict__ edgeCheck, VT* __restrict__ snOut,
-                           float* __restrict__ rmsOut, unsigned char* __restrict__ maskOut, int H, int W, int apodPix,
+                           float* rmsOut, unsigned char* __restrict__ maskOut, int H, int W, int apodPix,
                            int mulSurvey) {
     long long n = (long long)H * W;
     for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x) {
         int y = (int)(p / W), x = (int)(p % W);
-        VT f = filtered[p];
+        const VT fIn = filtered[p];
+        VT f = fIn;
         float r = rms[p];
         VT sn = f;
         if (r > 0.0f) sn = f / (VT)r;
@@ -452,9 +453,12 @@ __global__ void k_finalize(VT* __restrict__ filtered, const float* __restrict__ 
         unsigned char fm = inside ? sm : (unsigned char)0;
         sn = sn * (VT)fm;
         if (sn != sn) sn = (VT)0;
-        filtered[p] = f;
+        // stores of values that are already there are left out (x * 1 is x, bit for bit): with masks that are mostly one the
+        // filtered map - and the noise map, when it is updated in place - cost no write traffic
+        if (f != fIn || f != f) filtered[p] = f;
         snOut[p] = sn;
-        rmsOut[p] = r * (float)fm;
+        const float rNew = r * (float)fm;
+        if (rmsOut != rms || rNew != r || rNew != rNew) rmsOut[p] = rNew;
         maskOut[p] = fm;
     }
 }

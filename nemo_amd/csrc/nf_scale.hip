@@ -37,7 +37,7 @@ __global__ void k_rel_weights(const float* __restrict__ planes, const double* __
 
 // ---- workspace layout -------------------------------------------------------------------------------------------
 struct Layout {
-    size_t T, F, filtSym, work, sig, planes, pre, rms0, noise, noiseBytes, edgeTmp, edgeOut, mapMax, peak, total;
+    size_t T, F, filtSym, work, sig, planes, pre, noise, noiseBytes, edgeTmp, edgeOut, mapMax, peak, total;
 };
 
 Layout layout_of(const nf_mf_tile& t) {
@@ -62,7 +62,6 @@ Layout layout_of(const nf_mf_tile& t) {
     L.sig = take(npix * 4);                          // filtered template
     L.planes = take(yc && N > 1 ? N * npix * 4 : 0);
     L.pre = take(npix * outB);                       // filtered map before the pixel-window undo
-    L.rms0 = take(npix * 4);
     L.noiseBytes = nf_noise_workspace_bytes(t.H, t.W, t.ny, t.nx, t.numBins);
     L.noise = take(L.noiseBytes);
     L.edgeTmp = take(t.trimSizePix > 0 ? npix : 0);
@@ -136,7 +135,7 @@ int run_scale(nf_plan* plan, const nf_mf_tile& t, const nf_mf_scale& sc, const L
     float* planes = (float*)(ws + L.planes);
     const bool undo = t.axisWinY_d != nullptr;
     void* pre = undo ? (void*)(ws + L.pre) : sc.data_d;
-    float* rms0 = (float*)(ws + L.rms0);
+    float* rms0 = sc.rms_d;                                // the noise map is made in its output buffer, masked there in place
     double* mapMax = (double*)(ws + L.mapMax);
     double* peak = (double*)(ws + L.peak);
     void* S = (void*)st;

@@ -629,7 +629,7 @@ class TileEngine(object):
     def finalize(self, filtered, rms, surveyMask, psMask, edgeCheck, mulSurvey):
         t = self.t
         sn = t.empty_like(filtered)
-        rmsOut = t.empty_like(rms)
+        rmsOut = rms                                   # masked in place (the caller's noise map is the one made for this call)
         maskOut = t.empty((self.H, self.W), dtype=t.uint8, device=self.dev)
         check(self.lib.nf_finalize(prec_of(filtered), ptr(filtered), ptr(rms), ptr(surveyMask), ptr(psMask), ptr(edgeCheck),
                                    ptr(sn), ptr(rmsOut), ptr(maskOut), self.H, self.W, self.APOD_PIX, 1 if mulSurvey else 0,

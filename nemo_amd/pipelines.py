@@ -378,6 +378,10 @@ def _filterMapsAndMakeCatalogs(config, rootOutDir=None, useCachedFilters=False, 
         # round trips of one scale's detection overlap the next one's)
         numWorkers = max(1, int(os.environ.get('NEMO_AMD_ASYNC_WORKERS', config.parDict.get('asyncWorkers', 1))))
         pool, detStream = _detectionWorkers(numWorkers)
+        si = float(os.environ.get('NEMO_AMD_SWITCH_INTERVAL', '0'))
+        if si > 0:
+            import sys
+            sys.setswitchinterval(si)
     try:
         for tileName in config.tileNames:
             if verbose == True:

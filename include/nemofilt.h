@@ -201,7 +201,14 @@ int nf_edge_check(int vtype, const void* filtered_d, const unsigned char* psMask
  * Mask inputs may be NULL (= all ones).  rmsOut_d may be rms_d (in place).  Values that do not change are not stored again. */
 int nf_finalize(int vtype, void* filtered_d, const float* rms_d, const unsigned char* surveyMask_d,
                 const unsigned char* psMask_d, const unsigned char* edgeCheck_d, void* sn_d, float* rmsOut_d,
-                unsigned char* maskOut_d, int H, int W, int apodPix, int mulSurvey, void* stream);
+                unsigned char* maskOut_d, int H, int W, int apodPix, int mulSurvey, unsigned long long* snChunkRange_d,
+                void* stream);
+/* snChunkRange_d (optional, NULL = not wanted): 2 * nf_sn_chunks(H, W) 64-bit words - for every chunk of 1024 consecutive
+ * pixels (raster order) the largest S/N value written to sn_d, then, in the second half, the smallest (as order-preserving
+ * integer keys).  Handed to nf_label_and_stats with the same sn_d, it lets the labelling pass skip, unread, every chunk whose
+ * values cannot exceed the detection threshold - at 4 sigma nearly all of them (no counterpart in the reference: ndimage.label
+ * reads the whole map). */
+int nf_sn_chunks(int H, int W);
 
 /* nemo/pipelines.py:244-247 (useCachedRMSMap branch of the driver): sn_d (float64) = data, divided by the cached RMS map
  * (float32) where that is positive. */
@@ -297,10 +304,10 @@ int nf_object_stats_chunks(int vtype, const void* sn_d, int negate, const int* l
  * nf_object_stats writes them); the number of labels found stays on the device and comes back in stats_d[0] (the count field
  * of the background record, which is otherwise zero).  If it exceeds maxObjects the records are incomplete (labels above
  * maxObjects were skipped): repeat with room for that many.  dirty_d as nf_label_components_kept (NULL: labels_d is written
- * everywhere).  The call does not wait for the GPU: several maps' detections can be enqueued and their records fetched in
+ * everywhere).  snChunkRange_d: the table nf_finalize made for this very sn_d, or NULL.  The call does not wait for the GPU: several maps' detections can be enqueued and their records fetched in
  * one transfer (photometry.findObjectsGroup). */
 int nf_label_and_stats(int vtype, const void* sn_d, double threshold, int negate, int* labels_d, int H, int W, int* work_d,
-                       int* dirty_d, int maxObjects, double* stats_d, void* stream);
+                       int* dirty_d, int maxObjects, double* stats_d, const unsigned long long* snChunkRange_d, void* stream);
 
 /* The segment moments behind measureShapes (photometry.findObjects, nemo/photometry.py:136-150): per label id 0..numObjects
  * a record of 10 doubles {xMin, yMin, xMax, yMax, S, Sx, Sy, Sxx, Syy, Sxy} with S = sum v, Sx = sum v*(x - xMin),
@@ -449,6 +456,7 @@ typedef struct nf_mf_scale {
     void* sn_d;                        /* [H][W] S/N map, type of data_d */
     float* rms_d;                      /* [H][W] noise map */
     unsigned char* mask_d;             /* [H][W] survey mask after edge trim / apodisation border */
+    unsigned long long* snChunkRange_d; /* optional (may be NULL): the S/N range table of nf_finalize for sn_d */
 } nf_mf_scale;
 
 size_t nf_matched_filter_workspace_bytes(const nf_mf_tile* tile);

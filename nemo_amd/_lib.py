@@ -48,7 +48,7 @@ class MfScale(ctypes.Structure):
     _fields_ = [('r_d', _PD8), ('prof_d', _PD8), ('slope_d', _PD8),
                 ('ntab', c_int * NF_MF_MAXFREQ), ('r0', _D8), ('dlnr', _D8), ('amp', _D8), ('sign', _D8), ('templateScale', _D8),
                 ('filt_d', c_void_p), ('signalNorm_d', c_void_p), ('relWeights_d', c_void_p), ('data_d', c_void_p),
-                ('sn_d', c_void_p), ('rms_d', c_void_p), ('mask_d', c_void_p)]
+                ('sn_d', c_void_p), ('rms_d', c_void_p), ('mask_d', c_void_p), ('snChunkRange_d', c_void_p)]
 
 
 # name -> (restype, argtypes); every symbol include/nemofilt.h declares
@@ -91,7 +91,8 @@ SIGNATURES = {
     'nf_median_stack': (c_int, [c_int, c_void_p, c_void_p, c_int, c_ll, c_void_p]),
     'nf_edge_check': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'nf_finalize': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
-                            c_int, c_int, c_int, c_void_p]),
+                            c_int, c_int, c_int, c_void_p, c_void_p]),
+    'nf_sn_chunks': (c_int, [c_int, c_int]),
     'nf_sn_cached': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_ll, c_void_p]),
     'nf_restore_zeros': (c_int, [c_int, c_void_p, c_void_p, c_ll, c_void_p]),
     'nf_subtract': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_ll, c_void_p]),
@@ -110,7 +111,7 @@ SIGNATURES = {
     'nf_label_chunk_flags_offset': (ctypes.c_longlong, [c_int, c_int]),
     'nf_label_components_kept': (c_int, [c_int, c_void_p, c_double, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     'nf_object_stats_chunks': (c_int, [c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
-    'nf_label_and_stats': (c_int, [c_int, c_void_p, c_double, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    'nf_label_and_stats': (c_int, [c_int, c_void_p, c_double, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     'nf_object_shapes': (c_int, [c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     'nf_resample_bilinear': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'nf_rms_table': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,

@@ -520,15 +520,18 @@ int nf_edge_check(int vtype, const void* filtered, const unsigned char* psMask, 
 
 int nf_finalize(int vtype, void* filtered, const float* rms, const unsigned char* surveyMask, const unsigned char* psMask,
                 const unsigned char* edgeCheck, void* sn, float* rmsOut, unsigned char* maskOut, int H, int W, int apodPix,
-                int mulSurvey, void* stream) {
+                int mulSurvey, unsigned long long* snChunkRange, void* stream) {
     if (!filtered || !rms || !sn || !rmsOut || !maskOut || H < 1 || W < 1) {
         nf_set_error("nf_finalize: bad arguments");
         return NF_ERR_ARG;
     }
-    nf::ProfScope ps(nf::PT_FINALIZE, S(stream), (double)H * W * (3 * (vtype == NF_F32 ? 4.0 : 8.0) + 8.0 + 4.0));
+    // map + noise map + three masks in; S/N map + mask out (the filtered map and the noise map are stored only where they change)
+    nf::ProfScope ps(nf::PT_FINALIZE, S(stream), (double)H * W * (2 * (vtype == NF_F32 ? 4.0 : 8.0) + 4.0 + 3.0 + 1.0));
     return nf::finalize(vtype, filtered, rms, surveyMask, psMask, edgeCheck, sn, rmsOut, maskOut, H, W, apodPix, mulSurvey,
-                        S(stream));
+                        snChunkRange, S(stream));
 }
+
+int nf_sn_chunks(int H, int W) { return (H < 1 || W < 1) ? 0 : nf_div_up((long long)H * W, NF_SN_CHUNK); }
 
 int nf_restore_zeros(int vtype, void* data, const void* ref, long long n, void* stream) {
     if (!data || !ref || n < 1) {
@@ -678,13 +681,13 @@ int nf_object_stats_chunks(int vtype, const void* sn, int negate, const int* lab
 }
 
 int nf_label_and_stats(int vtype, const void* sn, double threshold, int negate, int* labels, int H, int W, int* work, int* dirty,
-                       int maxObjects, double* stats, void* stream) {
+                       int maxObjects, double* stats, const unsigned long long* snChunkRange, void* stream) {
     if (!sn || !labels || !work || !stats || H < 1 || W < 1 || maxObjects < 0 || (vtype != NF_F32 && vtype != NF_F64)) {
         nf_set_error("nf_label_and_stats: bad arguments");
         return NF_ERR_ARG;
     }
     nf::ProfScope ps(nf::PT_LABEL, S(stream), (double)H * W * (vtype == NF_F32 ? 4.0 : 8.0));
-    return nf::label_and_stats(vtype, sn, threshold, negate, labels, H, W, work, dirty, maxObjects, stats, S(stream));
+    return nf::label_and_stats(vtype, sn, threshold, negate, labels, H, W, work, dirty, maxObjects, stats, snChunkRange, S(stream));
 }
 
 int nf_object_shapes(int vtype, const void* sn, int negate, const int* labels, int H, int W, int numObjects, double* shapes,

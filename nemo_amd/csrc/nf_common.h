@@ -80,6 +80,17 @@ __device__ __forceinline__ cpx<T> cmulnegi(cpx<T> a) {
 
 static inline int nf_div_up(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// float64 <-> unsigned 64-bit key with the same order (integer atomicMax / atomicMin on doubles)
+__device__ __forceinline__ unsigned long long nf_ordered_key(double v) {
+    unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    return (b & 0x8000000000000000ULL) ? ~b : (b | 0x8000000000000000ULL);
+}
+__device__ __forceinline__ double nf_key_value(unsigned long long k) {
+    const unsigned long long b = (k & 0x8000000000000000ULL) ? (k & 0x7FFFFFFFFFFFFFFFULL) : ~k;
+    return __longlong_as_double((long long)b);
+}
+#define NF_SN_CHUNK 1024   // pixels per chunk of the S/N range table (nf_finalize) = the labelling passes' chunk
+
 // ---- optional per-entry-point timing with HIP events (nf_profile_* in include/nemofilt.h) ----
 namespace nf {
 enum ProfTag {

@@ -43,7 +43,15 @@ __device__ __forceinline__ bool is_fg(const VT* sn, long long p, VT thr, int neg
 // the labels) touch the whole map.
 template <typename VT>
 __global__ void __launch_bounds__(256) k_ccl_init(const VT* __restrict__ sn, VT thr, int negate, int* __restrict__ parent,
-                                                  long long n, int* __restrict__ chunkFG) {
+                                                  long long n, int* __restrict__ chunkFG, const unsigned long long* __restrict__ snRange) {
+    if (snRange != nullptr) {
+        // the chunk's largest / smallest S/N is known (nf_finalize wrote it): a chunk that cannot hold foreground is not read
+        VT top = negate ? (VT)nf_key_value(snRange[gridDim.x + blockIdx.x]) * (VT)-1 : (VT)nf_key_value(snRange[blockIdx.x]);
+        if (!(top > thr)) {
+            if (threadIdx.x == 0) chunkFG[blockIdx.x] = 0;
+            return;
+        }
+    }
     const long long base = (long long)blockIdx.x * NF_SCAN_CHUNK;
     int any = 0;
     bool fg[4];
@@ -236,7 +244,7 @@ long long label_chunk_flags_offset(int H, int W) {
 }
 
 int label_components(int vtype, const void* sn, double threshold, int negate, int* labels, int H, int W, int* work,
-                     int* numObjects, int* dirty, hipStream_t s) {
+                     int* numObjects, int* dirty, hipStream_t s, const unsigned long long* snRange) {
     const long long n = (long long)H * W;
     if (n >= 2147483647LL) {
         nf_set_error("label_components: map too large for 32-bit pixel indices");
@@ -248,9 +256,9 @@ int label_components(int vtype, const void* sn, double threshold, int negate, in
     int* chunkFG = blockCounts + nblocks + 1;    // nblocks
     dim3 g(nblocks), b(256);
     if (vtype == NF_F64)
-        hipLaunchKernelGGL(k_ccl_init<double>, g, b, 0, s, (const double*)sn, threshold, negate, parent, n, chunkFG);
+        hipLaunchKernelGGL(k_ccl_init<double>, g, b, 0, s, (const double*)sn, threshold, negate, parent, n, chunkFG, snRange);
     else  // a Python-float threshold compared against a float32 map is cast to float32 by numpy
-        hipLaunchKernelGGL(k_ccl_init<float>, g, b, 0, s, (const float*)sn, (float)threshold, negate, parent, n, chunkFG);
+        hipLaunchKernelGGL(k_ccl_init<float>, g, b, 0, s, (const float*)sn, (float)threshold, negate, parent, n, chunkFG, snRange);
     hipLaunchKernelGGL(k_ccl_merge, g, b, 0, s, parent, H, W, chunkFG);
     hipLaunchKernelGGL(k_ccl_flatten_count, g, b, 0, s, parent, n, chunkFG, blockCounts);
     hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, s, blockCounts, nblocks);
@@ -417,8 +425,8 @@ int object_stats(int vtype, const void* sn, int negate, const int* labels, int H
 // Labelling and the per-label sums without a host round trip in between: the record table has room for maxObjects labels,
 // the number found stays on the device and comes back in stats[0] (the background record's count, otherwise unused).
 int label_and_stats(int vtype, const void* sn, double threshold, int negate, int* labels, int H, int W, int* work, int* dirty,
-                    int maxObjects, double* stats, hipStream_t s) {
-    int rc = label_components(vtype, sn, threshold, negate, labels, H, W, work, nullptr, dirty, s);
+                    int maxObjects, double* stats, const unsigned long long* snRange, hipStream_t s) {
+    int rc = label_components(vtype, sn, threshold, negate, labels, H, W, work, nullptr, dirty, s, snRange);
     if (rc != NF_OK) return rc;
     const long long n = (long long)H * W;
     const int nblocks = nf_div_up(n, NF_SCAN_CHUNK);

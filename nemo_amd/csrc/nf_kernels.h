@@ -34,7 +34,7 @@ int scale_mask(int vtype, const float* in, void* out, double norm, const double*
                long long n, hipStream_t s);
 int finalize(int vtype, void* filtered, const float* rms, const unsigned char* surveyMask, const unsigned char* psMask,
              const unsigned char* edgeCheck, void* snOut, float* rmsOut, unsigned char* maskOut, int H, int W, int apodPix,
-             int mulSurvey, hipStream_t s);
+             int mulSurvey, unsigned long long* chunkRange, hipStream_t s);
 int sn_cached(int vtype, const void* data, const float* rms, double* sn, long long n, hipStream_t s);
 int restore_zeros(int vtype, void* data, const void* ref, long long n, hipStream_t s);
 
@@ -77,11 +77,11 @@ int median_stack(int rtype, const void* in, void* out, int N, long long n, hipSt
 // nf_detect.hip
 long long label_chunk_flags_offset(int H, int W);
 int label_components(int vtype, const void* sn, double threshold, int negate, int* labels, int H, int W, int* work,
-                     int* numObjects, int* dirty, hipStream_t s);
+                     int* numObjects, int* dirty, hipStream_t s, const unsigned long long* snRange = nullptr);
 int object_stats(int vtype, const void* sn, int negate, const int* labels, int H, int W, int numObjects, double* stats,
                  const int* chunkFG, hipStream_t s, const int* count = nullptr);
 int label_and_stats(int vtype, const void* sn, double threshold, int negate, int* labels, int H, int W, int* work, int* dirty,
-                    int maxObjects, double* stats, hipStream_t s);
+                    int maxObjects, double* stats, const unsigned long long* snRange, hipStream_t s);
 int object_shapes(int vtype, const void* sn, int negate, const int* labels, int H, int W, int numObjects, double* shapes, hipStream_t s);
 int resample_bilinear(const float* in, float* out, int N, int H, int W, int H2, int W2, const double* yIdx, const double* xIdx,
                       hipStream_t s);

@@ -431,48 +431,83 @@ int sn_cached(int vtype, const void* data, const float* rms, double* sn, long lo
 //   filtered' = filtered*edge [*surveyMask' if fourier variant];  surveyMask' = edge*surveyMask*psMask
 //   surveyMask'' = surveyMask' * apodMask;  SN' = SN*surveyMask'' (NaN -> 0);  RMS' = RMS*surveyMask''
 template <typename VT>
-__global__ void k_finalize(VT* __restrict__ filtered, const float* rms, const unsigned char* __restrict__ surveyMask,
+__global__ void __launch_bounds__(256) k_finalize(VT* __restrict__ filtered, const float* rms, const unsigned char* __restrict__ surveyMask,
                            const unsigned char* __restrict__ psMask, const unsigned char* __restrict__ edgeCheck, VT* __restrict__ snOut,
                            float* rmsOut, unsigned char* __restrict__ maskOut, int H, int W, int apodPix,
-                           int mulSurvey) {
-    long long n = (long long)H * W;
-    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x) {
-        int y = (int)(p / W), x = (int)(p % W);
-        const VT fIn = filtered[p];
-        VT f = fIn;
-        float r = rms[p];
-        VT sn = f;
-        if (r > 0.0f) sn = f / (VT)r;
-        unsigned char e = edgeCheck ? edgeCheck[p] : (unsigned char)1;
-        unsigned char sm = (unsigned char)(e * (surveyMask ? surveyMask[p] : 1) * (psMask ? psMask[p] : 1));
-        f = f * (VT)e;
-        if (mulSurvey) f = f * (VT)sm;
-        // apod(ones, w) == 1 only at distance >= w-1 from every edge
-        int ay = min(apodPix, H), ax = min(apodPix, W);
-        bool inside = (ay <= 0 || (y >= ay - 1 && y <= H - ay)) && (ax <= 0 || (x >= ax - 1 && x <= W - ax));
-        unsigned char fm = inside ? sm : (unsigned char)0;
-        sn = sn * (VT)fm;
-        if (sn != sn) sn = (VT)0;
-        // stores of values that are already there are left out (x * 1 is x, bit for bit): with masks that are mostly one the
-        // filtered map - and the noise map, when it is updated in place - cost no write traffic
-        if (f != fIn || f != f) filtered[p] = f;
-        snOut[p] = sn;
-        const float rNew = r * (float)fm;
-        if (rmsOut != rms || rNew != r || rNew != rNew) rmsOut[p] = rNew;
-        maskOut[p] = fm;
+                           int mulSurvey, unsigned long long* __restrict__ chunkRange, int nchunks) {
+    const long long n = (long long)H * W;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wavesPerWG = blockDim.x >> 6;
+    // a wavefront takes one 1024-pixel chunk after another, 64 consecutive pixels at a time: the chunk's largest and smallest
+    // S/N stay in registers and leave through one plain store each (no atomics, nothing to clear beforehand)
+    for (long long c = (long long)blockIdx.x * wavesPerWG + wave; c < nchunks; c += (long long)gridDim.x * wavesPerWG) {
+        double mx = -INFINITY, mn = INFINITY;
+        // pixel coordinates by 32-bit arithmetic, advanced by 64 per step (H * W < 2^31: host check)
+        const unsigned p0 = (unsigned)c * NF_SN_CHUNK + (unsigned)lane;
+        int y = (int)(p0 / (unsigned)W), x = (int)(p0 - (unsigned)y * (unsigned)W);
+        const int ay = min(apodPix, H), ax = min(apodPix, W);
+#pragma unroll 4
+        for (int it = 0; it < NF_SN_CHUNK / 64; ++it) {
+            const unsigned p = p0 + (unsigned)it * 64u;
+            if (it > 0) {
+                x += 64;
+                while (x >= W) {
+                    x -= W;
+                    ++y;
+                }
+            }
+            if (p >= (unsigned)n) continue;
+            const VT fIn = filtered[p];
+            VT f = fIn;
+            float r = rms[p];
+            VT sn = f;
+            if (r > 0.0f) sn = f / (VT)r;
+            unsigned char e = edgeCheck ? edgeCheck[p] : (unsigned char)1;
+            unsigned char sm = (unsigned char)(e * (surveyMask ? surveyMask[p] : 1) * (psMask ? psMask[p] : 1));
+            f = f * (VT)e;
+            if (mulSurvey) f = f * (VT)sm;
+            // apod(ones, w) == 1 only at distance >= w-1 from every edge
+            bool inside = (ay <= 0 || (y >= ay - 1 && y <= H - ay)) && (ax <= 0 || (x >= ax - 1 && x <= W - ax));
+            unsigned char fm = inside ? sm : (unsigned char)0;
+            sn = sn * (VT)fm;
+            if (sn != sn) sn = (VT)0;
+            // stores of values that are already there are left out (x * 1 is x, bit for bit): with masks that are mostly one the
+            // filtered map - and the noise map, when it is updated in place - cost no write traffic
+            if (f != fIn || f != f) filtered[p] = f;
+            snOut[p] = sn;
+            const float rNew = r * (float)fm;
+            if (rmsOut != rms || rNew != r || rNew != rNew) rmsOut[p] = rNew;
+            maskOut[p] = fm;
+            mx = fmax(mx, (double)sn);
+            mn = fmin(mn, (double)sn);
+        }
+        if (chunkRange != nullptr) {
+            for (int off = 32; off > 0; off >>= 1) {
+                mx = fmax(mx, __shfl_xor(mx, off, 64));
+                mn = fmin(mn, __shfl_xor(mn, off, 64));
+            }
+            if (lane == 0) {
+                chunkRange[c] = nf_ordered_key(mx);
+                chunkRange[nchunks + c] = nf_ordered_key(mn);
+            }
+        }
     }
 }
 
 int finalize(int vtype, void* filtered, const float* rms, const unsigned char* surveyMask, const unsigned char* psMask,
              const unsigned char* edgeCheck, void* snOut, float* rmsOut, unsigned char* maskOut, int H, int W, int apodPix,
-             int mulSurvey, hipStream_t s) {
-    dim3 g(grid_for((long long)H * W, 256)), b(256);
+             int mulSurvey, unsigned long long* chunkRange, hipStream_t s) {
+    if ((long long)H * W >= 2147483647LL) {
+        nf_set_error("finalize: map too large for 32-bit pixel indices");
+        return NF_ERR_SIZE;
+    }
+    const int nchunks = nf_div_up((long long)H * W, NF_SN_CHUNK);
+    dim3 g(grid_for((long long)nchunks * 64, 256)), b(256);        // one wavefront per chunk, as many at a time as the grid holds
     if (vtype == NF_F64)
         hipLaunchKernelGGL(k_finalize<double>, g, b, 0, s, (double*)filtered, rms, surveyMask, psMask, edgeCheck, (double*)snOut,
-                           rmsOut, maskOut, H, W, apodPix, mulSurvey);
+                           rmsOut, maskOut, H, W, apodPix, mulSurvey, chunkRange, nchunks);
     else
         hipLaunchKernelGGL(k_finalize<float>, g, b, 0, s, (float*)filtered, rms, surveyMask, psMask, edgeCheck, (float*)snOut,
-                           rmsOut, maskOut, H, W, apodPix, mulSurvey);
+                           rmsOut, maskOut, H, W, apodPix, mulSurvey, chunkRange, nchunks);
     NF_CHECK_LAUNCH("k_finalize");
     return NF_OK;
 }

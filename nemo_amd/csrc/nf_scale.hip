@@ -183,7 +183,7 @@ int run_scale(nf_plan* plan, const nf_mf_tile& t, const nf_mf_scale& sc, const L
         edge = (unsigned char*)(ws + L.edgeOut);
         NF_TRY(nf_edge_check(outPrec, pre, t.psMask_d, (unsigned char*)(ws + L.edgeTmp), edge, H, W, t.trimSizePix, S));
     }
-    NF_TRY(nf_finalize(outPrec, pre, rms0, t.surveyMask_d, t.psMask_d, edge, sc.sn_d, sc.rms_d, sc.mask_d, H, W, t.apodPix, 1, S));
+    NF_TRY(nf_finalize(outPrec, pre, rms0, t.surveyMask_d, t.psMask_d, edge, sc.sn_d, sc.rms_d, sc.mask_d, H, W, t.apodPix, 1, sc.snChunkRange_d, S));
     // pixel-window undo (:98-101): columns, then rows with the zeros of the input restored at the store
     if (undo) {
         const int ty = yc ? 1 : 2;

@@ -631,9 +631,12 @@ class TileEngine(object):
         sn = t.empty_like(filtered)
         rmsOut = rms                                   # masked in place (the caller's noise map is the one made for this call)
         maskOut = t.empty((self.H, self.W), dtype=t.uint8, device=self.dev)
+        # largest / smallest S/N per 1024-pixel chunk: lets label_and_stats skip the chunks without foreground unread
+        snChunks = t.empty(2 * ((self.npix + 1023) // 1024), dtype=t.int64, device=self.dev)
         check(self.lib.nf_finalize(prec_of(filtered), ptr(filtered), ptr(rms), ptr(surveyMask), ptr(psMask), ptr(edgeCheck),
                                    ptr(sn), ptr(rmsOut), ptr(maskOut), self.H, self.W, self.APOD_PIX, 1 if mulSurvey else 0,
-                                   stream_ptr()), "nf_finalize")
+                                   ptr(snChunks), stream_ptr()), "nf_finalize")
+        self.lastSNChunks = (sn, snChunks)
         return filtered, sn, rmsOut, maskOut
 
     def sn_cached(self, data, rms32):
@@ -826,10 +829,11 @@ class TileEngine(object):
         self._chunkFlags[labels.data_ptr()] = work[off:off + nchunks]        # (keeps `work` alive for object_stats)
         return labels, n.value
 
-    def label_and_stats(self, sn, threshold, negate=False, slot=None, cap=4096):
+    def label_and_stats(self, sn, threshold, negate=False, slot=None, cap=4096, snChunks=None):
         """label() and object_stats() as one enqueue that does not wait for the GPU (nf_label_and_stats): (labels, records)
         with records a float64 device tensor [(cap + 1), 6]; once fetched, records[0, 0] is the number of objects found - if
-        it exceeds ``cap`` the records are incomplete and the call must be repeated with room for that many."""
+        it exceeds ``cap`` the records are incomplete and the call must be repeated with room for that many.  ``snChunks``:
+        the S/N range table nf_finalize made for this very map (chunks that cannot hold foreground are then not read)."""
         t = self.t
         nchunks = (self.npix + 1023) // 1024
         work = t.empty(self.npix + 2 * nchunks + 16, dtype=t.int32, device=self.dev)
@@ -844,7 +848,7 @@ class TileEngine(object):
             labels, dirty = self._keptLabels[key]
         stats = t.empty((cap + 1) * 17, dtype=t.float64, device=self.dev)             # NF_OBJECT_STATS_DOUBLES
         check(self.lib.nf_label_and_stats(prec_of(sn), ptr(sn), float(threshold), 1 if negate else 0, ptr(labels), self.H, self.W,
-                                          ptr(work), ptr(dirty), int(cap), ptr(stats), stream_ptr()), "nf_label_and_stats")
+                                          ptr(work), ptr(dirty), int(cap), ptr(stats), ptr(snChunks), stream_ptr()), "nf_label_and_stats")
         return labels, stats[:(cap + 1) * 6].reshape(cap + 1, 6)
 
     def object_stats(self, sn, labels, numObjects, negate=False):

@@ -421,11 +421,15 @@ class MapFilter(object):
         if trimSizePix > 0:
             edge = eng.edge_check(dFiltered, self._dPSMask, trimSizePix)
         data, sn, rmsOut, mask = eng.finalize(dFiltered, rms, self._dSurveyMask, self._dPSMask, edge, fourierVariant)
+        self._snChunks = eng.lastSNChunks
         return data, sn, rmsOut, mask, trimSizePix > 0
 
     def _packResult(self, data, sn, rms, mask, trimmed, fourierVariant, mapUnits, combinedObsFreqGHz, beamSolidAngle_nsr):
         if RETURN_DEVICE_ARRAYS:
             out = {'data': data, 'SNMap': sn, 'RMSMap': rms, 'surveyMask': mask}
+            hint = getattr(self, '_snChunks', None)
+            if hint is not None and hint[0] is sn:
+                out['_snChunks'] = hint          # (S/N tensor, its per-chunk range table): photometry.findObjects' shortcut
         else:
             # dtypes as the reference produces them under numpy >= 2: the masks become float through
             # edgeCheck (float32 if a rank filter ran in the Fourier variant, else float64)
@@ -593,6 +597,8 @@ class MatchedFilter(MapFilter):
         rms = t.empty((G, H, W), dtype=t.float32, device=eng.dev)
         mask = t.empty((G, H, W), dtype=t.uint8, device=eng.dev)
         scal = t.empty((G, N + 2), dtype=t.float64, device=eng.dev)       # per scale: signalNorm, then the N + 1 weight operands
+        nch = 2 * ((H * W + 1023) // 1024)
+        snChunks = t.empty((G, nch), dtype=t.int64, device=eng.dev)       # per scale: S/N range per 1024-pixel chunk
         scales = (_lib.MfScale * G)()
         es = data.element_size()
         for g, obj in enumerate(objs):
@@ -610,6 +616,7 @@ class MatchedFilter(MapFilter):
             sc.sn_d = sn.data_ptr() + g * H * W * es
             sc.rms_d = rms.data_ptr() + g * H * W * 4
             sc.mask_d = mask.data_ptr() + g * H * W
+            sc.snChunkRange_d = snChunks.data_ptr() + g * nch * 8
         eng.matched_filter_scales(tile, scales, lanes)
         del keep
         _scaleEntryStats['calls'] += 1
@@ -627,7 +634,9 @@ class MatchedFilter(MapFilter):
                     obj.fRelWeights = _DeviceWeights([m['obsFreqGHz'] for m in obj.unfilteredMapsDictList], scal[g, 1:N + 2])
             mapUnits, combinedObsFreqGHz, beamSolidAngle_nsr = obj._unitsInfo()
             obj._saveFilterIfAsked()
-            out.append(obj._packResult(data[g], sn[g], rms[g], mask[g], tile.trimSizePix > 0, True, mapUnits, combinedObsFreqGHz,
+            snG = sn[g]
+            obj._snChunks = (snG, snChunks[g])
+            out.append(obj._packResult(data[g], snG, rms[g], mask[g], tile.trimSizePix > 0, True, mapUnits, combinedObsFreqGHz,
                                        beamSolidAngle_nsr))
         return out, windowDone
 

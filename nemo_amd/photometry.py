@@ -183,9 +183,12 @@ def _findObjectsSteps(filteredMapDict, threshold=3.0, minObjPix=3, rejectBorder=
     tm = time.perf_counter() if _TIMING else 0.0
     # labelling and per-label sums go out as one enqueue (:59); the records and the object count come back together
     slot = ('objects', _slot) if (_slot is not None and measureShapes == True) else 'objects'
+    hint = filteredMapDict.get('_snChunks', None) if hasattr(filteredMapDict, 'get') else None
+    # (the table belongs to one S/N tensor: a map that was replaced since - useCachedRMSMap - has none)
+    snChunks = hint[1] if (hint is not None and hint[0] is filteredMapDict['SNMap'] and hint[0].data_ptr() == dSN.data_ptr()) else None
     while True:
         cap = eng.statsCap
-        labels, recs = eng.label_and_stats(dSN, threshold, negate=invertMap, slot=slot, cap=cap)
+        labels, recs = eng.label_and_stats(dSN, threshold, negate=invertMap, slot=slot, cap=cap, snChunks=snChunks)
         tm = _mark('label+stats enqueue', tm)
         got = yield [('stats', recs)]
         st = got['stats'].reshape(cap + 1, 6)

@@ -540,3 +540,44 @@ def test_apply_window_as_two_axis_filters(shape, dtype, pow, batch):
         z = eng.apply_window(d, pow, zero_ref=d).cpu().numpy()
         assert np.all(z[m[0] == 0] == 0)
         assert np.array_equal(z[m[0] != 0], got.reshape(shape)[m[0] != 0])
+
+
+@pytest.mark.parametrize("vdtype", [np.float64, np.float32])
+def test_label_and_stats_with_sn_chunk_ranges(vdtype):
+    """nf_finalize's per-chunk S/N range table lets nf_label_and_stats skip chunks unread: same labels and records as without
+    it, for both signs of the detection, and the same as the two-call form (label + object_stats)."""
+    shape = (300, 517)
+    eng = _eng(shape)
+    rng = np.random.default_rng(77)
+    f = rng.standard_normal(shape).astype(vdtype) * 1.3
+    f[40:43, 100:104] += 9.0
+    f[200:202, 300:303] -= 8.0
+    rms = np.ones(shape, dtype=np.float32)
+    ones = np.ones(shape, dtype=np.uint8)
+    d, sn, r, mk = eng.finalize(engine.to_dev(f.copy()), engine.to_dev(rms), engine.to_dev(ones), engine.to_dev(ones), None, True)
+    snT, chunks = eng.lastSNChunks
+    assert snT is sn
+    snH = _np(sn)
+    # the table holds the chunk extrema of the S/N map that was written
+    flat = np.concatenate([snH.reshape(-1), np.full((-snH.size) % 1024, np.nan)]).reshape(-1, 1024)
+    keys = _np(chunks).view(np.uint64)
+    nch = flat.shape[0]
+
+    def unkey(k):
+        b = np.where(k & np.uint64(1 << 63), k & np.uint64((1 << 63) - 1), ~k)
+        return b.view(np.float64)
+    assert np.array_equal(unkey(keys[:nch]), np.nanmax(flat, axis=1).astype(np.float64))
+    assert np.array_equal(unkey(keys[nch:]), np.nanmin(flat, axis=1).astype(np.float64))
+    for negate in (False, True):
+        for thr in (4.0, 2.5):
+            labA, recA = eng.label_and_stats(sn, thr, negate=negate, cap=20000)
+            labB, recB = eng.label_and_stats(sn, thr, negate=negate, cap=20000, snChunks=chunks)
+            a, b = _np(recA), _np(recB)
+            n = int(a[0, 0])
+            assert n > 0 and n == int(b[0, 0])
+            assert np.array_equal(a[1:n + 1], b[1:n + 1])      # (record 0 is the background: count slot = n, the rest unused)
+            assert np.array_equal(_np(labA), _np(labB))
+            labC, nC = eng.label(sn, thr, negate=negate)
+            stC = _np(eng.object_stats(sn, labC, nC, negate=negate))
+            assert nC == n and np.array_equal(_np(labC), _np(labA))
+            assert np.array_equal(stC[1:], a[1:n + 1])

@@ -50,11 +50,12 @@ int nf_plan_destroy(nf_plan* plan);
  * over the map (two real lines share one complex transform; the spectrum stays in LDS).  wperm_d: n doubles with
  * wperm[rev[k]] = w[k] / n, rev from nf_plan_digit_reversal (n = W for axis 0, H for axis 1); w must be real and even
  * (w[k] == w[n-k]).  zeroRef_d (optional, a map of the output type): where it is zero the output is zero
- * (nemo/filters.py:99-101).  in_d == out_d is allowed.  Lengths with a prime factor above 13 are refused (NF_ERR_SIZE,
+ * (nemo/filters.py:99-101); zeroRows_d (optional, with zeroRef_d, axis 0, batch 1): H ints, 0 = that row of zeroRef_d holds
+ * no zero - such rows are not looked up (nf_finalize makes the table).  in_d == out_d is allowed.  Lengths with a prime factor above 13 are refused (NF_ERR_SIZE,
  * *bluestein = 1 from nf_plan_digit_reversal): use the 2-D transforms there. */
 int nf_plan_digit_reversal(nf_plan* plan, int prec, int axis, unsigned short* rev_host, int* bluestein);
 int nf_axis_filter(nf_plan* plan, int prec, int axis, const void* in_d, int inType, void* out_d, int outType, int batch,
-                   const double* wperm_d, const void* zeroRef_d, void* stream);
+                   const double* wperm_d, const void* zeroRef_d, const int* zeroRows_d, void* stream);
 
 /* enmap.fft (pixell), as used at nemo/filters.py:525,548,559,615,646,679,845: full complex 2-D DFT of
  * `batch` maps.  Input may be real (promoted) or complex.  If apodY_d/apodX_d are non-NULL the real input is
@@ -202,12 +203,14 @@ int nf_edge_check(int vtype, const void* filtered_d, const unsigned char* psMask
 int nf_finalize(int vtype, void* filtered_d, const float* rms_d, const unsigned char* surveyMask_d,
                 const unsigned char* psMask_d, const unsigned char* edgeCheck_d, void* sn_d, float* rmsOut_d,
                 unsigned char* maskOut_d, int H, int W, int apodPix, int mulSurvey, unsigned long long* snChunkRange_d,
-                void* stream);
+                int* zeroRows_d, void* stream);
 /* snChunkRange_d (optional, NULL = not wanted): 2 * nf_sn_chunks(H, W) 64-bit words - for every chunk of 1024 consecutive
  * pixels (raster order) the largest S/N value written to sn_d, then, in the second half, the smallest (as order-preserving
  * integer keys).  Handed to nf_label_and_stats with the same sn_d, it lets the labelling pass skip, unread, every chunk whose
  * values cannot exceed the detection threshold - at 4 sigma nearly all of them (no counterpart in the reference: ndimage.label
- * reads the whole map). */
+ * reads the whole map).
+ * zeroRows_d (optional): H ints, set to 1 for the rows of the updated filtered_d that hold a zero, else 0 - the table
+ * nf_axis_filter takes beside its zero reference. */
 int nf_sn_chunks(int H, int W);
 
 /* nemo/pipelines.py:244-247 (useCachedRMSMap branch of the driver): sn_d (float64) = data, divided by the cached RMS map

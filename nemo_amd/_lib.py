@@ -91,7 +91,7 @@ SIGNATURES = {
     'nf_median_stack': (c_int, [c_int, c_void_p, c_void_p, c_int, c_ll, c_void_p]),
     'nf_edge_check': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'nf_finalize': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
-                            c_int, c_int, c_int, c_void_p, c_void_p]),
+                            c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'nf_sn_chunks': (c_int, [c_int, c_int]),
     'nf_sn_cached': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_ll, c_void_p]),
     'nf_restore_zeros': (c_int, [c_int, c_void_p, c_void_p, c_ll, c_void_p]),
@@ -129,7 +129,7 @@ SIGNATURES = {
     'nf_profile_tag_name': (ctypes.c_char_p, [c_int]),
     'nf_profile_read': (c_int, [c_int, ctypes.POINTER(c_ll), ctypes.POINTER(c_double), ctypes.POINTER(c_double)]),
     'nf_plan_digit_reversal': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
-    'nf_axis_filter': (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    'nf_axis_filter': (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     'nf_spline_eval_batch': (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                      c_void_p]),
     'nf_spline_eval': (c_int, [c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),

@@ -198,7 +198,7 @@ int nf_plan_digit_reversal(nf_plan* p, int prec, int axis, unsigned short* rev, 
 }
 
 int nf_axis_filter(nf_plan* p, int prec, int axis, const void* in, int inType, void* out, int outType, int batch,
-                   const double* wperm, const void* zeroRef, void* stream) {
+                   const double* wperm, const void* zeroRef, const int* zeroRows, void* stream) {
     if (!p || !in || !out || !wperm || batch < 1 || (axis != 0 && axis != 1) || (inType != NF_IN_REAL64 && inType != NF_IN_REAL32) ||
         (outType != NF_IN_REAL64 && outType != NF_IN_REAL32)) {
         nf_set_error("nf_axis_filter: bad arguments (real maps in and out)");
@@ -206,8 +206,8 @@ int nf_axis_filter(nf_plan* p, int prec, int axis, const void* in, int inType, v
     }
     int rc = ensure_prec(p, prec);
     if (rc) return rc;
-    if (prec == NF_F32) return p->pf.axis_filter(axis, in, inType, out, outType, batch, wperm, zeroRef, S(stream));
-    return p->pd.axis_filter(axis, in, inType, out, outType, batch, wperm, zeroRef, S(stream));
+    if (prec == NF_F32) return p->pf.axis_filter(axis, in, inType, out, outType, batch, wperm, zeroRef, S(stream), zeroRows);
+    return p->pd.axis_filter(axis, in, inType, out, outType, batch, wperm, zeroRef, S(stream), zeroRows);
 }
 
 int nf_fft2_forward(nf_plan* p, int prec, const void* in, int inType, void* out, int batch, const double* apodY,
@@ -520,7 +520,7 @@ int nf_edge_check(int vtype, const void* filtered, const unsigned char* psMask, 
 
 int nf_finalize(int vtype, void* filtered, const float* rms, const unsigned char* surveyMask, const unsigned char* psMask,
                 const unsigned char* edgeCheck, void* sn, float* rmsOut, unsigned char* maskOut, int H, int W, int apodPix,
-                int mulSurvey, unsigned long long* snChunkRange, void* stream) {
+                int mulSurvey, unsigned long long* snChunkRange, int* zeroRows, void* stream) {
     if (!filtered || !rms || !sn || !rmsOut || !maskOut || H < 1 || W < 1) {
         nf_set_error("nf_finalize: bad arguments");
         return NF_ERR_ARG;
@@ -528,7 +528,7 @@ int nf_finalize(int vtype, void* filtered, const float* rms, const unsigned char
     // map + noise map + three masks in; S/N map + mask out (the filtered map and the noise map are stored only where they change)
     nf::ProfScope ps(nf::PT_FINALIZE, S(stream), (double)H * W * (2 * (vtype == NF_F32 ? 4.0 : 8.0) + 4.0 + 3.0 + 1.0));
     return nf::finalize(vtype, filtered, rms, surveyMask, psMask, edgeCheck, sn, rmsOut, maskOut, H, W, apodPix, mulSurvey,
-                        snChunkRange, S(stream));
+                        snChunkRange, zeroRows, S(stream));
 }
 
 int nf_sn_chunks(int H, int W) { return (H < 1 || W < 1) ? 0 : nf_div_up((long long)H * W, NF_SN_CHUNK); }

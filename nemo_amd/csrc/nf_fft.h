@@ -73,6 +73,7 @@ struct LineArgs {
     const double* epiScale;          // device scalar: out = (float)value * scale (* epiMask), formed in the output type
     const unsigned char* epiMask;    //   mask multiplied in after the scale
     const void* epiZeroRef;          // map of the output type: where it is zero the output is zero
+    const int* epiZeroRows;          // line filter, rows: per map row, 0 = that row of epiZeroRef holds no zero (it is not read)
     const double* apodLine;  // optional per-line apodisation factors (length nLines); rows kernel, real input only
     const double* apodElem;  // optional per-element apodisation factors (length n)
 };
@@ -87,7 +88,7 @@ struct Plan2D {
     std::vector<unsigned short> revRow, revCol;   // host copies of row.rev / col.rev (digit-reversed position of index k)
     bool packOk() const;
     int axis_filter(int axis, const void* in, int inType, void* out, int outType, int batch, const double* wperm,
-                    const void* zeroRef, hipStream_t stream);
+                    const void* zeroRef, hipStream_t stream, const int* zeroRows = nullptr);
     int init(int H, int W);
     void destroy();
     int forward(const void* in, int inType, void* out, int batch, const double* apodY, const double* apodX,

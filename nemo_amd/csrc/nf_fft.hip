@@ -974,14 +974,14 @@ __device__ __forceinline__ T lf_load(const void* p, int type, size_t off) {
 }
 
 template <typename T>
-__device__ __forceinline__ void lf_store(const nf::LineArgs<T>& a, void* outP, size_t off, T v) {
+__device__ __forceinline__ void lf_store(const nf::LineArgs<T>& a, void* outP, size_t off, T v, bool useRef) {
     if (a.outType == 1) {
         double w = (double)v;
-        if (a.epiZeroRef != nullptr && ((const double*)a.epiZeroRef)[off] == 0.0) w = 0.0;
+        if (useRef && ((const double*)a.epiZeroRef)[off] == 0.0) w = 0.0;
         ((double*)outP)[off] = w;
     } else {
         float w = (float)v;
-        if (a.epiZeroRef != nullptr && ((const float*)a.epiZeroRef)[off] == 0.0f) w = 0.0f;
+        if (useRef && ((const float*)a.epiZeroRef)[off] == 0.0f) w = 0.0f;
         ((float*)outP)[off] = w;
     }
 }
@@ -1083,10 +1083,11 @@ __global__ void __launch_bounds__(COLS ? NF_FFT_MAXTHREADS : 512) k_line_filter(
         if (G.nl > 0) {
             const size_t c0 = 2u * (size_t)(G.line0 + G.tl);
             const bool haveB = c0 + 1 < W;
+            const bool useRef = a.epiZeroRef != nullptr;
             for (int e = G.tb; e < n; e += G.TB) {
                 const cpx<T> v = buf[(unsigned)swz(e) * (unsigned)G.TL + (unsigned)G.tl];
-                lf_store<T>(a, G.outP, (size_t)e * W + c0, v.x);
-                if (haveB) lf_store<T>(a, G.outP, (size_t)e * W + c0 + 1, -v.y);
+                lf_store<T>(a, G.outP, (size_t)e * W + c0, v.x, useRef);
+                if (haveB) lf_store<T>(a, G.outP, (size_t)e * W + c0 + 1, -v.y, useRef);
             }
         }
     } else {
@@ -1094,10 +1095,13 @@ __global__ void __launch_bounds__(COLS ? NF_FFT_MAXTHREADS : 512) k_line_filter(
             const size_t rowA = 2u * (size_t)(G.line0 + line);
             const bool haveB = rowA + 1 < (size_t)a.realH;
             const cpx<T>* __restrict__ lb = buf + line * p.mPad;
+            // (a row the caller knows to hold no zero is not looked up in the zero reference)
+            const bool refA = a.epiZeroRef != nullptr && (a.epiZeroRows == nullptr || a.epiZeroRows[rowA] != 0);
+            const bool refB = haveB && a.epiZeroRef != nullptr && (a.epiZeroRows == nullptr || a.epiZeroRows[rowA + 1] != 0);
             for (int e = G.tb; e < n; e += G.TB) {
                 const cpx<T> v = lb[swz(e)];
-                lf_store<T>(a, G.outP, rowA * W + (size_t)e, v.x);
-                if (haveB) lf_store<T>(a, G.outP, (rowA + 1) * W + (size_t)e, -v.y);
+                lf_store<T>(a, G.outP, rowA * W + (size_t)e, v.x, refA);
+                if (haveB) lf_store<T>(a, G.outP, (rowA + 1) * W + (size_t)e, -v.y, refB);
             }
         }
     }
@@ -1642,7 +1646,7 @@ int Plan2D<T>::inverse_half(const void* in, void* work, void* out, int outType, 
 // before it is written; a rows workgroup would overwrite rows other workgroups still read... no: rows are disjoint too).
 template <typename T>
 int Plan2D<T>::axis_filter(int axis, const void* in, int inType, void* out, int outType, int batch, const double* wperm,
-                           const void* zeroRef, hipStream_t stream) {
+                           const void* zeroRef, hipStream_t stream, const int* zeroRows) {
     const LinePlan<T>& lp = axis == 0 ? row : col;
     if (lp.bluestein) {
         nf_set_error("axis_filter: this length needs Bluestein's algorithm - use the 2-D transforms");
@@ -1659,6 +1663,7 @@ int Plan2D<T>::axis_filter(int axis, const void* in, int inType, void* out, int 
     a.realW = W;
     a.winElem = wperm;
     a.epiZeroRef = zeroRef;
+    a.epiZeroRows = (axis == 0 && batch == 1 && zeroRef != nullptr) ? zeroRows : nullptr;
     a.conjInSign = a.conjOutSign = a.scale = 1.0;
     int mode = 0;
     for (int s = 0; s < lp.nst; ++s)
@@ -1674,7 +1679,7 @@ int Plan2D<T>::axis_filter(int axis, const void* in, int inType, void* out, int 
 #undef NF_ATTR
         attrSet[which] = true;
     }
-    const double bytes = (double)H * W * batch * ((inType == 1 ? 8.0 : 4.0) + (outType == 1 ? 8.0 : 4.0) * (zeroRef ? 2.0 : 1.0));
+    const double bytes = (double)H * W * batch * ((inType == 1 ? 8.0 : 4.0) + (outType == 1 ? 8.0 : 4.0) * ((zeroRef && !a.epiZeroRows) ? 2.0 : 1.0));
     if (axis == 0) {
         a.nLines = (H + 1) / 2;
         a.linesPerWG = rowsPerWG;

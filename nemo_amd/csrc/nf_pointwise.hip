@@ -434,7 +434,7 @@ template <typename VT>
 __global__ void __launch_bounds__(256) k_finalize(VT* __restrict__ filtered, const float* rms, const unsigned char* __restrict__ surveyMask,
                            const unsigned char* __restrict__ psMask, const unsigned char* __restrict__ edgeCheck, VT* __restrict__ snOut,
                            float* rmsOut, unsigned char* __restrict__ maskOut, int H, int W, int apodPix,
-                           int mulSurvey, unsigned long long* __restrict__ chunkRange, int nchunks) {
+                           int mulSurvey, unsigned long long* __restrict__ chunkRange, int nchunks, int* __restrict__ zeroRows) {
     const long long n = (long long)H * W;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wavesPerWG = blockDim.x >> 6;
     // a wavefront takes one 1024-pixel chunk after another, 64 consecutive pixels at a time: the chunk's largest and smallest
@@ -473,6 +473,7 @@ __global__ void __launch_bounds__(256) k_finalize(VT* __restrict__ filtered, con
             // stores of values that are already there are left out (x * 1 is x, bit for bit): with masks that are mostly one the
             // filtered map - and the noise map, when it is updated in place - cost no write traffic
             if (f != fIn || f != f) filtered[p] = f;
+            if (zeroRows != nullptr && f == (VT)0) zeroRows[y] = 1;     // (rows of the filtered map that hold a zero)
             snOut[p] = sn;
             const float rNew = r * (float)fm;
             if (rmsOut != rms || rNew != r || rNew != rNew) rmsOut[p] = rNew;
@@ -495,19 +496,20 @@ __global__ void __launch_bounds__(256) k_finalize(VT* __restrict__ filtered, con
 
 int finalize(int vtype, void* filtered, const float* rms, const unsigned char* surveyMask, const unsigned char* psMask,
              const unsigned char* edgeCheck, void* snOut, float* rmsOut, unsigned char* maskOut, int H, int W, int apodPix,
-             int mulSurvey, unsigned long long* chunkRange, hipStream_t s) {
+             int mulSurvey, unsigned long long* chunkRange, int* zeroRows, hipStream_t s) {
     if ((long long)H * W >= 2147483647LL) {
         nf_set_error("finalize: map too large for 32-bit pixel indices");
         return NF_ERR_SIZE;
     }
     const int nchunks = nf_div_up((long long)H * W, NF_SN_CHUNK);
+    if (zeroRows != nullptr) NF_HIP(hipMemsetAsync(zeroRows, 0, (size_t)H * sizeof(int), s));
     dim3 g(grid_for((long long)nchunks * 64, 256)), b(256);        // one wavefront per chunk, as many at a time as the grid holds
     if (vtype == NF_F64)
         hipLaunchKernelGGL(k_finalize<double>, g, b, 0, s, (double*)filtered, rms, surveyMask, psMask, edgeCheck, (double*)snOut,
-                           rmsOut, maskOut, H, W, apodPix, mulSurvey, chunkRange, nchunks);
+                           rmsOut, maskOut, H, W, apodPix, mulSurvey, chunkRange, nchunks, zeroRows);
     else
         hipLaunchKernelGGL(k_finalize<float>, g, b, 0, s, (float*)filtered, rms, surveyMask, psMask, edgeCheck, (float*)snOut,
-                           rmsOut, maskOut, H, W, apodPix, mulSurvey, chunkRange, nchunks);
+                           rmsOut, maskOut, H, W, apodPix, mulSurvey, chunkRange, nchunks, zeroRows);
     NF_CHECK_LAUNCH("k_finalize");
     return NF_OK;
 }

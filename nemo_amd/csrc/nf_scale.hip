@@ -37,7 +37,7 @@ __global__ void k_rel_weights(const float* __restrict__ planes, const double* __
 
 // ---- workspace layout -------------------------------------------------------------------------------------------
 struct Layout {
-    size_t T, F, filtSym, work, sig, planes, pre, noise, noiseBytes, edgeTmp, edgeOut, mapMax, peak, total;
+    size_t T, F, filtSym, work, sig, planes, pre, zeroRows, noise, noiseBytes, edgeTmp, edgeOut, mapMax, peak, total;
 };
 
 Layout layout_of(const nf_mf_tile& t) {
@@ -62,6 +62,7 @@ Layout layout_of(const nf_mf_tile& t) {
     L.sig = take(npix * 4);                          // filtered template
     L.planes = take(yc && N > 1 ? N * npix * 4 : 0);
     L.pre = take(npix * outB);                       // filtered map before the pixel-window undo
+    L.zeroRows = take((size_t)t.H * 4);               // rows of the filtered map that hold a zero (for the window undo)
     L.noiseBytes = nf_noise_workspace_bytes(t.H, t.W, t.ny, t.nx, t.numBins);
     L.noise = take(L.noiseBytes);
     L.edgeTmp = take(t.trimSizePix > 0 ? npix : 0);
@@ -136,6 +137,7 @@ int run_scale(nf_plan* plan, const nf_mf_tile& t, const nf_mf_scale& sc, const L
     const bool undo = t.axisWinY_d != nullptr;
     void* pre = undo ? (void*)(ws + L.pre) : sc.data_d;
     float* rms0 = sc.rms_d;                                // the noise map is made in its output buffer, masked there in place
+    int* zeroRows = (int*)(ws + L.zeroRows);
     double* mapMax = (double*)(ws + L.mapMax);
     double* peak = (double*)(ws + L.peak);
     void* S = (void*)st;
@@ -183,12 +185,13 @@ int run_scale(nf_plan* plan, const nf_mf_tile& t, const nf_mf_scale& sc, const L
         edge = (unsigned char*)(ws + L.edgeOut);
         NF_TRY(nf_edge_check(outPrec, pre, t.psMask_d, (unsigned char*)(ws + L.edgeTmp), edge, H, W, t.trimSizePix, S));
     }
-    NF_TRY(nf_finalize(outPrec, pre, rms0, t.surveyMask_d, t.psMask_d, edge, sc.sn_d, sc.rms_d, sc.mask_d, H, W, t.apodPix, 1, sc.snChunkRange_d, S));
+    NF_TRY(nf_finalize(outPrec, pre, rms0, t.surveyMask_d, t.psMask_d, edge, sc.sn_d, sc.rms_d, sc.mask_d, H, W, t.apodPix, 1, sc.snChunkRange_d,
+                       undo ? zeroRows : nullptr, S));
     // pixel-window undo (:98-101): columns, then rows with the zeros of the input restored at the store
     if (undo) {
         const int ty = yc ? 1 : 2;
-        NF_TRY(nf_axis_filter(plan, outPrec, 1, pre, ty, sc.data_d, ty, 1, t.axisWinY_d, nullptr, S));
-        NF_TRY(nf_axis_filter(plan, outPrec, 0, sc.data_d, ty, sc.data_d, ty, 1, t.axisWinX_d, pre, S));
+        NF_TRY(nf_axis_filter(plan, outPrec, 1, pre, ty, sc.data_d, ty, 1, t.axisWinY_d, nullptr, nullptr, S));
+        NF_TRY(nf_axis_filter(plan, outPrec, 0, sc.data_d, ty, sc.data_d, ty, 1, t.axisWinX_d, pre, zeroRows, S));
     }
     return NF_OK;
 }

@@ -447,10 +447,10 @@ class TileEngine(object):
         ty = 1 if m.dtype == t.float64 else 2
         # columns first: the rows pass (two workgroups per CU, contiguous runs) is the one that can afford the extra read of
         # the zero reference
-        check(self.lib.nf_axis_filter(self.plan, prec, 1, ptr(m3), ty, ptr(out), ty, m3.shape[0], ptr(tabs[1]), None, stream_ptr()),
+        check(self.lib.nf_axis_filter(self.plan, prec, 1, ptr(m3), ty, ptr(out), ty, m3.shape[0], ptr(tabs[1]), None, None, stream_ptr()),
               "nf_axis_filter")
         check(self.lib.nf_axis_filter(self.plan, prec, 0, ptr(out), ty, ptr(out), ty, m3.shape[0], ptr(tabs[0]), ptr(zero_ref),
-                                      stream_ptr()), "nf_axis_filter")
+                                      None, stream_ptr()), "nf_axis_filter")
         return out.reshape(m.shape)
 
     # ---- templates -----------------------------------------------------------------------------------------
@@ -635,7 +635,7 @@ class TileEngine(object):
         snChunks = t.empty(2 * ((self.npix + 1023) // 1024), dtype=t.int64, device=self.dev)
         check(self.lib.nf_finalize(prec_of(filtered), ptr(filtered), ptr(rms), ptr(surveyMask), ptr(psMask), ptr(edgeCheck),
                                    ptr(sn), ptr(rmsOut), ptr(maskOut), self.H, self.W, self.APOD_PIX, 1 if mulSurvey else 0,
-                                   ptr(snChunks), stream_ptr()), "nf_finalize")
+                                   ptr(snChunks), None, stream_ptr()), "nf_finalize")
         self.lastSNChunks = (sn, snChunks)
         return filtered, sn, rmsOut, maskOut
 

@@ -123,6 +123,10 @@ int nf_fft2_inverse_half_epi(nf_plan* plan, int prec, const void* in_d, const do
 int nf_cross_power_half(int prec, const void* F_d, void* NP_d, int N, int H, int W, void* stream);
 int nf_build_filter_half(int covType, int sigType, const void* cov_d, const void* S_d, const double* w, float* filt_d,
                          int N, int H, int W, void* stream);
+/* nf_build_filter_half and nf_symmetrise_filter in one pass: the same filter cube filt_d and the same symmetrised form
+ * filtSym_d, bit for bit, without reading the cube back (a thread computes a mode and its mirror mode together). */
+int nf_build_filter_sym_half(int covType, int sigType, const void* cov_d, const void* S_d, const double* w, float* filt_d,
+                             double* filtSym_d, int N, int H, int W, void* stream);
 
 /* scipy.ndimage.gaussian_filter with mode='reflect' (nemo/filters.py:580 with sigma (3,3); nemo/maps.py:1380).
  * wY_d / wX_d: normalised 1-D kernels of length 2*rad+1 (device, float64) for axis 0 / axis 1, as

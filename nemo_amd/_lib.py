@@ -72,6 +72,8 @@ SIGNATURES = {
     'nf_cross_power_half': (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'nf_build_filter_half': (c_int, [c_int, c_int, c_void_p, c_void_p, ctypes.POINTER(c_double), c_void_p, c_int, c_int, c_int,
                                      c_void_p]),
+    'nf_build_filter_sym_half': (c_int, [c_int, c_int, c_void_p, c_void_p, ctypes.POINTER(c_double), c_void_p, c_void_p, c_int, c_int,
+                                         c_int, c_void_p]),
     'nf_gaussian_filter': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p,
                                    c_int, c_void_p]),
     'nf_build_filter': (c_int, [c_int, c_int, c_void_p, c_void_p, ctypes.POINTER(c_double), c_void_p, c_int, c_ll, c_void_p]),

@@ -382,6 +382,22 @@ int nf_build_filter_half(int covType, int sigType, const void* cov, const void* 
     return nf::build_filter(covType, sigType, cov, Sg, wv, filt, N, npix, S(stream), H, W);
 }
 
+int nf_build_filter_sym_half(int covType, int sigType, const void* cov, const void* Sg, const double* w, float* filt, double* filtSym,
+                             int N, int H, int W, void* stream) {
+    if (!cov || !Sg || !w || !filt || !filtSym || N < 1 || N > 6 || H < 1 || W < 1) {
+        nf_set_error("nf_build_filter_sym_half: bad arguments (1 <= N <= 6)");
+        return NF_ERR_ARG;
+    }
+    const long long npix = (long long)H * W;
+    nf::WeightVec wv;
+    memset(&wv, 0, sizeof(wv));
+    for (int i = 0; i < N; ++i) wv.v[i] = w[i];
+    nf::ProfScope ps(nf::PT_BUILD_FILTER, S(stream),
+                     (double)npix * ((double)N * N * (covType == NF_F32 ? 4.0 : 8.0) + N * (sigType == NF_F32 ? 4.0 : 8.0) + N * 4.0 +
+                                     N * 4.0));
+    return nf::build_filter_sym(covType, sigType, cov, Sg, wv, filt, filtSym, N, H, W, S(stream));
+}
+
 int nf_apply_filter(int prec, const void* F, const float* filt, void* G, int N, int sum, long long npix, void* stream) {
     if (!F || !filt || !G || N < 1 || npix < 1) {
         nf_set_error("nf_apply_filter: bad arguments");

@@ -20,6 +20,8 @@ int xmatch_self_static(const double* u, const double* snr, int n, double lo2, do
 int symmetrise_filter(const float* filt, double* filtSym, int N, int H, int W, hipStream_t s);
 int build_filter(int covType, int sigType, const void* cov, const void* S, const WeightVec& w, float* filt, int N,
                  long long npix, hipStream_t s, int halfH = 0, int halfW = 0);
+int build_filter_sym(int covType, int sigType, const void* cov, const void* S, const WeightVec& w, float* filt, double* sym, int N,
+                     int H, int W, hipStream_t s);
 template <typename T>
 int apply_filter(const void* F, const float* filt, void* G, int N, int sum, long long npix, hipStream_t s);
 template <typename T>

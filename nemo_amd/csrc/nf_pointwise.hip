@@ -88,97 +88,137 @@ template int cross_power<double>(const void*, void*, int, long long, hipStream_t
 // N x N inverse by LU with partial pivoting in the covariance precision T (np.linalg.inv -> LAPACK gesv),
 // then a float64 matrix-vector product with w*|S| (numpy promotes the f32 inverse to f64 in np.dot),
 // stored as float32.  A singular pivot leaves the mode at zero, like the reference's try/except.
+// one Fourier mode p of the filter: out[i] = (inv(cov[:, :, p]) . (w |S[:, ps]|))_i as float32 (ps: where the mode's spectrum
+// value is stored)
+template <typename T, typename TS, int N>
+__device__ __forceinline__ void build_mode(const T* __restrict__ cov, const cpx<TS>* __restrict__ S, const nf::WeightVec& w,
+                                           long long npix, long long p, long long ps, float* out) {
+    double rhs[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        cpx<TS> s = S[(long long)i * npix + ps];
+        // np.abs(complex) = hypot; computed in the template precision TS, then promoted
+        TS mag = (sizeof(TS) == 4) ? (TS)hypotf((float)s.x, (float)s.y) : (TS)hypot((double)s.x, (double)s.y);
+        rhs[i] = w.v[i] * (double)mag;
+    }
+    if (N == 1) {
+        T a = cov[p];
+        if (a == (T)0) {
+            out[0] = 0.0f;
+        } else {
+            T inv = (T)1 / a;
+            out[0] = (float)((double)inv * rhs[0]);
+        }
+    } else {
+        T A[N][N], B[N][N];
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                A[i][j] = cov[((long long)i * N + j) * npix + p];
+                B[i][j] = (i == j) ? (T)1 : (T)0;
+            }
+        bool singular = false;
+#pragma unroll
+        for (int c = 0; c < N; ++c) {
+            int piv = c;
+            T best = fabs(A[c][c]);
+#pragma unroll
+            for (int r = c + 1; r < N; ++r) {
+                T v = fabs(A[r][c]);
+                if (v > best) {
+                    best = v;
+                    piv = r;
+                }
+            }
+            if (best == (T)0) singular = true;
+#pragma unroll
+            for (int r = c + 1; r < N; ++r) {
+                if (r == piv) {
+#pragma unroll
+                    for (int j = 0; j < N; ++j) {
+                        T t = A[c][j];
+                        A[c][j] = A[r][j];
+                        A[r][j] = t;
+                        t = B[c][j];
+                        B[c][j] = B[r][j];
+                        B[r][j] = t;
+                    }
+                }
+            }
+            T rp = (T)1 / A[c][c];
+#pragma unroll
+            for (int r = c + 1; r < N; ++r) {
+                T f = A[r][c] * rp;
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    if (j > c) A[r][j] -= f * A[c][j];
+                    B[r][j] -= f * B[c][j];
+                }
+            }
+        }
+        // back substitution: X = U^-1 (L^-1 P I)
+#pragma unroll
+        for (int c = N - 1; c >= 0; --c) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                T v = B[c][j];
+#pragma unroll
+                for (int k = c + 1; k < N; ++k) v -= A[c][k] * B[k][j];
+                B[c][j] = v / A[c][c];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            double acc = 0.0;
+#pragma unroll
+            for (int j = 0; j < N; ++j) acc += (double)B[i][j] * rhs[j];
+            out[i] = singular ? 0.0f : (float)acc;
+        }
+    }
+}
+
 template <typename T, typename TS, int N, bool HALF>
 __global__ void k_build_filter(const T* __restrict__ cov, const cpx<TS>* __restrict__ S, nf::WeightVec w,
                                float* __restrict__ filt, long long npix, int H, int W) {
     for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < npix; p += (long long)gridDim.x * blockDim.x) {
-        double rhs[N];
-        const long long ps = HALF ? half_src(p, H, W) : p;
-#pragma unroll
-        for (int i = 0; i < N; ++i) {
-            cpx<TS> s = S[(long long)i * npix + ps];
-            // np.abs(complex) = hypot; computed in the template precision TS, then promoted
-            TS mag = (sizeof(TS) == 4) ? (TS)hypotf((float)s.x, (float)s.y) : (TS)hypot((double)s.x, (double)s.y);
-            rhs[i] = w.v[i] * (double)mag;
-        }
         float out[N];
-        if (N == 1) {
-            T a = cov[p];
-            if (a == (T)0) {
-                out[0] = 0.0f;
+        build_mode<T, TS, N>(cov, S, w, npix, p, HALF ? half_src(p, H, W) : p, out);
+#pragma unroll
+        for (int i = 0; i < N; ++i) filt[(long long)i * npix + p] = out[i];
+    }
+}
+
+// The filter and its symmetrised form in one pass (half-stored spectra): a thread owns the mode (y, x <= W/2) and its mirror
+// (-y, -x), computes both filter values exactly as k_build_filter does, stores them, and stores 0.5 (a + b) as
+// k_symmetrise_filter would - the filter cube is not read back.  In the self-mirrored columns (x = 0, and x = W/2 for even W)
+// the mirror mode belongs to another thread of the same column: its value is computed here too, but stored there.
+template <typename T, typename TS, int N>
+__global__ void k_build_filter_sym(const T* __restrict__ cov, const cpx<TS>* __restrict__ S, nf::WeightVec w,
+                                   float* __restrict__ filt, double* __restrict__ sym, int H, int W) {
+    const int hw = W / 2 + 1;
+    const long long npix = (long long)H * W;
+    for (int y = blockIdx.y; y < H; y += gridDim.y) {
+        const int ym = y == 0 ? 0 : H - y;
+        for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < hw; x += gridDim.x * blockDim.x) {
+            const int xm = x == 0 ? 0 : W - x;
+            const long long p = (long long)y * W + x, pm = (long long)ym * W + xm;
+            float o1[N], o2[N];
+            build_mode<T, TS, N>(cov, S, w, npix, p, p, o1);
+            const bool selfColumn = xm == x;                  // the mirror lies in this column (stored as it is)
+            if (pm == p) {
+#pragma unroll
+                for (int i = 0; i < N; ++i) o2[i] = o1[i];
             } else {
-                T inv = (T)1 / a;
-                out[0] = (float)((double)inv * rhs[0]);
-            }
-        } else {
-            T A[N][N], B[N][N];
-#pragma unroll
-            for (int i = 0; i < N; ++i)
-#pragma unroll
-                for (int j = 0; j < N; ++j) {
-                    A[i][j] = cov[((long long)i * N + j) * npix + p];
-                    B[i][j] = (i == j) ? (T)1 : (T)0;
-                }
-            bool singular = false;
-#pragma unroll
-            for (int c = 0; c < N; ++c) {
-                int piv = c;
-                T best = fabs(A[c][c]);
-#pragma unroll
-                for (int r = c + 1; r < N; ++r) {
-                    T v = fabs(A[r][c]);
-                    if (v > best) {
-                        best = v;
-                        piv = r;
-                    }
-                }
-                if (best == (T)0) singular = true;
-#pragma unroll
-                for (int r = c + 1; r < N; ++r) {
-                    if (r == piv) {
-#pragma unroll
-                        for (int j = 0; j < N; ++j) {
-                            T t = A[c][j];
-                            A[c][j] = A[r][j];
-                            A[r][j] = t;
-                            t = B[c][j];
-                            B[c][j] = B[r][j];
-                            B[r][j] = t;
-                        }
-                    }
-                }
-                T rp = (T)1 / A[c][c];
-#pragma unroll
-                for (int r = c + 1; r < N; ++r) {
-                    T f = A[r][c] * rp;
-#pragma unroll
-                    for (int j = 0; j < N; ++j) {
-                        if (j > c) A[r][j] -= f * A[c][j];
-                        B[r][j] -= f * B[c][j];
-                    }
-                }
-            }
-            // back substitution: X = U^-1 (L^-1 P I)
-#pragma unroll
-            for (int c = N - 1; c >= 0; --c) {
-#pragma unroll
-                for (int j = 0; j < N; ++j) {
-                    T v = B[c][j];
-#pragma unroll
-                    for (int k = c + 1; k < N; ++k) v -= A[c][k] * B[k][j];
-                    B[c][j] = v / A[c][c];
-                }
+                build_mode<T, TS, N>(cov, S, w, npix, pm, selfColumn ? pm : p, o2);
             }
 #pragma unroll
             for (int i = 0; i < N; ++i) {
-                double acc = 0.0;
-#pragma unroll
-                for (int j = 0; j < N; ++j) acc += (double)B[i][j] * rhs[j];
-                out[i] = singular ? 0.0f : (float)acc;
+                filt[(long long)i * npix + p] = o1[i];
+                if (!selfColumn) filt[(long long)i * npix + pm] = o2[i];
+                sym[(long long)i * npix + p] = 0.5 * ((double)o1[i] + (double)o2[i]);
             }
         }
-#pragma unroll
-        for (int i = 0; i < N; ++i) filt[(long long)i * npix + p] = out[i];
     }
 }
 
@@ -209,6 +249,40 @@ static int build_filter_n(const void* cov, const void* S, const WeightVec& w, fl
 #undef NF_BF
     NF_CHECK_LAUNCH("k_build_filter");
     return NF_OK;
+}
+
+template <typename T, typename TS>
+static int build_filter_sym_n(const void* cov, const void* S, const WeightVec& w, float* filt, double* sym, int N, int H, int W,
+                              hipStream_t s) {
+    dim3 g(nf_div_up(W / 2 + 1, 256), H < 4096 ? H : 4096), b(256);
+#define NF_BFS(NN)                                                                                                             \
+    case NN:                                                                                                                   \
+        hipLaunchKernelGGL((k_build_filter_sym<T, TS, NN>), g, b, 0, s, (const T*)cov, (const cpx<TS>*)S, w, filt, sym, H, W); \
+        break;
+    switch (N) {
+        NF_BFS(1)
+        NF_BFS(2)
+        NF_BFS(3)
+        NF_BFS(4)
+        NF_BFS(5)
+        NF_BFS(6)
+        default:
+            nf_set_error("build_filter supports 1..6 frequencies");
+            return NF_ERR_ARG;
+    }
+#undef NF_BFS
+    NF_CHECK_LAUNCH("k_build_filter_sym");
+    return NF_OK;
+}
+
+int build_filter_sym(int covType, int sigType, const void* cov, const void* S, const WeightVec& w, float* filt, double* sym, int N,
+                     int H, int W, hipStream_t s) {
+    if (covType == NF_F64 && sigType == NF_F32) return build_filter_sym_n<double, float>(cov, S, w, filt, sym, N, H, W, s);
+    if (covType == NF_F64 && sigType == NF_F64) return build_filter_sym_n<double, double>(cov, S, w, filt, sym, N, H, W, s);
+    if (covType == NF_F32 && sigType == NF_F32) return build_filter_sym_n<float, float>(cov, S, w, filt, sym, N, H, W, s);
+    if (covType == NF_F32 && sigType == NF_F64) return build_filter_sym_n<float, double>(cov, S, w, filt, sym, N, H, W, s);
+    nf_set_error("build_filter: bad dtype");
+    return NF_ERR_ARG;
 }
 
 int build_filter(int covType, int sigType, const void* cov, const void* S, const WeightVec& w, float* filt, int N,

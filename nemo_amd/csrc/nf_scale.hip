@@ -151,8 +151,7 @@ int run_scale(nf_plan* plan, const nf_mf_tile& t, const nf_mf_scale& sc, const L
                                sc.r0[i], sc.dlnr[i], sc.amp[i], sc.sign[i], S));
     NF_TRY(nf_fft2_forward_half(plan, NF_F32, T, NF_IN_REAL32, F, N, nullptr, nullptr, 1, S));
     // the filter (:621-627) and its symmetrised form for the half-spectrum inverse
-    NF_TRY(nf_build_filter_half(t.covType, NF_F32, t.noiseCov_d, F, t.w, sc.filt_d, N, H, W, S));
-    NF_TRY(nf_symmetrise_filter(sc.filt_d, filtSym, N, H, W, S));
+    NF_TRY(nf_build_filter_sym_half(t.covType, NF_F32, t.noiseCov_d, F, t.w, sc.filt_d, filtSym, N, H, W, S));
     // normalisation
     if (yc) {
         // the y0-scaled templates (:639-646) are the unit templates times templateScale: the factor rides on the load

@@ -388,6 +388,17 @@ class TileEngine(object):
                                            ptr(filt), N, self.npix, stream_ptr()), "nf_build_filter")
         return filt
 
+    def build_filter_sym(self, noiseCov, fSignals, w):
+        """build_filter(half=True) and symmetrise_filter in one pass: (filt float32 [N,H,W], filtSym float64 [N,H,W])."""
+        t = self.t
+        N = fSignals.shape[0]
+        filt = t.empty((N, self.H, self.W), dtype=t.float32, device=self.dev)
+        sym = t.empty((N, self.H, self.W), dtype=t.float64, device=self.dev)
+        warr = (ctypes.c_double * N)(*[float(v) for v in w])
+        check(self.lib.nf_build_filter_sym_half(prec_of(noiseCov), prec_of(fSignals), ptr(noiseCov), ptr(fSignals), warr, ptr(filt),
+                                                ptr(sym), N, self.H, self.W, stream_ptr()), "nf_build_filter_sym_half")
+        return filt, sym
+
     def apply_filter(self, F, filt, sum=True):
         t = self.t
         N = F.shape[0]

@@ -679,7 +679,8 @@ class MatchedFilter(MapFilter):
                 templateScale.append(scale)
             fSignals = eng.fft(templates, half=True)
             del templates
-            self._dFilt = eng.build_filter(noiseCov, fSignals, w, half=True)              # :621-627  K6
+            self._dFilt, sym = eng.build_filter_sym(noiseCov, fSignals, w)                # :621-627  K6 (+ the symmetrised form)
+            self._dFiltSymOf = (self._dFilt, sym)
             del noiseCov
 
             if self.params['outputUnits'] == 'yc':                                # :632-668

@@ -172,6 +172,10 @@ def test_half_stored_spectra(shape, dtype, N):
     filtH = _np(eng.build_filter(engine.to_dev(cov), Fh, w, half=True))
     filtF = _np(eng.build_filter(engine.to_dev(cov), engine.to_dev(Ffull), w))
     assert np.array_equal(filtH, filtF)
+    # the one-pass form (filter and symmetrised filter together): both outputs bit for bit
+    f1, sym1 = eng.build_filter_sym(engine.to_dev(cov), Fh, w)
+    assert np.array_equal(_np(f1), filtH)
+    assert np.array_equal(_np(sym1)[..., :hw], _np(eng.symmetrise_filter(engine.to_dev(filtH)))[..., :hw])
     # filtered inverse: asymmetric float32 filter, window, frequency sum
     filt = rng.standard_normal((N,) + shape).astype(np.float32)
     dfilt = engine.to_dev(filt)

@@ -62,18 +62,103 @@ static inline int grid_for(long long n, int threads) {
     return (int)g;
 }
 
-int gaussian_filter(int rtype, const void* in, void* tmp, void* out, int H, int W, int batch, const double* wY, int radY,
-                    const double* wX, int radX, hipStream_t s) {
-    dim3 g(grid_for((long long)H * W, 256), batch), b(256);
-    if (rtype == NF_F64) {
-        hipLaunchKernelGGL((k_gauss_axis<double, 0>), g, b, 0, s, (const double*)in, (double*)tmp, H, W, wY, radY);
-        hipLaunchKernelGGL((k_gauss_axis<double, 1>), g, b, 0, s, (const double*)tmp, (double*)out, H, W, wX, radX);
+// The same two passes with each input value fetched once instead of 2 rad + 1 times.  Same arithmetic, same order of the
+// additions (centre tap, then the pairs from the outermost inwards): bit for bit what k_gauss_axis gives.
+//  along y (axis 0): a thread owns one column of a strip of NF_GA_STRIP rows and holds its NF_GA_STRIP + 2 RAD inputs in registers
+//                    (lanes = consecutive columns: every load is a coalesced row segment);
+//  along x (axis 1): a workgroup stages 1024 + 2 rad values of one row in LDS, every thread forms four outputs from there.
+#define NF_GA_STRIP 16
+template <typename T, int RAD>
+__global__ void __launch_bounds__(256) k_gauss_cols_strip(const T* __restrict__ in, T* __restrict__ out, int H, int W,
+                                                          const double* __restrict__ w) {
+    const long long plane = (long long)H * W;
+    const T* src = in + (long long)blockIdx.z * plane;
+    T* dst = out + (long long)blockIdx.z * plane;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= W) return;
+    const int y0 = blockIdx.y * NF_GA_STRIP;
+    const bool interior = (y0 - RAD >= 0) && (y0 + NF_GA_STRIP - 1 + RAD < H);
+    double v[NF_GA_STRIP + 2 * RAD];
+#pragma unroll
+    for (int i = 0; i < NF_GA_STRIP + 2 * RAD; ++i) {
+        int yy = y0 - RAD + i;
+        if (!interior) yy = reflect_index(yy, H);
+        v[i] = (double)src[(long long)yy * W + x];
+    }
+    double wr[RAD + 1];
+#pragma unroll
+    for (int j = 0; j <= RAD; ++j) wr[j] = w[j];
+#pragma unroll
+    for (int o = 0; o < NF_GA_STRIP; ++o) {
+        if (y0 + o >= H) break;
+        double acc = __dmul_rn(v[o + RAD], wr[RAD]);
+#pragma unroll
+        for (int j = -RAD; j < 0; ++j) {
+            const double pair = __dadd_rn(v[o + RAD + j], v[o + RAD - j]);
+            acc = __dadd_rn(acc, __dmul_rn(pair, wr[RAD + j]));
+        }
+        dst[(long long)(y0 + o) * W + x] = (T)acc;
+    }
+}
+
+#define NF_GA_SEG 1024
+template <typename T>
+__global__ void __launch_bounds__(256) k_gauss_rows_lds(const T* __restrict__ in, T* __restrict__ out, int H, int W,
+                                                        const double* __restrict__ w, int rad) {
+    extern __shared__ __align__(16) unsigned char nf_gsmem[];
+    T* tile = (T*)nf_gsmem;
+    const long long plane = (long long)H * W;
+    const int y = blockIdx.y, x0 = blockIdx.x * NF_GA_SEG;
+    const T* row = in + (long long)blockIdx.z * plane + (long long)y * W;
+    T* drow = out + (long long)blockIdx.z * plane + (long long)y * W;
+    const int span = NF_GA_SEG + 2 * rad;
+    for (int i = threadIdx.x; i < span; i += blockDim.x) {
+        const int xx = x0 - rad + i;
+        tile[i] = row[(xx >= 0 && xx < W) ? xx : reflect_index(xx, W)];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NF_GA_SEG / 256; ++k) {
+        const int c = k * 256 + (int)threadIdx.x;
+        if (x0 + c >= W) break;
+        const T* t = tile + c + rad;
+        double acc = __dmul_rn((double)t[0], w[rad]);
+        for (int j = -rad; j < 0; ++j) {
+            const double pair = __dadd_rn((double)t[j], (double)t[-j]);
+            acc = __dadd_rn(acc, __dmul_rn(pair, w[rad + j]));
+        }
+        drow[x0 + c] = (T)acc;
+    }
+}
+
+template <typename T>
+static int gaussian_filter_t(const T* in, T* tmp, T* out, int H, int W, int batch, const double* wY, int radY, const double* wX,
+                             int radX, hipStream_t s) {
+    dim3 b(256);
+    // along y: the register strip for the radius of the noise-power smoothing (sigma 3 -> 12 taps each side)
+    if (radY == 12 && H <= 65535 * NF_GA_STRIP && batch <= 65535) {
+        dim3 g(nf_div_up(W, 256), nf_div_up(H, NF_GA_STRIP), batch);
+        hipLaunchKernelGGL((k_gauss_cols_strip<T, 12>), g, b, 0, s, in, tmp, H, W, wY);
     } else {
-        hipLaunchKernelGGL((k_gauss_axis<float, 0>), g, b, 0, s, (const float*)in, (float*)tmp, H, W, wY, radY);
-        hipLaunchKernelGGL((k_gauss_axis<float, 1>), g, b, 0, s, (const float*)tmp, (float*)out, H, W, wX, radX);
+        dim3 g(grid_for((long long)H * W, 256), batch);
+        hipLaunchKernelGGL((k_gauss_axis<T, 0>), g, b, 0, s, in, tmp, H, W, wY, radY);
+    }
+    if (radX <= 512 && H <= 65535 && batch <= 65535) {
+        dim3 g(nf_div_up(W, NF_GA_SEG), H, batch);
+        hipLaunchKernelGGL((k_gauss_rows_lds<T>), g, b, (size_t)(NF_GA_SEG + 2 * radX) * sizeof(T), s, tmp, out, H, W, wX, radX);
+    } else {
+        dim3 g(grid_for((long long)H * W, 256), batch);
+        hipLaunchKernelGGL((k_gauss_axis<T, 1>), g, b, 0, s, tmp, out, H, W, wX, radX);
     }
     NF_CHECK_LAUNCH("k_gauss_axis");
     return NF_OK;
+}
+
+int gaussian_filter(int rtype, const void* in, void* tmp, void* out, int H, int W, int batch, const double* wY, int radY,
+                    const double* wX, int radX, hipStream_t s) {
+    if (rtype == NF_F64)
+        return gaussian_filter_t<double>((const double*)in, (double*)tmp, (double*)out, H, W, batch, wY, radY, wX, radX, s);
+    return gaussian_filter_t<float>((const float*)in, (float*)tmp, (float*)out, H, W, batch, wY, radY, wX, radX, s);
 }
 
 template <typename T>

@@ -223,6 +223,12 @@ def test_gaussian_filter_and_background(dtype):
     xs = rng.standard_normal(small).astype(dtype)
     got = _np(_eng(small).gaussian_filter(engine.to_dev(xs), (9.0, 2.0)))
     assert np.array_equal(got, ndimage.gaussian_filter(xs, (9.0, 2.0)))
+    # several LDS segments along x, several strips along y, a batch of planes
+    wide = (130, 2300)
+    xw = rng.standard_normal((2,) + wide).astype(dtype)
+    got = _np(_eng(wide).gaussian_filter(engine.to_dev(xw), (3, 3)))
+    for k in range(2):
+        assert np.array_equal(got[k], ndimage.gaussian_filter(xw[k], (3, 3)))
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])

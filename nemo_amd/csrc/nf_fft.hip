@@ -1314,8 +1314,22 @@ static int env_int(const char* name, int dflt) {
     return atoi(v);
 }
 
+// A column pass over a small map has few tiles (840 x 1440: 180 tiles of four columns for 256 CUs): narrower tiles, down to one
+// column, until there are two workgroups per CU - the short runs are merged by the L2 (neighbouring tiles run on the same XCD),
+// an idle CU is not.  NF_FFT_COL_FILL=0 switches it off.
 template <typename T>
-int launch_lines(const LineArgs<T>& a, bool cols, int batch, int threads, hipStream_t stream) {
+static void fit_col_tiles(LineArgs<T>& a, int batch) {
+    static const int fill = env_int("NF_FFT_COL_FILL", 512);
+    while (a.linesPerWG > 1 && (long long)a.nTiles * batch < fill) {
+        a.linesPerWG /= 2;
+        a.nTiles = nf_div_up(a.nLines, a.linesPerWG);
+    }
+}
+
+template <typename T>
+int launch_lines(const LineArgs<T>& a0, bool cols, int batch, int threads, hipStream_t stream) {
+    LineArgs<T> a = a0;
+    if (cols) fit_col_tiles<T>(a, batch);
     size_t lds = (size_t)a.plan.mPad * a.linesPerWG * sizeof(cpx<T>);
     if (lds > (size_t)kMaxLds) {
         nf_set_error("FFT line of this length does not fit in LDS");
@@ -1695,6 +1709,7 @@ int Plan2D<T>::axis_filter(int axis, const void* in, int inType, void* out, int 
         a.nLines = (W + 1) / 2;
         a.linesPerWG = colsPerWG;
         a.nTiles = nf_div_up(a.nLines, colsPerWG);
+        fit_col_tiles<T>(a, batch);
         const size_t lds = (size_t)lp.mPad * a.linesPerWG * sizeof(cpx<T>);
         ProfScope ps(PT_AXIS_FILTER_COLS, stream, bytes);
         dim3 grid(((a.nTiles + 7) / 8) * 8, batch);

@@ -9,13 +9,11 @@ while read -r envs; do
   echo "== $envs" >> $O
   env $envs timeout -k 10 200 python bench.py --cpu-procs 0 --no-profile --tile 840x1440 --freqs 2 --tiles-per-gpu 8 --scales 16 --steps 10 --warmup 3 2>/dev/null | python -c "import sys,json;b=json.loads(sys.stdin.readline());print(b['value'], b['ms_per_step'])" >> $O || { echo failed >> $O; exit 1; }
 done <<LIST
-NEMO_AMD_SWITCH_INTERVAL=0
-NEMO_AMD_SWITCH_INTERVAL=0.0005
-NEMO_AMD_SWITCH_INTERVAL=0
-NEMO_AMD_SWITCH_INTERVAL=0.0005
-NEMO_AMD_SWITCH_INTERVAL=0.0001
-NEMO_AMD_SWITCH_INTERVAL=0
-NEMO_AMD_SWITCH_INTERVAL=0.0001
-NEMO_AMD_SWITCH_INTERVAL=0.002
+NF_FFT_COL_FILL=0
+NF_FFT_COL_FILL=512
+NF_FFT_COL_FILL=1024
+NF_FFT_COL_FILL=0
+NF_FFT_COL_FILL=512
+NF_FFT_COL_FILL=1024
 LIST
 cat $O

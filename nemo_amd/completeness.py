@@ -24,6 +24,50 @@ def _tileMap(config, attr, tileName, selFnDir, stem):
     return None
 
 
+def _loadTile(tileName, baseDir, baseFileName, extension='fits'):
+    """A tile image from <base>#<tile>.fits (in baseDir or in baseDir/<tile>/) or from the extension <tile> of the
+    multi-extension file <base>.fits - whichever is found, in the reference's order (nemo/completeness.py:1132-1163).
+    Returns (map array, WCS)."""
+    from .wcs import CARWCS
+    sep = os.path.sep
+    perTile = "%s#%s.%s" % (baseFileName, tileName, extension)
+    if os.path.exists(baseDir + sep + perTile):
+        fileName = baseDir + sep + perTile
+    elif os.path.exists(baseDir + sep + tileName + sep + perTile):
+        fileName = baseDir + sep + tileName + sep + perTile
+    else:
+        fileName = baseDir + sep + "%s.%s" % (baseFileName, extension)
+    hdus = fitsio.readHDUs(fileName)
+    pick = None
+    for name, data, header in hdus:
+        if name == tileName and data is not None:
+            pick = (data, header)
+            break
+    if pick is None:                       # not found by name: the first extension that holds an image
+        for name, data, header in hdus:
+            if data is not None and not isinstance(data, dict):
+                pick = (data, header)
+                break
+    if pick is None:
+        raise Exception("no image for tile '%s' in %s" % (tileName, fileName))
+    return pick[0], CARWCS(pick[1])
+
+
+def loadAreaMask(tileName, selFnDir):
+    """nemo/completeness.py:1031-1047."""
+    return _loadTile(tileName, selFnDir, "areaMask", extension='fits')
+
+
+def loadFlagMask(tileName, selFnDir):
+    """nemo/completeness.py:1050-1066."""
+    return _loadTile(tileName, selFnDir, "flagMask", extension='fits')
+
+
+def loadRMSMap(tileName, selFnDir, photFilter):
+    """nemo/completeness.py:1069-1088."""
+    return _loadTile(tileName, selFnDir, "RMSMap_%s" % (photFilter), extension='fits')
+
+
 def getRMSTab(tileName, photFilterLabel, selFnDir, footprintLabel=None, maxFlags=None, config=None, intersectMask=None):
     """Table of survey area (``areaDeg2``) against noise level (``y0RMS``) for one tile (nemo/completeness.py:1284-1345).
     ``intersectMask``: the footprint's intersection mask (what makeIntersectionMask returns there), given by the caller."""

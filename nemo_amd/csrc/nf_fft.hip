@@ -1713,10 +1713,12 @@ int Plan2D<T>::axis_filter(int axis, const void* in, int inType, void* out, int 
         const size_t lds = (size_t)lp.mPad * a.linesPerWG * sizeof(cpx<T>);
         ProfScope ps(PT_AXIS_FILTER_COLS, stream, bytes);
         dim3 grid(((a.nTiles + 7) / 8) * 8, batch);
+        static const int lfThreads = env_int("NF_LF_COL_THREADS", 0);
+        const int thr = lfThreads > 0 ? std::max(lfThreads, a.linesPerWG) : threadsCol;
         if (mode == 0)
-            hipLaunchKernelGGL((k_line_filter<T, true, 0>), grid, dim3(threadsCol), lds, stream, a);
+            hipLaunchKernelGGL((k_line_filter<T, true, 0>), grid, dim3(thr), lds, stream, a);
         else
-            hipLaunchKernelGGL((k_line_filter<T, true, 1>), grid, dim3(threadsCol), lds, stream, a);
+            hipLaunchKernelGGL((k_line_filter<T, true, 1>), grid, dim3(thr), lds, stream, a);
     }
     NF_CHECK_LAUNCH("k_line_filter");
     return NF_OK;

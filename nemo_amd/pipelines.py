@@ -176,6 +176,40 @@ def _gatherCatalogs(optimalCatalog, config):
     return tab
 
 
+def _loadCachedFilteredMap(config, f, tileName):
+    """The filtered map and S/N map of filter ``f`` for ``tileName`` as an earlier run left them under
+    filteredMaps/<tile>/<label>#<tile>_filteredMap.fits / _SNMap.fits, with the tile's area mask from selFn/
+    (nemo/pipelines.py:202-218), on the device; None if they are not there.  The reference's dictionary has no flag mask
+    (its findObjects then fails); here the one in selFn/ is used when present, else no flags."""
+    if config.filteredMapsDir is None:
+        return None
+    from . import completeness
+    from .wcs import CARWCS
+    label = f['label'] + "#" + tileName
+    stem = config.filteredMapsDir + os.path.sep + tileName + os.path.sep + label
+    if not (os.path.exists(stem + "_filteredMap.fits") and os.path.exists(stem + "_SNMap.fits")):
+        return None
+    print("... loading cached filtered map %s ..." % (stem + "_filteredMap.fits"))
+    t = engine.torch()
+    data, header = fitsio.readFITS(stem + "_filteredMap.fits")
+    d = {'data': engine.to_dev(np.ascontiguousarray(data)), 'wcs': CARWCS(header)}
+    d['mapUnits'] = header['BUNIT']
+    if 'BEAMNSR' in header.keys():
+        d['beamSolidAngle_nsr'] = header['BEAMNSR']
+        d['obsFreqGHz'] = header['FREQGHZ']
+    d['SNMap'] = engine.to_dev(np.ascontiguousarray(fitsio.readFITS(stem + "_SNMap.fits")[0]))
+    areaMask, wcs = completeness.loadAreaMask(tileName, config.selFnDir)
+    d['surveyMask'] = engine.to_dev(np.ascontiguousarray(areaMask))
+    try:
+        flagMask = completeness.loadFlagMask(tileName, config.selFnDir)[0]
+    except Exception:
+        flagMask = np.zeros(data.shape, dtype=np.int32)
+    d['flagMask'] = engine.to_dev(np.ascontiguousarray(flagMask)).to(t.int32)
+    d['label'] = f['label']
+    d['tileName'] = tileName
+    return d
+
+
 def _loadCachedRMSMap(config, tileName, photFilter):
     """RMS map of the reference filter for ``tileName`` as a float32 device tensor: from HBM if an earlier pass of this
     process left it there, else from selFnDir/<tile>/RMSMap_<photFilter>#<tile>.fits."""
@@ -336,9 +370,6 @@ def _filterMapsAndMakeCatalogs(config, rootOutDir=None, useCachedFilters=False, 
                                useCachedFilteredMaps=False, measureFluxes=True, invertMap=False, verbose=True,
                                writeAreaMask=False, writeFlagMask=False):
     """nemo/pipelines.py:118-398."""
-    if useCachedFilteredMaps:
-        raise NotImplementedError("useCachedFilteredMaps reads FITS products written by an earlier run (nemo/pipelines.py:204-218): "
-                                  "on-disk formats are a 'next' row of the scope table")
     # nemo/pipelines.py:177-179: with a cached RMS map the pixel window is undone after the new S/N map is made
     undoPixelWindow = config.parDict['undoPixelWindow']
     if useCachedRMSMap == True:
@@ -393,22 +424,34 @@ def _filterMapsAndMakeCatalogs(config, rootOutDir=None, useCachedFilters=False, 
                 tileCache[('cachedFilter', config.cachedFilters[tileName].label)] = config.cachedFilters[tileName]
             lanes, groupSize = _scaleGrouping(config, tileName, len(filtersList))
             def filteredScales():
-                # the filters of this tile, `groupSize` of them per library call (filters.filterMapsGroup)
+                # the filters of this tile, `groupSize` of them per library call (filters.filterMapsGroup); with
+                # useCachedFilteredMaps a filter whose maps an earlier run left on disk is read instead (nemo/pipelines.py:202-218)
                 for g0 in range(0, len(filtersList), groupSize):
                     group = filtersList[g0:g0 + groupSize]
-                    res = filters.filterMapsGroup(config.unfilteredMapsDictList, group, tileName, diagnosticsDir=diagnosticsDir,
+                    cached = {}
+                    if useCachedFilteredMaps == True:
+                        for f in group:
+                            loaded = _loadCachedFilteredMap(config, f, tileName)
+                            if loaded is not None:
+                                cached[f['label']] = loaded
+                    toFilter = [f for f in group if f['label'] not in cached]
+                    res = filters.filterMapsGroup(config.unfilteredMapsDictList, toFilter, tileName, diagnosticsDir=diagnosticsDir,
                                                   selFnDir=config.selFnDir, verbose=verbose, undoPixelWindow=undoPixelWindow,
-                                                  useCachedFilter=useCachedFilters, tileCache=tileCache, lanes=lanes)
-                    for f in group:
-                        yield (f,) + res.pop(0) + (len(res) == 0,)
+                                                  useCachedFilter=useCachedFilters, tileCache=tileCache, lanes=lanes) if toFilter else []
+                    for k, f in enumerate(group):
+                        last = k == len(group) - 1
+                        if f['label'] in cached:
+                            yield (f, cached[f['label']], None, last)
+                        else:
+                            yield (f,) + res.pop(0) + (last,)
 
             groupJobs = []
             for f, filteredMapDict, filterObj, lastOfGroup in filteredScales():
                 label = f['label'] + "#" + tileName
                 catalogDict[label] = {}
-                if f['label'] == photFilter:
+                if f['label'] == photFilter and filterObj is not None:
                     config.cachedFilters[tileName] = filterObj
-                if f['label'] == photFilter and useCachedRMSMap == False:
+                if f['label'] == photFilter and useCachedRMSMap == False and 'RMSMap' in filteredMapDict:
                     # kept in HBM for later passes with useCachedRMSMap (the reference reloads selFn/RMSMap_<photFilter>.fits,
                     # nemo/completeness.py:1070-1088); also written there when saveRMSMap is set and there is a selFnDir
                     config.cachedRMSMapDict[tileName] = filteredMapDict['RMSMap']

@@ -182,3 +182,35 @@ def test_driver_writes_the_tile_products(tmp_path):
     back = catalogs.readCatalog(out)
     assert len(back) == len(cat) and list(np.asarray(back['name'])) == list(np.asarray(cat['name']))
     assert np.array_equal(np.asarray(back['SNR']), np.asarray(cat['SNR']))
+
+
+def test_use_cached_filtered_maps(tmp_path):
+    """useCachedFilteredMaps (nemo/pipelines.py:202-218): filters whose maps lie under filteredMaps/<tile>/ are read, not run;
+    detection and photometry on the read maps give the catalogue of the run that made them.  (The reference no longer writes
+    these per-tile files itself: the test writes them with the library's own FITS writer.)"""
+    from nemo_amd import filters, fitsio
+    mapsL, wcs, truth = helpers.make_tile(SHAPE, seed=12, numSources=5, kind='clusters', holes=True)
+    config = _config(helpers.product_maps(mapsL), outputDir=str(tmp_path / "run"))
+    cat = pipelines.filterMapsAndMakeCatalogs(config, verbose=False, writeAreaMask=True, writeFlagMask=True)
+    assert len(cat) >= 3
+    tile = config.tileNames[0]
+    os.makedirs(config.filteredMapsDir + os.sep + tile, exist_ok=True)
+    keep = filters.RETURN_DEVICE_ARRAYS
+    filters.RETURN_DEVICE_ARRAYS = False
+    try:
+        cache = {}
+        for f in config.parDict['mapFilters'][:2]:            # two of the three filters on disk, the third is filtered again
+            d = filters.filterMaps(config.unfilteredMapsDictList, f, tile, diagnosticsDir=None, selFnDir=None, verbose=False,
+                                   undoPixelWindow=config.parDict['undoPixelWindow'], tileCache=cache)
+            stem = config.filteredMapsDir + os.sep + tile + os.sep + f['label'] + "#" + tile
+            fitsio.writeFITS(stem + "_filteredMap.fits", d['data'], d['wcs'].header)
+            fitsio.writeFITS(stem + "_SNMap.fits", d['SNMap'], d['wcs'].header)
+    finally:
+        filters.RETURN_DEVICE_ARRAYS = keep
+    before = dict(filters._scaleEntryStats)
+    cat2 = pipelines.filterMapsAndMakeCatalogs(config, verbose=False, useCachedFilteredMaps=True)
+    assert filters._scaleEntryStats['scales'] == before['scales'] + 1          # only the third filter ran
+    _same_catalog(cat, cat2, snrTol=0.0, posTol=0.0)
+    for k in ('y_c', 'fixed_y_c', 'fixed_SNR', 'flags', 'numSigPix'):
+        ia, ib = np.lexsort((cat['decDeg'], cat['RADeg'])), np.lexsort((cat2['decDeg'], cat2['RADeg']))
+        assert np.array_equal(np.asarray(cat[k])[ia], np.asarray(cat2[k])[ib]), k

@@ -463,7 +463,9 @@ def makeForcedPhotometryCatalog(filteredMapDict, inputCatalog, useInterpolator=T
     """Catalogue of S/N values at given positions (nemo/photometry.py:380-444).  ``inputCatalog``: a
     :class:`nemo_amd.catalogs.Table` (or dict of columns) with RADeg/decDeg (or ra/dec, RA/DEC) columns."""
     if isinstance(inputCatalog, str):
-        raise NotImplementedError("reading catalogue files needs astropy.table; pass a Table")
+        # a catalogue file (nemo/photometry.py:402-403 reads it with astropy.table): FITS binary table or tab-delimited .csv,
+        # as catalogs.writeCatalog writes them
+        inputCatalog = catalogs.readCatalog(inputCatalog)
     tab = inputCatalog if isinstance(inputCatalog, catalogs.Table) else catalogs.Table(cols=dict(inputCatalog))
     RAKey, decKey = catalogs.getTableRADecKeys(tab)
     RA = np.array(tab[RAKey], dtype=np.float64)

@@ -98,7 +98,7 @@ def test_cached_filter_and_rms_refilter_mode():
     assert np.abs(np.asarray(again['y_c']) / np.asarray(first['y_c']) - 1).max() < 1e-12
 
 
-def test_forced_photometry_in_the_driver():
+def test_forced_photometry_in_the_driver(tmp_path):
     mapsL, wcs, truth = helpers.make_tile(SHAPE, seed=8, numSources=5, kind='clusters')
     config = _config(helpers.product_maps(mapsL))
     detected = pipelines.filterMapsAndMakeCatalogs(config, verbose=False)
@@ -114,6 +114,13 @@ def test_forced_photometry_in_the_driver():
     ia, ib = np.argsort(np.asarray(cat['RADeg'])), np.argsort(np.asarray(detected['RADeg']))
     ratio = np.asarray(cat['SNR'])[ia] / np.asarray(detected['SNR'])[ib]
     assert np.all(ratio > 0.8) and np.all(ratio < 1.05)
+    # the same from a catalogue file (nemo/photometry.py:402-403), FITS table and .csv
+    for ext in ("fits", "csv"):
+        path = str(tmp_path / ("forced." + ext))
+        catalogs.writeCatalog(forced, path)
+        cat3 = pipelines.filterMapsAndMakeCatalogs(_config(helpers.product_maps(mapsL), forcedPhotometryCatalog=path), verbose=False)
+        ic = np.argsort(np.asarray(cat3['RADeg']))
+        assert len(cat3) == len(cat) and np.array_equal(np.asarray(cat3['SNR'])[ic], np.asarray(cat['SNR'])[ia])
 
 
 def test_fitQ_against_the_oracle():

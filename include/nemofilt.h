@@ -145,6 +145,10 @@ int nf_build_filter(int covType, int sigType, const void* cov_d, const void* S_d
 int nf_apply_filter(int prec, const void* F_d, const float* filt_d, void* G_d, int N, int sum, long long npix,
                     void* stream);
 
+/* nemo/filters.py:847, the frequency sum AFTER the inverse transforms, as the reference takes it: out_d[n] = in_d[0][n] +
+ * in_d[1][n] + ... in float32, planes added in order (ndarray.sum(axis=0)). */
+int nf_sum_planes(const float* in_d, float* out_d, int N, long long n, void* stream);
+
 /* pixel-window multiplication inside enmap.apply_window (nemo/filters.py:100,644): F[b][y][x] *= wy[y]*wx[x]
  * with wy = sinc(fftfreq(H))**pow, wx likewise (float64 device tables). */
 int nf_window_mul(int prec, void* F_d, const double* wy_d, const double* wx_d, int H, int W, int batch, void* stream);

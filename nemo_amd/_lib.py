@@ -78,6 +78,7 @@ SIGNATURES = {
                                    c_int, c_void_p]),
     'nf_build_filter': (c_int, [c_int, c_int, c_void_p, c_void_p, ctypes.POINTER(c_double), c_void_p, c_int, c_ll, c_void_p]),
     'nf_apply_filter': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_ll, c_void_p]),
+    'nf_sum_planes': (c_int, [c_void_p, c_void_p, c_int, c_ll, c_void_p]),
     'nf_window_mul': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     'nf_paint_radial2': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_int, c_double, c_double, c_double, c_double, c_double, c_double, c_void_p]),

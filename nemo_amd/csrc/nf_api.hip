@@ -515,6 +515,15 @@ int nf_noise_map_smart(int vtype, const void* filtered, const void* weights, int
     return nf::noise_map_smart(vtype, filtered, weights, wtype, rms, n, numBins, work, workBytes, S(stream));
 }
 
+int nf_sum_planes(const float* in, float* out, int N, long long n, void* stream) {
+    if (!in || !out || N < 1 || n < 1) {
+        nf_set_error("nf_sum_planes: bad arguments");
+        return NF_ERR_ARG;
+    }
+    nf::ProfScope ps(nf::PT_APPLY_FILTER, S(stream), (double)n * (N + 1) * 4.0);
+    return nf::sum_planes(in, out, N, n, S(stream));
+}
+
 int nf_median_stack(int rtype, const void* in, void* out, int N, long long n, void* stream) {
     if (!in || !out || N < 1 || N > 8 || n < 1) {
         nf_set_error("nf_median_stack: bad arguments (1 <= N <= 8)");

@@ -37,6 +37,7 @@ int scale_mask(int vtype, const float* in, void* out, double norm, const double*
 int finalize(int vtype, void* filtered, const float* rms, const unsigned char* surveyMask, const unsigned char* psMask,
              const unsigned char* edgeCheck, void* snOut, float* rmsOut, unsigned char* maskOut, int H, int W, int apodPix,
              int mulSurvey, unsigned long long* chunkRange, int* zeroRows, hipStream_t s);
+int sum_planes(const float* in, float* out, int N, long long n, hipStream_t s);
 int sn_cached(int vtype, const void* data, const float* rms, double* sn, long long n, hipStream_t s);
 int restore_zeros(int vtype, void* data, const void* ref, long long n, hipStream_t s);
 

@@ -453,6 +453,22 @@ int paint_radial2(float* out, float* out2, int H, int W, const double* A, const 
     return NF_OK;
 }
 
+// out = in[0] + in[1] + ... + in[N-1], float32 planes added in plane order (ndarray.sum(axis=0) of a [N, H, W] cube adds the
+// planes one after the other): nemo/filters.py:847 sums the per-frequency filtered maps AFTER the inverse transforms.
+__global__ void k_sum_planes(const float* __restrict__ in, float* __restrict__ out, int N, long long n) {
+    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x) {
+        float acc = in[p];
+        for (int i = 1; i < N; ++i) acc = __fadd_rn(acc, in[(long long)i * n + p]);
+        out[p] = acc;
+    }
+}
+
+int sum_planes(const float* in, float* out, int N, long long n, hipStream_t s) {
+    hipLaunchKernelGGL(k_sum_planes, dim3(grid_for(n, 256)), dim3(256), 0, s, in, out, N, n);
+    NF_CHECK_LAUNCH("k_sum_planes");
+    return NF_OK;
+}
+
 // filtered(VT) = float32 map * signalNorm * psMask.  VT = double when signalNorm is a float64 scalar
 // ('yc' mode under numpy >= 2 promotion), float when it is a float32 scalar ('uK' mode).
 template <typename VT>

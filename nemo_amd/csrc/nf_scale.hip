@@ -155,16 +155,22 @@ int run_scale(nf_plan* plan, const nf_mf_tile& t, const nf_mf_scale& sc, const L
     // normalisation
     if (yc) {
         // the y0-scaled templates (:639-646) are the unit templates times templateScale: the factor rides on the load
-        // (one map: only its rows around the tile centre are read below, so only those are computed)
-        NF_TRY(nf_fft2_inverse_half(plan, NF_F32, F, filtSym, N, 0, t.winY_d, t.winX_d, sc.templateScale, work, sig, NF_IN_REAL32, 1,
-                                    N == 1 ? t.centreRowLo : 0, N == 1 ? t.centreRowHi : 0, 0, S));
+        if (N == 1) {
+            // one map: only its rows around the tile centre are read below, so only those are computed
+            NF_TRY(nf_fft2_inverse_half(plan, NF_F32, F, filtSym, 1, 0, t.winY_d, t.winX_d, sc.templateScale, work, sig, NF_IN_REAL32, 1,
+                                        t.centreRowLo, t.centreRowHi, 0, S));
+        } else {
+            // several maps: the per-frequency filtered templates are wanted anyway (:662-667); their sum in real space, in
+            // plane order, is the filtered template (:647 -> :847 sums after the inverse transforms)
+            NF_TRY(nf_fft2_inverse_half(plan, NF_F32, F, filtSym, 1, 1, t.winY_d, t.winX_d, sc.templateScale, work, planes,
+                                        NF_IN_REAL32, N, 0, 0, 0, S));
+            NF_TRY(nf_sum_planes(planes, sig, N, npix, S));
+        }
         NF_TRY(nf_spline_eval(NF_F32, sig, 0, H, W, t.centreYX_d, 1, t.halfWin, t.centreClass, nullptr, 0, peak, S));
         hipLaunchKernelGGL(k_signal_norm, dim3(1), dim3(64), 0, st, 0, peak, t.y0, sc.signalNorm_d);
         NF_CHECK_LAUNCH("k_signal_norm");
         if (N > 1) {
             NF_TRY(nf_map_max(NF_F32, sig, npix, mapMax, S));
-            NF_TRY(nf_fft2_inverse_half(plan, NF_F32, F, filtSym, 1, 1, t.winY_d, t.winX_d, sc.templateScale, work, planes,
-                                        NF_IN_REAL32, N, 0, 0, 0, S));
             hipLaunchKernelGGL(k_rel_weights, dim3(1), dim3(64), 0, st, planes, mapMax, N, npix, sc.relWeights_d);
             NF_CHECK_LAUNCH("k_rel_weights");
         }

@@ -407,6 +407,16 @@ class TileEngine(object):
                                        stream_ptr()), "nf_apply_filter")
         return G
 
+    def sum_planes(self, planes):
+        """float32 [N,H,W] -> [H,W], planes added in order (ndarray.sum(axis=0); nemo/filters.py:847)."""
+        t = self.t
+        p3 = planes.reshape(-1, self.H, self.W)
+        if p3.dtype != t.float32 or not p3.is_contiguous():
+            raise NemoFiltError("sum_planes takes contiguous float32 planes")
+        out = t.empty((self.H, self.W), dtype=t.float32, device=self.dev)
+        check(self.lib.nf_sum_planes(ptr(p3), ptr(out), p3.shape[0], self.npix, stream_ptr()), "nf_sum_planes")
+        return out
+
     def window_mul_(self, F, pow):
         wy, wx = self.window(pow)
         F3 = F.reshape(-1, self.H, self.W)

@@ -691,9 +691,18 @@ class MatchedFilter(MapFilter):
                 cRADeg, cDecDeg = self.wcs.getCentreWCSCoords()
                 cx, cy = self.wcs.wcs2pix(cRADeg, cDecDeg)
                 bckSub = 'bckSub' in self.params.keys() and 'bckSubScaleArcmin' in self.params.keys() and self.params['bckSub'] == True
-                # one frequency: the filtered template is only read around the tile centre (:654-657) - only those rows are made
-                filteredSignal = self._applyFilterDevice(fSignals, window=1.0, half=True, planeScale=templateScale,
-                                                         rows=self._centreRows(cy) if (N == 1 and not bckSub) else None)
+                planes = None
+                if N == 1 and not bckSub:
+                    # one frequency: the filtered template is only read around the tile centre (:654-657) - only those rows are made
+                    filteredSignal = self._applyFilterDevice(fSignals, window=1.0, half=True, planeScale=templateScale,
+                                                             rows=self._centreRows(cy))
+                elif not bckSub:
+                    # several frequencies: the per-frequency filtered templates are wanted below anyway (:662-667); the filtered
+                    # template is their sum in real space, in plane order, as :847 takes it
+                    planes = eng.ifft(fSignals, out='f32', filt=self._filtFor(True), window=1.0, half=True, planeScale=templateScale)
+                    filteredSignal = eng.sum_planes(planes)
+                else:
+                    filteredSignal = self._applyFilterDevice(fSignals, window=1.0, half=True, planeScale=templateScale)
                 # signalNorm = y0 / peak stays on the device (float64 division there): the host goes on enqueueing
                 peak = eng.spline_eval(filteredSignal, [[cy, cx]], to_host=False)                # :654-657  K9
                 self._signalNorm = eng.signal_norm('yc', peak, y0)                # :659
@@ -706,8 +715,9 @@ class MatchedFilter(MapFilter):
                     # the peak and the planes' values there stay on the device; the float32 divisions of :667 are done on
                     # the host when somebody reads the weights (_DeviceWeights) - the enqueueing thread does not wait
                     mm = eng.map_max(filteredSignal, to_host=False)               # :661
-                    planes = eng.ifft(fSignals, out='f32', filt=self._filtFor(True), window=1.0, half=True,
-                                      planeScale=templateScale)                                                      # :662-667
+                    if planes is None:
+                        planes = eng.ifft(fSignals, out='f32', filt=self._filtFor(True), window=1.0, half=True,
+                                          planeScale=templateScale)                                                  # :662-667
                     vals = planes.reshape(N, -1).index_select(1, mm[1:2].to(t.int64)).reshape(N)
                     self.fRelWeights = _DeviceWeights([m['obsFreqGHz'] for m in self.unfilteredMapsDictList],
                                                       t.cat([vals.to(t.float64), mm[:1]]))

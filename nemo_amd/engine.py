@@ -944,22 +944,43 @@ class TileEngine(object):
     def spline_points(self, yx, halfWin=32):
         """Evaluation points uploaded once (one transfer: the pairs, then the indices of the border points), for several
         spline evaluations at the same positions (different maps)."""
-        yx = np.ascontiguousarray(np.asarray(yx, dtype=np.float64).reshape(-1, 2))
-        n = len(yx)
-        if n == 0:
-            return _SplinePoints(None, 0, 1, halfWin)
-        iy, ix = np.floor(yx[:, 0]), np.floor(yx[:, 1])
-        interior = (iy - halfWin - 1 >= 0) & (iy + halfWin + 2 <= self.H - 1) & (ix - halfWin - 1 >= 0) & \
-            (ix + halfWin + 2 <= self.W - 1) & (yx[:, 0] >= 0) & (yx[:, 0] <= self.H - 1) & (yx[:, 1] >= 0) & (yx[:, 1] <= self.W - 1)
-        pointsClass = 1 if interior.all() else (2 if not interior.any() else 0)
-        edgeIdx = np.flatnonzero(~interior).astype(np.int32)
-        buf = np.empty(2 * n + (len(edgeIdx) + 1) // 2, dtype=np.float64)
-        buf[:2 * n] = yx.reshape(-1)
-        if len(edgeIdx) > 0:
-            buf[2 * n:].view(np.int32)[:len(edgeIdx)] = edgeIdx
+        return self.spline_points_multi([yx], halfWin)[0]
+
+    def spline_points_multi(self, yxList, halfWin=32):
+        """spline_points for several point sets in ONE upload (every upload is host time on the enqueueing thread)."""
+        sets, total = [], 0
+        for yx in yxList:
+            yx = np.ascontiguousarray(np.asarray(yx, dtype=np.float64).reshape(-1, 2))
+            n = len(yx)
+            if n == 0:
+                sets.append((yx, 0, None, 1, 0, 0))
+                continue
+            iy, ix = np.floor(yx[:, 0]), np.floor(yx[:, 1])
+            interior = (iy - halfWin - 1 >= 0) & (iy + halfWin + 2 <= self.H - 1) & (ix - halfWin - 1 >= 0) & \
+                (ix + halfWin + 2 <= self.W - 1) & (yx[:, 0] >= 0) & (yx[:, 0] <= self.H - 1) & (yx[:, 1] >= 0) & (yx[:, 1] <= self.W - 1)
+            pointsClass = 1 if interior.all() else (2 if not interior.any() else 0)
+            edgeIdx = np.flatnonzero(~interior).astype(np.int32)
+            size = 2 * n + (len(edgeIdx) + 1) // 2
+            sets.append((yx, n, edgeIdx, pointsClass, total, size))
+            total += size
+        if total == 0:
+            return [_SplinePoints(None, 0, 1, halfWin) for _ in sets]
+        buf = np.empty(total, dtype=np.float64)
+        for yx, n, edgeIdx, pointsClass, off, size in sets:
+            if n == 0:
+                continue
+            buf[off:off + 2 * n] = yx.reshape(-1)
+            if len(edgeIdx) > 0:
+                buf[off + 2 * n:off + size].view(np.int32)[:len(edgeIdx)] = edgeIdx
         dev = to_dev(buf)
-        edge = dev[2 * n:].view(self.t.int32) if len(edgeIdx) > 0 else None
-        return _SplinePoints(dev[:2 * n], n, pointsClass, halfWin, edge, len(edgeIdx))
+        out = []
+        for yx, n, edgeIdx, pointsClass, off, size in sets:
+            if n == 0:
+                out.append(_SplinePoints(None, 0, 1, halfWin))
+                continue
+            edge = dev[off + 2 * n:off + size].view(self.t.int32) if len(edgeIdx) > 0 else None
+            out.append(_SplinePoints(dev[off:off + 2 * n], n, pointsClass, halfWin, edge, len(edgeIdx)))
+        return out
 
     def spline_eval_batch(self, jobs):
         """[(map tensor, _SplinePoints, negate)] -> list of float64 device tensors, one launch per kernel for all jobs of a

@@ -208,6 +208,9 @@ class MapFilter(object):
                 self._dFlagMask = term if self._dFlagMask is None else self._dFlagMask + term
             if shared is not None:
                 shared['dFlagMask'] = self._dFlagMask
+                # "does the tile have any flagged pixel": asked once per tile on the device, read by photometry.findObjects
+                # together with its first fetch - a tile without flags needs no flag lookups at the objects
+                shared['flagAny'] = (self._dFlagMask, (self._dFlagMask != 0).any().to(t.float64).reshape(1))
         self._flagMaskHost = None
 
         # Beam solid angles in nanosteradians (nemo/filters.py:170-189)
@@ -430,6 +433,8 @@ class MapFilter(object):
             hint = getattr(self, '_snChunks', None)
             if hint is not None and hint[0] is sn:
                 out['_snChunks'] = hint          # (S/N tensor, its per-chunk range table): photometry.findObjects' shortcut
+            if self._shared is not None and 'flagAny' in self._shared and self._shared['flagAny'][0] is self._dFlagMask:
+                out['_flagAny'] = self._shared['flagAny']
         else:
             # dtypes as the reference produces them under numpy >= 2: the masks become float through
             # edgeCheck (float32 if a rank filter ran in the Fourier variant, else float64)

@@ -190,7 +190,11 @@ def _findObjectsSteps(filteredMapDict, threshold=3.0, minObjPix=3, rejectBorder=
         cap = eng.statsCap
         labels, recs = eng.label_and_stats(dSN, threshold, negate=invertMap, slot=slot, cap=cap, snChunks=snChunks)
         tm = _mark('label+stats enqueue', tm)
-        got = yield [('stats', recs)]
+        flagAny = filteredMapDict.get('_flagAny', None) if hasattr(filteredMapDict, 'get') else None
+        if flagAny is not None and flagAny[0] is not flagMask:
+            flagAny = None
+        got = yield ([('stats', recs)] + ([('flagAny', flagAny[1])] if flagAny is not None else []))
+        noFlags = flagAny is not None and got['flagAny'][0] == 0.0
         st = got['stats'].reshape(cap + 1, 6)
         numObjects = int(st[0, 0])
         if numObjects <= cap:
@@ -226,7 +230,7 @@ def _findObjectsSteps(filteredMapDict, threshold=3.0, minObjPix=3, rejectBorder=
     queued = []        # device results wanted on the host: (key, 1-D tensor), fetched together below
     splineJobs = []    # (key, map, points, negate): every spline read of this pass goes out as one batch
     if useInterpolator == True:                                                   # :81-84,128
-        splineJobs.append(('SNR', dSN, eng.spline_points(np.stack([ys, xs], axis=1)), invertMap))
+        pass        # (the positions go up below, in one transfer with those of the prefetch reads)
     else:
         queued.append(('SNR', _lookupDev(dSN, iyr, ixr) * (-1.0 if invertMap else 1.0)))
     if ringLabels is not None:                                                    # :112-114
@@ -235,7 +239,7 @@ def _findObjectsSteps(filteredMapDict, threshold=3.0, minObjPix=3, rejectBorder=
         lab = ringLabels[iy, ix].to(t.int64)
         queued.append(('ring', isRing[lab]))
     flagsOnDevice = hasattr(flagMask, 'is_cuda')
-    if flagsOnDevice:
+    if flagsOnDevice and not noFlags:
         queued.append(('flags', _lookupDev(flagMask, iyr, ixr)))
     if measureShapes == True:                                                     # :133-150 (the sums; the ellipse below)
         shapes = eng.object_shapes(dSN, labels, numObjects, negate=invertMap)
@@ -252,7 +256,10 @@ def _findObjectsSteps(filteredMapDict, threshold=3.0, minObjPix=3, rejectBorder=
         inside = (x2.astype(np.int64) > 0) & (x2.astype(np.int64) < W) & (y2.astype(np.int64) > 0) & (y2.astype(np.int64) < H)
         yy = np.clip(y2, 0.0, H - 1.0)
         xx = np.clip(x2, 0.0, W - 1.0)
-        pts = eng.spline_points(np.stack([yy, xx], axis=1)) if useInterpolator else None     # one upload for all maps
+        pts = None
+        if useInterpolator:
+            ptsSN, pts = eng.spline_points_multi([np.stack([ys, xs], axis=1), np.stack([yy, xx], axis=1)])   # one upload
+            splineJobs.append(('SNR', dSN, ptsSN, invertMap))
         for k, (mapLike, neg) in enumerate(_prefetch):
             d = engine.to_dev(mapLike)
             if useInterpolator:
@@ -265,6 +272,8 @@ def _findObjectsSteps(filteredMapDict, threshold=3.0, minObjPix=3, rejectBorder=
                 queued.append(('pre%d' % k, _lookupDev(d, iyn % H, ixn % W) * (-1.0 if neg else 1.0)))
         if pre is not None:
             pre = [(mapLike, neg) for mapLike, neg in _prefetch]
+    elif useInterpolator == True:
+        splineJobs.append(('SNR', dSN, eng.spline_points(np.stack([ys, xs], axis=1)), invertMap))
     if splineJobs:
         for (key, _, _, _), out in zip(splineJobs, eng.spline_eval_batch([(m, p, n) for _, m, p, n in splineJobs])):
             queued.append((key, out))
@@ -276,7 +285,10 @@ def _findObjectsSteps(filteredMapDict, threshold=3.0, minObjPix=3, rejectBorder=
     keep = SNRs > threshold                                                       # :186
     if keep.sum() == 0:
         return []
-    flags = got['flags'].astype(_numpyDtype(flagMask)) if flagsOnDevice else np.asarray(flagMask)[iyr, ixr]
+    if flagsOnDevice and noFlags:
+        flags = np.zeros(len(sel), dtype=_numpyDtype(flagMask))         # (the tile has no flagged pixel at all)
+    else:
+        flags = got['flags'].astype(_numpyDtype(flagMask)) if flagsOnDevice else np.asarray(flagMask)[iyr, ixr]
     tab = catalogs.Table()
     tab.setLazyNames(objIdent, longNames)                                          # :120-123 (built on first access)
     tab['RADeg'] = RADeg[keep]

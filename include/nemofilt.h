@@ -185,11 +185,15 @@ int nf_scale_mask_dev(int vtype, const float* in_d, void* out_d, const double* s
  * default estimator with one bin this includes the per-block sums, the tail lists in list and in magnitude-class
  * order and the class tables of the single-read evaluation, about 16 bytes per pixel).
  * estimator: 0 = 3-sigma clipped standard deviation (10 iterations, the default), 1 = RMSEstimator 'percentile'
- * (np.percentile(abs(values), 68.3), nemo/filters.py:459-460).  'biweight' needs astropy.stats and is not provided. */
+ * (np.percentile(abs(values), 68.3), nemo/filters.py:459-460).  'biweight' needs astropy.stats and is not provided.
+ * tablesValid (a hint that changes no result; 0 = never wrong): non-zero says that work_d was last used by a call of this entry
+ * point with the same H, W, grid (ny, nx, edges, overlap), estimator, numBins = 1 and the same values in weights_d, and has not
+ * been written since - the block tables it still holds (the cuts of the grid into blocks, every block's weight range) are
+ * then not rebuilt and the weights are read only for blocks whose pixels are valid in part: the scales of one tile. */
 size_t nf_noise_workspace_bytes(int H, int W, int ny, int nx, int numBins);
 int nf_noise_map(int vtype, const void* filtered_d, const void* weights_d, int wtype, float* rms_d, int H, int W,
                  int ny, int nx, const int* yEdges_d, const int* xEdges_d, int overlap, int numBins,
-                 const double* quantiles, int estimator, void* work_d, size_t workBytes, void* stream);
+                 const double* quantiles, int estimator, void* work_d, size_t workBytes, int tablesValid, void* stream);
 /* MapFilter.makeNoiseMap with noiseGridArcmin: "smart" (nemo/filters.py:363-404): numBins edges
  * np.linspace(w.min(), w.max(), numBins) over the median weight map, per bin (strictly between two edges) the 3-sigma
  * clipped standard deviation of the non-zero map values, written to every pixel of the bin when positive.  n = H*W;
@@ -448,6 +452,8 @@ typedef struct nf_mf_tile {
     const double* winX_d;
     const double* axisWinY_d;          /* pixel-window undo (both or neither): nf_axis_filter tables for axis 1 and axis 0 */
     const double* axisWinX_d;
+    unsigned int noiseTablesLanes;     /* bit l: work_d[l] still holds this tile's noise block tables (tablesValid of nf_noise_map
+                                        * for the first scale of lane l; later scales of a lane in one call always reuse) */
 } nf_mf_tile;
 
 typedef struct nf_mf_scale {

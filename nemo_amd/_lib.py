@@ -40,7 +40,7 @@ class MfTile(ctypes.Structure):
                 ('xEdges_d', c_void_p), ('overlap', c_int), ('numBins', c_int), ('estimator', c_int),
                 ('quantiles', ctypes.POINTER(c_double)), ('trimSizePix', c_int), ('apodPix', c_int), ('y0', c_double),
                 ('centreYX_d', c_void_p), ('centreClass', c_int), ('centreRowLo', c_int), ('centreRowHi', c_int), ('halfWin', c_int), ('winY_d', c_void_p), ('winX_d', c_void_p),
-                ('axisWinY_d', c_void_p), ('axisWinX_d', c_void_p)]
+                ('axisWinY_d', c_void_p), ('axisWinX_d', c_void_p), ('noiseTablesLanes', ctypes.c_uint)]
 
 
 class MfScale(ctypes.Structure):
@@ -88,7 +88,7 @@ SIGNATURES = {
     'nf_scale_mask_dev': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_ll, c_void_p]),
     'nf_noise_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     'nf_noise_map': (c_int, [c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
-                             c_int, c_int, ctypes.POINTER(c_double), c_int, c_void_p, c_size_t, c_void_p]),
+                             c_int, c_int, ctypes.POINTER(c_double), c_int, c_void_p, c_size_t, c_int, c_void_p]),
     'nf_noise_smart_workspace_bytes': (c_size_t, []),
     'nf_noise_map_smart': (c_int, [c_int, c_void_p, c_void_p, c_int, c_void_p, c_ll, c_int, c_void_p, c_size_t, c_void_p]),
     'nf_median_stack': (c_int, [c_int, c_void_p, c_void_p, c_int, c_ll, c_void_p]),

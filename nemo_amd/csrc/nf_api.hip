@@ -472,7 +472,7 @@ size_t nf_noise_workspace_bytes(int H, int W, int ny, int nx, int numBins) {
 
 int nf_noise_map(int vtype, const void* filtered, const void* weights, int wtype, float* rms, int H, int W, int ny, int nx,
                  const int* yEdges, const int* xEdges, int overlap, int numBins, const double* quantiles, int estimator,
-                 void* work, size_t workBytes, void* stream) {
+                 void* work, size_t workBytes, int tablesValid, void* stream) {
     if (!filtered || !weights || !rms || !yEdges || !xEdges || !work || ny < 1 || nx < 1 || overlap < 0 || numBins < 1 ||
         numBins > 16 || (numBins > 1 && !quantiles)) {
         nf_set_error("nf_noise_map: bad arguments");
@@ -491,7 +491,7 @@ int nf_noise_map(int vtype, const void* filtered, const void* weights, int wtype
     for (int i = 0; i < numBins && quantiles; ++i) g.quantiles[i] = quantiles[i];
     nf::ProfScope ps(nf::PT_NOISE_MAP, S(stream),
                      (double)H * W * ((vtype == NF_F32 ? 4.0 : 8.0) + (wtype == NF_F32 ? 4.0 : 8.0) + 4.0));
-    return nf::noise_map(vtype, filtered, weights, wtype, rms, H, W, g, work, workBytes, S(stream));
+    return nf::noise_map(vtype, filtered, weights, wtype, rms, H, W, g, work, workBytes, tablesValid != 0, S(stream));
 }
 
 int nf_sn_cached(int vtype, const void* data, const float* rms, double* sn, long long n, void* stream) {

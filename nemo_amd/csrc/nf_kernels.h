@@ -70,7 +70,7 @@ struct NoiseGrid {
     double quantiles[16];  // percentile/100 of the lower edge of each weight bin (np.arange(0,100,100/numBins)/100)
 };
 int noise_map(int vtype, const void* filtered, const void* weights, int wtype, float* rms, int H, int W, const NoiseGrid& g,
-              void* cellStats, size_t cellStatsBytes, hipStream_t s);
+              void* cellStats, size_t cellStatsBytes, bool tablesValid, hipStream_t s);
 size_t noise_workspace_bytes(const NoiseGrid& g, int H, int W);
 size_t noise_smart_workspace_bytes();
 int noise_map_smart(int vtype, const void* filtered, const void* weights, int wtype, float* rms, long long n, int numBins,

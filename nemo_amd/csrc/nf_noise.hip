@@ -853,7 +853,16 @@ __device__ __forceinline__ void cell_range(const int* __restrict__ e, int ncell,
 // past the block re-read its first pixel and are discarded).
 // First sweep (k_noise_block_stats): valid count, sum v, sum v^2, weight ranges.
 template <typename VT, typename WT>
-__global__ void __launch_bounds__(64) k_noise_block_stats(const VT* __restrict__ v, const WT* __restrict__ wts, int W, BlockWs ws) {
+__global__ void __launch_bounds__(64) k_noise_block_stats(const VT* __restrict__ v, const WT* __restrict__ wts, int W, BlockWs ws,
+                                                         int reuse) {
+    // reuse: the workspace still holds the block tables of an earlier call with the same grid and weights (k_noise_breaks did
+    // not run: the call's counters are cleared here) and every block's weight range over all of its pixels (rec[10], rec[11]).
+    // The weights are then read only for a block that is valid in part.
+    if (reuse && blockIdx.x == 0 && threadIdx.x == 0) {
+        ws.hdr[2] = 0;
+        ws.hdr[3] = 0;
+        ws.hdr[4] = 0;
+    }
     int by, bx;
     if (!block_of_workgroup(ws, &by, &bx)) return;
     const int y0 = ws.breakY[by], y1 = ws.breakY[by + 1], x0 = ws.breakX[bx], x1 = ws.breakX[bx + 1];
@@ -877,7 +886,7 @@ __global__ void __launch_bounds__(64) k_noise_block_stats(const VT* __restrict__
             const bool in = (i0 + u) * 64 + lane < npx;
             const unsigned q = in ? base + (unsigned)rr * (unsigned)W + (unsigned)xx : base;
             tv[u] = v[q];
-            tw[u] = wts[q];
+            tw[u] = reuse ? (WT)0 : wts[q];
             rr += dr;
             xx += dx;
             if (xx >= bw) {
@@ -907,6 +916,35 @@ __global__ void __launch_bounds__(64) k_noise_block_stats(const VT* __restrict__
     sv = wave_total(sv);
     sv2 = wave_total(sv2);
     n = wave_total(n);
+    if (reuse) {
+        wminAll = rec[10];
+        wmaxAll = rec[11];
+        wmin = n > 0.0 ? wminAll : INFINITY;
+        wmax = n > 0.0 ? wmaxAll : -INFINITY;
+        if (n > 0.0 && n < (double)npx) {
+            // valid in part: the range over the valid pixels needs the weights after all (the map comes from the caches)
+            wmin = INFINITY;
+            wmax = -INFINITY;
+            rr = r0;
+            xx = c0;
+            for (int i = 0; i < iters; ++i) {
+                const bool in = i * 64 + lane < npx;
+                const unsigned q = in ? base + (unsigned)rr * (unsigned)W + (unsigned)xx : base;
+                const double t = in ? (double)v[q] : 0.0;
+                const double wv = (double)wts[q];
+                if (t != 0.0) {
+                    wmin = fmin(wmin, wv);
+                    wmax = fmax(wmax, wv);
+                }
+                rr += dr;
+                xx += dx;
+                if (xx >= bw) {
+                    xx -= bw;
+                    rr += 1;
+                }
+            }
+        }
+    }
     for (int off = 32; off > 0; off >>= 1) {
         wmin = fmin(wmin, __shfl_xor(wmin, off, 64));
         wmax = fmax(wmax, __shfl_xor(wmax, off, 64));
@@ -1212,6 +1250,7 @@ __global__ void __launch_bounds__(64 * NF_CLS_WAVES) k_noise_block_classes(Block
 
 // ---- k_noise_windows: ONE WAVEFRONT per cell (no barriers; reductions on the vector ALU) ----
 #define NF_WIN_MAXBLK 64      // blocks of a window whose records are staged in LDS (more: everything from global memory)
+#define NF_WIN_HREG 4         // heavy blocks of a window whose class tables are held in registers (16 lanes each)
 #define NF_WIN_MAXTAIL 1536   // tail values of a window held in LDS
 
 // one block scanned pixel by pixel (its T exceeds the threshold of this iteration): flat over the block, 4 loads per lane
@@ -1277,6 +1316,12 @@ struct WinState {
     // lane = block: the block record (core threshold, core count/mean/sums about the mean; all valid pixels: count, sums
     // about v0) - registers, not LDS, which keeps ten windows resident per CU
     double T, nc, mu, S1, S2, nAll, v0, A1, A2;
+    // the magnitude classes of the window's first NF_WIN_HREG heavy blocks: lane = 16 * (rank of the heavy block in the window)
+    // + class (count, sum v, sum v^2, offset inside the block's class-ordered list, class bounds, block); hB < 0: nothing here.
+    // hRest: the heavy blocks beyond those (bit = block), whose tables are read from global memory in every iteration.
+    double hCn, hC1, hC2, hLo, hHi;
+    int hOff, hB;
+    unsigned long long hRest;
     int nW;
     double thrW;
     bool complete;
@@ -1377,9 +1422,55 @@ __device__ __forceinline__ void window_sums(const VT* __restrict__ v, int W, con
             __syncthreads();
         }
         if (thr != INFINITY) {
-            // heavy blocks in core mode: lane c takes magnitude class c - whole classes below thr from their sums, the one
-            // class that straddles thr element by element (by the whole wavefront)
-            unsigned long long hm = __ballot(core && L.heavy[lane < nblk ? lane : 0] >= 0);
+            // heavy blocks in core mode: whole magnitude classes below thr from their sums, the one class that straddles thr
+            // element by element.  The first NF_WIN_HREG heavy blocks of the window have their class tables in registers (no
+            // load per iteration), and their straddling classes are read as ONE flattened list (independent loads).
+            {
+                const bool hv = st.hB >= 0 && ((coreMask >> (st.hB & 63)) & 1ULL) && st.hCn > 0.0;
+                if (hv && st.hHi <= thr) {
+                    const double cn = st.hCn, c1 = st.hC1, c2 = st.hC2;
+                    s += c1 - cn * c0;
+                    ss += c2 - 2.0 * c0 * c1 + cn * c0 * c0;
+                    nn += cn;
+                }
+                const unsigned long long pm = __ballot(hv && st.hLo < thr && thr < st.hHi);
+                if (pm) {
+                    int cntS[NF_WIN_HREG];
+                    const double* ptrS[NF_WIN_HREG];
+#pragma unroll
+                    for (int h = 0; h < NF_WIN_HREG; ++h) {
+                        const unsigned long long ph = pm & (0xFFFFULL << (16 * h));
+                        cntS[h] = 0;
+                        ptrS[h] = ws.tails2;
+                        if (ph) {
+                            const int srcLane = __ffsll((long long)ph) - 1;
+                            cntS[h] = __shfl((int)st.hCn, srcLane, 64);
+                            ptrS[h] = ws.tails2 + L.tailOff[__shfl(st.hB, srcLane, 64)] + __shfl(st.hOff, srcLane, 64);
+                        }
+                    }
+                    const int e1 = cntS[0], e2 = e1 + cntS[1], e3 = e2 + cntS[2], E = e3 + cntS[3];
+                    for (int e0 = 0; e0 < E; e0 += 512) {
+                        double tv[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int e = e0 + u * 64 + lane;
+                            const double* p = e < e1 ? ptrS[0] + e : (e < e2 ? ptrS[1] + (e - e1) : (e < e3 ? ptrS[2] + (e - e2) : ptrS[3] + (e - e3)));
+                            tv[u] = *(e < E ? p : ws.tails2);
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int e = e0 + u * 64 + lane;
+                            if (e < E && fabs(tv[u]) < thr) {
+                                const double d = tv[u] - c0;
+                                s += d;
+                                ss += d * d;
+                                nn += 1.0;
+                            }
+                        }
+                    }
+                }
+            }
+            unsigned long long hm = __ballot(core && L.heavy[lane < nblk ? lane : 0] >= 0) & st.hRest;
             while (hm) {
                 const int b = __ffsll((long long)hm) - 1;
                 hm &= hm - 1;
@@ -1549,7 +1640,7 @@ __global__ void __launch_bounds__(64) k_noise_windows(const VT* __restrict__ v, 
         WinState st;
         st.T = st.mu = st.S1 = st.S2 = st.nAll = st.A1 = st.A2 = st.v0 = 0.0;
         st.nc = -1.0;
-        int tc = 0;
+        int tc = 0, slotR = -1;
         if (lane < nblk) {
             const int byo = lane / nbx;
             const double* __restrict__ rb = ws.rec + ((long long)(BY0 + byo) * ws.maxBx + BX0 + (lane - byo * nbx)) * NF_BREC;
@@ -1561,6 +1652,7 @@ __global__ void __launch_bounds__(64) k_noise_windows(const VT* __restrict__ v, 
             st.S2 = rb[7];
             tc = live ? (int)rb[8] : 0;
             const int slot = live ? (int)rb[15] : -1;
+            slotR = slot;
             L.heavy[lane] = slot;
             if (slot >= 0) tc = 0;           // a heavy block's tails are served from its class table, not from the LDS set
             L.tailOff[lane] = (long long)rb[9];
@@ -1576,6 +1668,34 @@ __global__ void __launch_bounds__(64) k_noise_windows(const VT* __restrict__ v, 
             if (lane >= off) incl += up;
         }
         if (lane < nblk) L.tailBase[lane] = incl - tc;
+        {
+            // class tables of the first heavy blocks into registers, 16 lanes per block
+            unsigned long long rest = __ballot(slotR >= 0);
+            st.hB = -1;
+            st.hOff = 0;
+            st.hCn = st.hC1 = st.hC2 = 0.0;
+            st.hLo = st.hHi = INFINITY;
+#pragma unroll
+            for (int h = 0; h < NF_WIN_HREG; ++h) {
+                if (!rest) break;
+                const int b = __ffsll((long long)rest) - 1;
+                rest &= rest - 1;
+                const int slotB = __shfl(slotR, b, 64);
+                const double Tb = __shfl(st.T, b, 64);
+                if ((lane >> 4) == h) {
+                    const int c = lane & 15;
+                    const double* __restrict__ ce = ws.cls + ((long long)slotB * NF_NCLS + c) * 4;
+                    st.hCn = ce[0];
+                    st.hC1 = ce[1];
+                    st.hC2 = ce[2];
+                    st.hOff = (int)ce[3];
+                    st.hLo = cls_bound(Tb, c);
+                    st.hHi = c == NF_NCLS - 1 ? INFINITY : cls_bound(Tb, c + 1);
+                    st.hB = b;
+                }
+            }
+            st.hRest = rest;
+        }
         __syncthreads();
         // the block of flat tail index e by binary search in the prefix (LDS only), then the loads, all independent
         st.complete = tcSum <= NF_WIN_MAXTAIL;
@@ -1600,6 +1720,11 @@ __global__ void __launch_bounds__(64) k_noise_windows(const VT* __restrict__ v, 
         st.complete = false;
         st.nW = 0;
         st.thrW = 0.0;
+        st.hB = -1;
+        st.hOff = 0;
+        st.hCn = st.hC1 = st.hC2 = 0.0;
+        st.hLo = st.hHi = INFINITY;
+        st.hRest = 0;
         rms = window_clip<VT, false>(v, W, ws, L, st, BY0, BX0, nbx, nblk, 0);
     }
     if (lane == 0) {
@@ -1619,45 +1744,58 @@ k_noise_paint_blocks(const WT* __restrict__ wts, float* __restrict__ rmsMap, int
                      const double* __restrict__ stats) {
     __shared__ double cLo[NF_PAINT_MAXCAND], cHi[NF_PAINT_MAXCAND];
     __shared__ float cR[NF_PAINT_MAXCAND];
-    __shared__ int nCand, range[4], uniform;
+    __shared__ int nCand, range[4];
     int by, bx;
     if (!block_of_workgroup(ws, &by, &bx)) return;
     const int y0 = ws.breakY[by], y1 = ws.breakY[by + 1], x0 = ws.breakX[bx], x1 = ws.breakX[bx + 1];
     const int bw = x1 - x0, bh = y1 - y0, npx = bw * bh;
     const int tid = threadIdx.x;
-    if (tid == 0) {
+    // the first wavefront looks at the candidate cells side by side (lane = candidate, in overwrite order) and keeps the
+    // usable ones in that order: one round of loads instead of a chain of dependent ones
+    const double* __restrict__ rb = ws.rec + ((long long)by * ws.maxBx + bx) * NF_BREC;
+    const double wLoAll = rb[10], wHiAll = rb[11];
+    if (tid < 64) {
         int iLo, iHi, kLo, kHi;
         cell_range(g.yEdges, g.ny, g.overlap, y0, &iLo, &iHi);
         cell_range(g.xEdges, g.nx, g.overlap, x0, &kLo, &kHi);
+        const int nk = kHi - kLo + 1, ni = iHi - iLo + 1, ncand = (ni > 0 && nk > 0) ? ni * nk : 0;
         int n = 0;
-        bool overflow = false;
-        for (int i = iHi; i >= iLo; --i)
-            for (int k = kHi; k >= kLo; --k) {
-                const double* rec = stats + (long long)(i * g.nx + k) * cell_stride(1);
-                if (rec[0] == 0.0 || !(rec[3] > 0.0)) continue;
-                if (n < NF_PAINT_MAXCAND) {
-                    cLo[n] = rec[1];
-                    cHi[n] = rec[2];
-                    cR[n] = (float)rec[3];
-                    ++n;
-                } else {
-                    overflow = true;
-                }
+        for (int c0 = 0; c0 < ncand; c0 += 64) {
+            const int c = c0 + tid;
+            bool ok = false;
+            double lo = 0.0, hi = 0.0, r = 0.0;
+            if (c < ncand) {
+                const int ci = c / nk;
+                const double* rec = stats + (long long)((iHi - ci) * g.nx + kHi - (c - ci * nk)) * cell_stride(1);
+                const double act = rec[0];
+                lo = rec[1];
+                hi = rec[2];
+                r = rec[3];
+                ok = act != 0.0 && r > 0.0;
             }
-        nCand = overflow ? -1 : n;
-        // every weight of the block inside the first candidate's range: one value for the whole block, weights not read
-        const double* rb = ws.rec + ((long long)by * ws.maxBx + bx) * NF_BREC;
-        uniform = (!overflow && n >= 1 && rb[10] >= cLo[0] && rb[11] < cHi[0]) ? 1 : 0;
-        range[0] = iLo;
-        range[1] = iHi;
-        range[2] = kLo;
-        range[3] = kHi;
+            const unsigned long long m = __ballot(ok);
+            const int pos = n + __popcll(m & ((1ULL << tid) - 1ULL));
+            if (ok && pos < NF_PAINT_MAXCAND) {
+                cLo[pos] = lo;
+                cHi[pos] = hi;
+                cR[pos] = (float)r;
+            }
+            n += __popcll(m);
+        }
+        if (tid == 0) {
+            nCand = n > NF_PAINT_MAXCAND ? -1 : n;
+            range[0] = iLo;
+            range[1] = iHi;
+            range[2] = kLo;
+            range[3] = kHi;
+        }
     }
     __syncthreads();
+    // every weight of the block inside the first candidate's range: one value for the whole block, weights not read
     const int nc = nCand;
     int rr = tid / bw, xx = tid - rr * bw;
     const int dr = NF_BLK_THREADS / bw, dx = NF_BLK_THREADS - dr * bw;
-    const bool uni = uniform != 0;
+    const bool uni = nc >= 1 && wLoAll >= cLo[0] && wHiAll < cHi[0];
     const float uniVal = uni ? cR[0] : 0.0f;
     for (int p = tid; p < npx; p += NF_BLK_THREADS) {
         const long long q = (long long)(y0 + rr) * W + x0 + xx;
@@ -1822,7 +1960,7 @@ size_t noise_workspace_bytes(const NoiseGrid& g, int H, int W) {
 }
 
 int noise_map(int vtype, const void* filtered, const void* weights, int wtype, float* rms, int H, int W, const NoiseGrid& g,
-              void* cellStats, size_t cellStatsBytes, hipStream_t s) {
+              void* cellStats, size_t cellStatsBytes, bool tablesValid, hipStream_t s) {
     if (g.numBins < 1 || g.numBins > NF_MAXBINS) {
         nf_set_error("noise_map: numNoiseBins must be in 1..16");
         return NF_ERR_ARG;
@@ -1861,12 +1999,15 @@ int noise_map(int vtype, const void* filtered, const void* weights, int wtype, f
             nf_set_error("noise_map: map too large for the 32-bit pixel offsets of the block kernels");
             return NF_ERR_SIZE;
         }
-        hipLaunchKernelGGL(k_noise_breaks, dim3(1), dim3(256), 0, s, g, H, W, ws);
-        NF_CHECK_LAUNCH("k_noise_breaks");
+        const int reuse = tablesValid ? 1 : 0;
+        if (!reuse) {
+            hipLaunchKernelGGL(k_noise_breaks, dim3(1), dim3(256), 0, s, g, H, W, ws);
+            NF_CHECK_LAUNCH("k_noise_breaks");
+        }
         dim3 gb(blocks_grid(ws)), gw(g.ny * g.nx);
 #define NF_NB(VT, WT)                                                                                                      \
     do {                                                                                                                   \
-        hipLaunchKernelGGL((k_noise_block_stats<VT, WT>), gb, dim3(64), 0, s, (const VT*)filtered, (const WT*)weights, W, ws); \
+        hipLaunchKernelGGL((k_noise_block_stats<VT, WT>), gb, dim3(64), 0, s, (const VT*)filtered, (const WT*)weights, W, ws, reuse); \
         hipLaunchKernelGGL(k_noise_window_rms0, gw, dim3(64), 0, s, g, ws, stats);                                         \
         hipLaunchKernelGGL((k_noise_block_core<VT>), gb, dim3(64), 0, s, (const VT*)filtered, W, g, ws, stats);            \
         hipLaunchKernelGGL(k_noise_block_classes, dim3(512), dim3(64 * NF_CLS_WAVES), 0, s, ws);                                    \

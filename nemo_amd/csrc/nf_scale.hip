@@ -122,7 +122,7 @@ int lanes_for(int nLanes, Lanes** out) {
     } while (0)
 
 // the sequence for one scale on one stream
-int run_scale(nf_plan* plan, const nf_mf_tile& t, const nf_mf_scale& sc, const Layout& L, char* ws, hipStream_t st) {
+int run_scale(nf_plan* plan, const nf_mf_tile& t, const nf_mf_scale& sc, const Layout& L, char* ws, bool noiseTablesValid, hipStream_t st) {
     const int H = t.H, W = t.W, N = t.N;
     const long long npix = (long long)H * W;
     const bool yc = t.outputUnits == 0;
@@ -184,7 +184,7 @@ int run_scale(nf_plan* plan, const nf_mf_tile& t, const nf_mf_scale& sc, const L
     NF_TRY(nf_fft2_inverse_half_epi(plan, t.prec, t.fMaps_d, filtSym, N, nullptr, nullptr, work, pre, outType, 0, sc.signalNorm_d,
                                     t.psMask_d, nullptr, S));
     NF_TRY(nf_noise_map(outPrec, pre, t.medWeights_d, t.wtype, rms0, H, W, t.ny, t.nx, t.yEdges_d, t.xEdges_d, t.overlap, t.numBins,
-                        t.quantiles, t.estimator, ws + L.noise, L.noiseBytes, S));
+                        t.quantiles, t.estimator, ws + L.noise, L.noiseBytes, noiseTablesValid ? 1 : 0, S));
     unsigned char* edge = nullptr;
     if (t.trimSizePix > 0) {
         edge = (unsigned char*)(ws + L.edgeOut);
@@ -245,7 +245,9 @@ int nf_matched_filter_scales(nf_plan* plan, const nf_mf_tile* tile, const nf_mf_
     int rc = NF_OK;
     for (int k = 0; k < nScales && rc == NF_OK; ++k) {
         const int l = k % nLanes;
-        rc = run_scale(plan, *tile, scales[k], L, (char*)work_d[l], l == 0 ? mainStream : lanes->streams[l - 1]);
+        // the noise block tables of a lane's workspace: valid after the lane's first scale, or when the caller says so
+        const bool tables = k >= nLanes || (l < 32 && ((tile->noiseTablesLanes >> l) & 1u));
+        rc = run_scale(plan, *tile, scales[k], L, (char*)work_d[l], tables, l == 0 ? mainStream : lanes->streams[l - 1]);
     }
     // join whatever was enqueued, also after an error: the caller's stream must not run ahead of the lanes
     for (int l = 1; l < nLanes; ++l) {

@@ -220,6 +220,7 @@ class TileEngine(object):
         self._geom2 = {}
         self.statsCap = 2048        # room (labels) of the record table of label_and_stats; grows when a map has more
         self._scaleWork = {}        # workspace bytes -> per-lane buffers of nf_matched_filter_scales
+        self._scaleWorkKeys = []    # per lane: the noiseKey its workspace's noise block tables belong to
 
     # ---- tables --------------------------------------------------------------------------------------------
     def window(self, pow):
@@ -532,10 +533,11 @@ class TileEngine(object):
         check(self.lib.nf_signal_norm(0 if outputUnits == 'yc' else 1, ptr(src), float(y0), ptr(out), stream_ptr()), "nf_signal_norm")
         return DeviceScalar(out, wide=outputUnits == 'yc')
 
-    def matched_filter_scales(self, tile, scales, lanes):
+    def matched_filter_scales(self, tile, scales, lanes, noiseKey=None):
         """nf_matched_filter_scales: ``tile`` an _lib.MfTile, ``scales`` a ctypes array of _lib.MfScale.  The lanes' workspaces
         are kept by the engine (one set per size) and reused call after call: calls are ordered by the stream they are made
-        on."""
+        on.  ``noiseKey`` (hashable, or None) stands for the tile's median weights and noise grid: a lane whose workspace was
+        last used under an equal key keeps its noise block tables (``noiseTablesLanes`` of the tile struct)."""
         t = self.t
         n = len(scales)
         lanes = max(1, min(int(lanes), n))
@@ -545,10 +547,17 @@ class TileEngine(object):
         work = self._scaleWork.get(nbytes, [])
         while len(work) < lanes:
             work.append(t.empty(nbytes, dtype=t.uint8, device=self.dev))
+        if nbytes not in self._scaleWork:
+            self._scaleWorkKeys = []
         self._scaleWork = {nbytes: work}          # one size at a time: another configuration of the same shape replaces it
+        keys = self._scaleWorkKeys
+        keys.extend([None] * (len(work) - len(keys)))
+        tile.noiseTablesLanes = sum(1 << l for l in range(min(lanes, 32)) if noiseKey is not None and keys[l] == noiseKey)
+        keys[:lanes] = [None] * lanes             # (an error below leaves the lanes' tables in an unknown state)
         ptrs = (ctypes.c_void_p * lanes)(*[w.data_ptr() for w in work[:lanes]])
         check(self.lib.nf_matched_filter_scales(self.plan, ctypes.byref(tile), scales, n, ptrs, lanes, stream_ptr()),
               "nf_matched_filter_scales")
+        keys[:lanes] = [noiseKey] * lanes
 
     # ---- real-space tail -----------------------------------------------------------------------------------
     def scale_mask(self, m32, signalNorm, psMask):
@@ -603,8 +612,9 @@ class TileEngine(object):
         yE, xE = self._geom2[key]
         return ncy, ncx, yE, xE, overlap, nb, quant, 1 if noiseParams.get('RMSEstimator', None) == 'percentile' else 0
 
-    def noise_map(self, filtered, medWeights, noiseParams, pixSizeDeg):
-        """MapFilter.makeNoiseMap, grid mode (nemo/filters.py:407-478)."""
+    def noise_map(self, filtered, medWeights, noiseParams, pixSizeDeg, work=None, tablesValid=False):
+        """MapFilter.makeNoiseMap, grid mode (nemo/filters.py:407-478).  ``work`` / ``tablesValid``: the workspace of an earlier
+        call for the same grid and weights (``self._lastNoiseWork[0]``), whose block tables are then reused (nf_noise_map)."""
         t = self.t
         estimator = noiseParams.get('RMSEstimator', None)
         if estimator not in (None, 'percentile'):
@@ -632,10 +642,11 @@ class TileEngine(object):
             return rms
         ncy, ncx, yE, xE, overlap, nb, quant, est = grid
         wbytes = self.lib.nf_noise_workspace_bytes(self.H, self.W, ncy, ncx, nb)
-        work = t.empty(wbytes // 8 + 1, dtype=t.float64, device=self.dev)
+        if work is None or work.numel() < wbytes // 8 + 1:
+            work, tablesValid = t.empty(wbytes // 8 + 1, dtype=t.float64, device=self.dev), False
         check(self.lib.nf_noise_map(prec_of(filtered), ptr(filtered), ptr(medWeights), prec_of(medWeights), ptr(rms),
                                     self.H, self.W, ncy, ncx, ptr(yE), ptr(xE), overlap, nb, quant, est, ptr(work),
-                                    work.numel() * 8, stream_ptr()), "nf_noise_map")
+                                    work.numel() * 8, 1 if tablesValid else 0, stream_ptr()), "nf_noise_map")
         self._lastNoiseWork = (work, ncy, ncx, nb)       # diagnostics (tools/noisedbg.py)
         return rms
 

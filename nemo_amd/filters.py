@@ -622,7 +622,11 @@ class MatchedFilter(MapFilter):
             sc.rms_d = rms.data_ptr() + g * H * W * 4
             sc.mask_d = mask.data_ptr() + g * H * W
             sc.snChunkRange_d = snChunks.data_ptr() + g * nch * 8
-        eng.matched_filter_scales(tile, scales, lanes)
+        # the noise block tables a lane's workspace holds stay good for this tile's weights and grid (one token per tile cache)
+        noiseKey = None
+        if first._shared is not None:
+            noiseKey = (first._shared.setdefault('noiseTablesToken', object()), H, W, ncy, ncx, overlap, nb, est)
+        eng.matched_filter_scales(tile, scales, lanes, noiseKey=noiseKey)
         del keep
         _scaleEntryStats['calls'] += 1
         _scaleEntryStats['scales'] += G

@@ -337,6 +337,40 @@ def test_noise_map_heavy_tails(vdtype):
 
 
 @pytest.mark.parametrize("vdtype", [np.float64, np.float32])
+def test_noise_map_with_kept_block_tables(vdtype):
+    """tablesValid of nf_noise_map: a workspace that was last used with the same grid and weights keeps its block tables; the
+    next map (other values, other holes, heavy blocks) gets bit for bit the noise map of a fresh call."""
+    shape = (420, 530)
+    rng = np.random.default_rng(78)
+    yy, xx = np.mgrid[0:shape[0], 0:shape[1]]
+    w = (1.0 + 0.2 * np.sin(xx / 40.0) * np.cos(yy / 55.0)).astype(vdtype)
+    w[200:260, 100:180] *= 3.0                      # blocks whose weights leave their windows' ranges (painted pixel by pixel)
+    maps = []
+    for k in range(3):
+        m = rng.standard_normal(shape) * (1.0 + k)
+        if k == 1:
+            m += 300.0 * np.exp(-0.5 * ((yy - 150) ** 2 + (xx - 300) ** 2) / 11.0 ** 2)
+            m[90:130, 400:470] = 0                   # a hole the first map did not have: blocks valid in part, blocks empty
+            m[rng.uniform(size=shape) > 0.9995] = 0
+        if k == 2:
+            m[:, :37] = 0
+        maps.append(engine.to_dev(m.astype(vdtype)))
+    eng = _eng(shape)
+    dw = engine.to_dev(w)
+    pix = 0.5 / 60.0
+    for grid in (40.0, 20.0):
+        params = {'noiseGridArcmin': grid, 'numNoiseBins': 1}
+        fresh = [_np(eng.noise_map(m, dw, params, pix)) for m in maps]
+        work = None
+        for k, m in enumerate(maps):
+            got = _np(eng.noise_map(m, dw, params, pix, work=work, tablesValid=work is not None))
+            work = eng._lastNoiseWork[0]
+            assert np.array_equal(got, fresh[k])
+        ref = ofilt.make_noise_map(_np(maps[1]), [w], params, pix)
+        assert np.array_equal(fresh[1] > 0, ref > 0) and np.abs(fresh[1] - ref).max() <= 1.2e-7 * ref.max()
+
+
+@pytest.mark.parametrize("vdtype", [np.float64, np.float32])
 def test_edge_check_and_finalize(vdtype):
     shape = (129, 86)
     rng = np.random.default_rng(31)

@@ -8,7 +8,7 @@ from nemo_amd import engine, pipelines
 
 shape = (4096, 4096)
 mapsL, wcs, truth = bench.make_workload(shape, 1, 'f64')
-config = bench.make_config(mapsL, int(sys.argv[1]) if len(sys.argv) > 1 else 4)
+config = bench.make_config(mapsL, int(sys.argv[1]) if len(sys.argv) > 1 else 15)
 eng = engine.TileEngine.get(shape)
 orig = eng.noise_map
 

@@ -489,8 +489,9 @@ int nf_noise_map(int vtype, const void* filtered, const void* weights, int wtype
     g.yEdges = yEdges;
     g.xEdges = xEdges;
     for (int i = 0; i < numBins && quantiles; ++i) g.quantiles[i] = quantiles[i];
+    // algorithmic bytes: the map in, the noise map out, and the weights unless the kept tables stand for them
     nf::ProfScope ps(nf::PT_NOISE_MAP, S(stream),
-                     (double)H * W * ((vtype == NF_F32 ? 4.0 : 8.0) + (wtype == NF_F32 ? 4.0 : 8.0) + 4.0));
+                     (double)H * W * ((vtype == NF_F32 ? 4.0 : 8.0) + (tablesValid ? 0.0 : (wtype == NF_F32 ? 4.0 : 8.0)) + 4.0));
     return nf::noise_map(vtype, filtered, weights, wtype, rms, H, W, g, work, workBytes, tablesValid != 0, S(stream));
 }
 

@@ -1322,6 +1322,10 @@ struct WinState {
     double hCn, hC1, hC2, hLo, hHi;
     int hOff, hB;
     unsigned long long hRest;
+    // the straddling classes last read (hKey = their lanes, 0 = none) lie in LDS behind the working set, hE values: the
+    // threshold moves little from one iteration to the next, so the same classes straddle it again
+    unsigned long long hKey;
+    int hE;
     int nW;
     double thrW;
     bool complete;
@@ -1419,6 +1423,7 @@ __device__ __forceinline__ void window_sums(const VT* __restrict__ v, int W, con
             st.complete = fits;
             st.nW = fits ? nW : 0;
             st.thrW = thr;
+            st.hKey = 0ULL;            // (the classes kept behind the old working set are gone)
             __syncthreads();
         }
         if (thr != INFINITY) {
@@ -1434,7 +1439,18 @@ __device__ __forceinline__ void window_sums(const VT* __restrict__ v, int W, con
                     nn += cn;
                 }
                 const unsigned long long pm = __ballot(hv && st.hLo < thr && thr < st.hHi);
-                if (pm) {
+                if (pm && st.complete && pm == st.hKey) {
+#pragma unroll 4
+                    for (int e = lane; e < st.hE; e += 64) {
+                        const double t = L.tail[st.nW + e];
+                        if (fabs(t) < thr) {
+                            const double d = t - c0;
+                            s += d;
+                            ss += d * d;
+                            nn += 1.0;
+                        }
+                    }
+                } else if (pm) {
                     int cntS[NF_WIN_HREG];
                     const double* ptrS[NF_WIN_HREG];
 #pragma unroll
@@ -1449,6 +1465,7 @@ __device__ __forceinline__ void window_sums(const VT* __restrict__ v, int W, con
                         }
                     }
                     const int e1 = cntS[0], e2 = e1 + cntS[1], e3 = e2 + cntS[2], E = e3 + cntS[3];
+                    const bool keep = st.complete && E <= NF_WIN_MAXTAIL - st.nW;
                     for (int e0 = 0; e0 < E; e0 += 512) {
                         double tv[8];
 #pragma unroll
@@ -1460,6 +1477,7 @@ __device__ __forceinline__ void window_sums(const VT* __restrict__ v, int W, con
 #pragma unroll
                         for (int u = 0; u < 8; ++u) {
                             const int e = e0 + u * 64 + lane;
+                            if (keep && e < E) L.tail[st.nW + e] = tv[u];
                             if (e < E && fabs(tv[u]) < thr) {
                                 const double d = tv[u] - c0;
                                 s += d;
@@ -1468,6 +1486,9 @@ __device__ __forceinline__ void window_sums(const VT* __restrict__ v, int W, con
                             }
                         }
                     }
+                    st.hKey = keep ? pm : 0ULL;
+                    st.hE = E;
+                    __syncthreads();
                 }
             }
             unsigned long long hm = __ballot(core && L.heavy[lane < nblk ? lane : 0] >= 0) & st.hRest;
@@ -1695,6 +1716,8 @@ __global__ void __launch_bounds__(64) k_noise_windows(const VT* __restrict__ v, 
                 }
             }
             st.hRest = rest;
+            st.hKey = 0ULL;
+            st.hE = 0;
         }
         __syncthreads();
         // the block of flat tail index e by binary search in the prefix (LDS only), then the loads, all independent
@@ -1725,6 +1748,8 @@ __global__ void __launch_bounds__(64) k_noise_windows(const VT* __restrict__ v, 
         st.hCn = st.hC1 = st.hC2 = 0.0;
         st.hLo = st.hHi = INFINITY;
         st.hRest = 0;
+        st.hKey = 0ULL;
+        st.hE = 0;
         rms = window_clip<VT, false>(v, W, ws, L, st, BY0, BX0, nbx, nblk, 0);
     }
     if (lane == 0) {
@@ -1857,6 +1882,109 @@ __device__ __forceinline__ void cell_range(const int* __restrict__ e, int ncell,
     }
     *lo = l;
     *hi = h;
+}
+
+// Paint by rows: one workgroup per (block row, group of NF_PR_ROWS rows).  Per block of the row, the value every pixel takes when
+// all of the block's weights lie inside the range of its last-writing usable cell (the common case: weights are then not
+// read) - found once, lane = block; the rows then leave as whole lines, 16 bytes per lane.  A block whose weights straddle a
+// range boundary is painted pixel by pixel like k_noise_paint does it.
+#define NF_PR_ROWS 8
+#define NF_PR_MAXBX 1024
+template <typename WT>
+__device__ float paint_pixel(const WT* __restrict__ wts, long long q, const NoiseGrid& g, const double* __restrict__ stats, int iLo,
+                             int iHi, int kLo, int kHi) {
+    const double wv = (double)wts[q];
+    for (int i = iHi; i >= iLo; --i)
+        for (int k = kHi; k >= kLo; --k) {
+            const double* rec = stats + (long long)(i * g.nx + k) * cell_stride(1);
+            if (rec[0] == 0.0) continue;
+            if (wv >= rec[1] && wv < rec[2] && rec[3] > 0.0) return (float)rec[3];
+        }
+    return 0.0f;
+}
+
+template <typename WT>
+__global__ void __launch_bounds__(256)
+k_noise_paint_rows(const WT* __restrict__ wts, float* __restrict__ rmsMap, int W, NoiseGrid g, BlockWs ws,
+                   const double* __restrict__ stats) {
+    __shared__ int bX[NF_PR_MAXBX + 1];
+    __shared__ float val[NF_PR_MAXBX];
+    __shared__ unsigned char uni[NF_PR_MAXBX];
+    const int nby = ws.hdr[0] - 1, nbx = ws.hdr[1] - 1;
+    const int by = blockIdx.y;
+    if (by >= nby || nbx < 1) return;
+    const int y0 = ws.breakY[by], y1 = ws.breakY[by + 1];
+    const int ya = y0 + (int)blockIdx.x * NF_PR_ROWS, yb = min(ya + NF_PR_ROWS, y1);
+    if (ya >= y1) return;
+    const int tid = threadIdx.x;
+    int iLo, iHi;
+    cell_range(g.yEdges, g.ny, g.overlap, y0, &iLo, &iHi);
+    for (int bx = tid; bx <= nbx; bx += 256) bX[bx] = ws.breakX[bx];
+    for (int bx = tid; bx < nbx; bx += 256) {
+        int kLo, kHi;
+        cell_range(g.xEdges, g.nx, g.overlap, ws.breakX[bx], &kLo, &kHi);
+        // the last writer among the usable cells (nemo/filters.py:470-478 overwrites in (i, k) order)
+        bool found = false;
+        double lo = 0.0, hi = 0.0, r = 0.0;
+        for (int i = iHi; i >= iLo && !found; --i)
+            for (int k = kHi; k >= kLo && !found; --k) {
+                const double* rec = stats + (long long)(i * g.nx + k) * cell_stride(1);
+                if (rec[0] == 0.0 || !(rec[3] > 0.0)) continue;
+                lo = rec[1];
+                hi = rec[2];
+                r = rec[3];
+                found = true;
+            }
+        const double* rb = ws.rec + ((long long)by * ws.maxBx + bx) * NF_BREC;
+        const bool u = !found || (rb[10] >= lo && rb[11] < hi);
+        uni[bx] = u ? 1 : 0;
+        val[bx] = found ? (float)r : 0.0f;
+    }
+    __syncthreads();
+    const int x0 = bX[0], xEnd = bX[nbx];          // (the blocks cover the whole map: 0 .. W)
+    for (int xa = x0 + tid * 4; xa < xEnd; xa += 1024) {
+        // block of xa, then forward through the boundaries for the next three pixels
+        int lo = 0, hi = nbx - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (bX[mid] <= xa) lo = mid; else hi = mid - 1;
+        }
+        int bxs[4];
+        bool allUni = true;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            while (lo < nbx - 1 && bX[lo + 1] <= xa + j) ++lo;
+            bxs[j] = lo;
+            allUni = allUni && uni[lo] != 0;
+        }
+        const bool vec = allUni && xa + 3 < xEnd && (W & 3) == 0 && (x0 & 3) == 0 && ((size_t)rmsMap & 15) == 0;
+        if (vec) {
+            float4 o;
+            o.x = val[bxs[0]];
+            o.y = val[bxs[1]];
+            o.z = val[bxs[2]];
+            o.w = val[bxs[3]];
+            for (int y = ya; y < yb; ++y) *(float4*)(rmsMap + (long long)y * W + xa) = o;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int x = xa + j;
+                if (x >= xEnd) break;
+                const int bx = bxs[j];
+                if (uni[bx]) {
+                    const float o = val[bx];
+                    for (int y = ya; y < yb; ++y) rmsMap[(long long)y * W + x] = o;
+                } else {
+                    int kLo, kHi;
+                    cell_range(g.xEdges, g.nx, g.overlap, bX[bx], &kLo, &kHi);
+                    for (int y = ya; y < yb; ++y) {
+                        const long long q = (long long)y * W + x;
+                        rmsMap[q] = paint_pixel<WT>(wts, q, g, stats, iLo, iHi, kLo, kHi);
+                    }
+                }
+            }
+        }
+    }
 }
 
 template <typename WT>
@@ -2019,11 +2147,18 @@ int noise_map(int vtype, const void* filtered, const void* weights, int wtype, f
         else NF_NB(float, float);
 #undef NF_NB
         NF_CHECK_LAUNCH("k_noise_blocks / k_noise_windows");
-        if (wtype == NF_F64)
+        static const bool paintRows = env_flag_default_on("NF_NOISE_PAINT_ROWS");
+        if (paintRows && ws.maxBx <= NF_PR_MAXBX) {
+            dim3 gr((NF_BLK + NF_PR_ROWS - 1) / NF_PR_ROWS, ws.maxBy - 1);
+            if (wtype == NF_F64)
+                hipLaunchKernelGGL(k_noise_paint_rows<double>, gr, dim3(256), 0, s, (const double*)weights, rms, W, g, ws, stats);
+            else
+                hipLaunchKernelGGL(k_noise_paint_rows<float>, gr, dim3(256), 0, s, (const float*)weights, rms, W, g, ws, stats);
+        } else if (wtype == NF_F64)
             hipLaunchKernelGGL(k_noise_paint_blocks<double>, gb, dim3(NF_BLK_THREADS), 0, s, (const double*)weights, rms, W, g, ws, stats);
         else
             hipLaunchKernelGGL(k_noise_paint_blocks<float>, gb, dim3(NF_BLK_THREADS), 0, s, (const float*)weights, rms, W, g, ws, stats);
-        NF_CHECK_LAUNCH("k_noise_paint_blocks");
+        NF_CHECK_LAUNCH("k_noise_paint_blocks / k_noise_paint_rows");
         return NF_OK;
     }
     dim3 gc(g.ny * g.nx), bc(NF_NOISE_THREADS);

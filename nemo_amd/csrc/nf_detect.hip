@@ -43,7 +43,10 @@ __device__ __forceinline__ bool is_fg(const VT* sn, long long p, VT thr, int neg
 // the labels) touch the whole map.
 template <typename VT>
 __global__ void __launch_bounds__(256) k_ccl_init(const VT* __restrict__ sn, VT thr, int negate, int* __restrict__ parent,
-                                                  long long n, int* __restrict__ chunkFG, const unsigned long long* __restrict__ snRange) {
+                                                  long long n, int* __restrict__ chunkFG, const unsigned long long* __restrict__ snRange,
+                                                  unsigned long long* __restrict__ clear, long long clearWords) {
+    // (label_and_stats: the record table of the sums that follow is cleared here rather than by a fill of its own)
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < clearWords; i += (long long)gridDim.x * 256) clear[i] = 0ULL;
     if (snRange != nullptr) {
         // the chunk's largest / smallest S/N is known (nf_finalize wrote it): a chunk that cannot hold foreground is not read
         VT top = negate ? (VT)nf_key_value(snRange[gridDim.x + blockIdx.x]) * (VT)-1 : (VT)nf_key_value(snRange[blockIdx.x]);
@@ -133,57 +136,32 @@ __global__ void __launch_bounds__(256) k_ccl_flatten_count(int* __restrict__ par
     if (threadIdx.x == 0) blockCounts[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
-// exclusive scan of blockCounts (single workgroup: a run of consecutive entries per thread, then one scan over the
-// threads' sums); total written to blockCounts[nblocks]
-__global__ void __launch_bounds__(1024) k_scan_counts(int* __restrict__ blockCounts, int nblocks) {
-    __shared__ int waveTot[16];
-    const int per = (nblocks + 1023) / 1024, start = threadIdx.x * per;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int sum = 0;
-    int v16[16];                   // the usual case (up to 16 entries per thread: maps up to 16.8 Mpx) in one batch of loads
-    if (per <= 16) {
+// The roots of chunk b are numbered from 1 + (roots in the chunks before b), raster order.  Every chunk with foreground sums the
+// counts before it by itself (at most 64 KB of coalesced reads from the L2 - cheaper than a scan kernel between two launches);
+// the last workgroup also leaves the total in blockCounts[nblocks].
+__global__ void __launch_bounds__(256) k_number_roots(const int* __restrict__ parent, long long n, int* __restrict__ blockCounts,
+                                                      int nblocks, const int* __restrict__ chunkFG, int* __restrict__ labels) {
+    __shared__ int waveTot[4], redTot[4];
+    const bool fg = chunkFG[blockIdx.x] != 0, last = (int)blockIdx.x == nblocks - 1;
+    if (!fg && !last) return;
+    int before = 0;
+    {
+        int acc = 0;
+        const int upto = (int)blockIdx.x;
+        for (int i0 = threadIdx.x; i0 < upto; i0 += 256 * 8) {
+            int v[8];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) v16[i] = (i < per && start + i < nblocks) ? blockCounts[start + i] : 0;
+            for (int u = 0; u < 8; ++u) v[u] = i0 + u * 256 < upto ? blockCounts[i0 + u * 256] : 0;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) sum += v16[i];
-    } else {
-        for (int i = 0; i < per; ++i)
-            if (start + i < nblocks) sum += blockCounts[start + i];
+            for (int u = 0; u < 8; ++u) acc += v[u];
+        }
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+        if ((threadIdx.x & 63) == 0) redTot[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        before = redTot[0] + redTot[1] + redTot[2] + redTot[3];
+        if (last && threadIdx.x == 0) blockCounts[nblocks] = before + blockCounts[blockIdx.x];
     }
-    int incl = sum;
-    for (int off = 1; off < 64; off <<= 1) {
-        const int t = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += t;
-    }
-    if (lane == 63) waveTot[wave] = incl;
-    __syncthreads();
-    int run = incl - sum, total = 0;
-    for (int w = 0; w < 16; ++w) {
-        if (w < wave) run += waveTot[w];
-        total += waveTot[w];
-    }
-    if (per <= 16) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i)
-            if (i < per && start + i < nblocks) {
-                blockCounts[start + i] = run;
-                run += v16[i];
-            }
-    } else {
-        for (int i = 0; i < per; ++i)
-            if (start + i < nblocks) {
-                const int v = blockCounts[start + i];
-                blockCounts[start + i] = run;
-                run += v;
-            }
-    }
-    if (threadIdx.x == 0) blockCounts[nblocks] = total;
-}
-
-__global__ void __launch_bounds__(256) k_number_roots(const int* __restrict__ parent, long long n, const int* __restrict__ blockOffsets,
-                                                      const int* __restrict__ chunkFG, int* __restrict__ labels) {
-    __shared__ int waveTot[4];
-    if (!chunkFG[blockIdx.x]) return;
+    if (!fg) return;
     long long base = (long long)blockIdx.x * NF_SCAN_CHUNK;
     int flags[4], c = 0;
     for (int j = 0; j < 4; ++j) {
@@ -202,7 +180,7 @@ __global__ void __launch_bounds__(256) k_number_roots(const int* __restrict__ pa
     __syncthreads();
     int pre = incl - c;
     for (int w = 0; w < wave; ++w) pre += waveTot[w];
-    int id = blockOffsets[blockIdx.x] + pre;
+    int id = before + pre;
     for (int j = 0; j < 4; ++j) {
         long long p = base + threadIdx.x * 4 + j;
         if (p < n && flags[j]) labels[p] = ++id;   // ids start at 1
@@ -244,7 +222,8 @@ long long label_chunk_flags_offset(int H, int W) {
 }
 
 int label_components(int vtype, const void* sn, double threshold, int negate, int* labels, int H, int W, int* work,
-                     int* numObjects, int* dirty, hipStream_t s, const unsigned long long* snRange) {
+                     int* numObjects, int* dirty, hipStream_t s, const unsigned long long* snRange, unsigned long long* clear,
+                     long long clearWords) {
     const long long n = (long long)H * W;
     if (n >= 2147483647LL) {
         nf_set_error("label_components: map too large for 32-bit pixel indices");
@@ -256,13 +235,13 @@ int label_components(int vtype, const void* sn, double threshold, int negate, in
     int* chunkFG = blockCounts + nblocks + 1;    // nblocks
     dim3 g(nblocks), b(256);
     if (vtype == NF_F64)
-        hipLaunchKernelGGL(k_ccl_init<double>, g, b, 0, s, (const double*)sn, threshold, negate, parent, n, chunkFG, snRange);
+        hipLaunchKernelGGL(k_ccl_init<double>, g, b, 0, s, (const double*)sn, threshold, negate, parent, n, chunkFG, snRange, clear, clearWords);
     else  // a Python-float threshold compared against a float32 map is cast to float32 by numpy
-        hipLaunchKernelGGL(k_ccl_init<float>, g, b, 0, s, (const float*)sn, (float)threshold, negate, parent, n, chunkFG, snRange);
+        hipLaunchKernelGGL(k_ccl_init<float>, g, b, 0, s, (const float*)sn, (float)threshold, negate, parent, n, chunkFG, snRange, clear,
+                           clearWords);
     hipLaunchKernelGGL(k_ccl_merge, g, b, 0, s, parent, H, W, chunkFG);
     hipLaunchKernelGGL(k_ccl_flatten_count, g, b, 0, s, parent, n, chunkFG, blockCounts);
-    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, s, blockCounts, nblocks);
-    hipLaunchKernelGGL(k_number_roots, g, b, 0, s, parent, n, blockCounts, chunkFG, labels);
+    hipLaunchKernelGGL(k_number_roots, g, b, 0, s, parent, n, blockCounts, nblocks, chunkFG, labels);
     hipLaunchKernelGGL(k_relabel, g, b, 0, s, parent, labels, n, chunkFG, dirty);
     NF_CHECK_LAUNCH("label_components");
     if (numObjects != nullptr) {        // (NULL: the count stays on the device, work[n + nblocks] - label_and_stats)
@@ -370,7 +349,7 @@ __global__ void __launch_bounds__(256) k_object_argmax(const VT* __restrict__ sn
         if (id <= 0 || id > maxId) continue;
         double v = (double)sn[p];
         if (negate) v = -v;
-        if (ordered_key(v) == maxKey[id]) atomicMin(&argmax[id], (unsigned long long)p);
+        if (ordered_key(v) == maxKey[id]) atomicMax(&argmax[id], ~(unsigned long long)p);    // (inverted: 0 = none, the largest = the first pixel)
     }
 }
 
@@ -392,7 +371,7 @@ __global__ void k_stats_finish(double* __restrict__ stats, const unsigned long l
         unsigned long long k = maxKey[id];
         unsigned long long b = (k & 0x8000000000000000ULL) ? (k & 0x7FFFFFFFFFFFFFFFULL) : ~k;
         r[4] = __longlong_as_double((long long)b);
-        r[5] = (double)argmax[id];
+        r[5] = (double)~argmax[id];
         // label_and_stats: the number of labels found travels in the (otherwise empty) background record
         if (id == 0 && count != nullptr) r[0] = (double)count[0];
     }
@@ -401,14 +380,14 @@ __global__ void k_stats_finish(double* __restrict__ stats, const unsigned long l
 // `stats` must hold (numObjects+1) * 17 doubles: 6 per record, then scratch - the 9 integer limbs, the maximum key and the
 // argmax of every label
 int object_stats(int vtype, const void* sn, int negate, const int* labels, int H, int W, int numObjects, double* stats,
-                 const int* chunkFG, hipStream_t s, const int* count) {
+                 const int* chunkFG, hipStream_t s, const int* count, bool cleared) {
     const long long n = (long long)H * W;
     const size_t nrec = (size_t)numObjects + 1;
     unsigned long long* limbs = (unsigned long long*)(stats + nrec * NF_STAT_STRIDE);
     unsigned long long* maxKey = limbs + nrec * NF_LIMB_WORDS;
     unsigned long long* argmax = maxKey + nrec;
-    NF_HIP(hipMemsetAsync(stats, 0, nrec * (NF_STAT_STRIDE + NF_LIMB_WORDS + 1) * sizeof(double), s));
-    NF_HIP(hipMemsetAsync(argmax, 0xFF, nrec * sizeof(unsigned long long), s));
+    // records, limbs, maximum keys and (inverted) argmax all start at zero
+    if (!cleared) NF_HIP(hipMemsetAsync(stats, 0, nrec * (NF_STAT_STRIDE + NF_LIMB_WORDS + 2) * sizeof(double), s));
     dim3 g(nf_div_up(n, NF_SCAN_CHUNK)), b(256);
     if (vtype == NF_F64) {
         hipLaunchKernelGGL(k_object_sums<double>, g, b, 0, s, (const double*)sn, negate, labels, H, W, stats, limbs, maxKey, chunkFG, numObjects);
@@ -426,13 +405,15 @@ int object_stats(int vtype, const void* sn, int negate, const int* labels, int H
 // the number found stays on the device and comes back in stats[0] (the background record's count, otherwise unused).
 int label_and_stats(int vtype, const void* sn, double threshold, int negate, int* labels, int H, int W, int* work, int* dirty,
                     int maxObjects, double* stats, const unsigned long long* snRange, hipStream_t s) {
-    int rc = label_components(vtype, sn, threshold, negate, labels, H, W, work, nullptr, dirty, s, snRange);
+    const long long clearWords = ((long long)maxObjects + 1) * (NF_STAT_STRIDE + NF_LIMB_WORDS + 2);
+    int rc = label_components(vtype, sn, threshold, negate, labels, H, W, work, nullptr, dirty, s, snRange, (unsigned long long*)stats,
+                              clearWords);
     if (rc != NF_OK) return rc;
     const long long n = (long long)H * W;
     const int nblocks = nf_div_up(n, NF_SCAN_CHUNK);
     const int* count = work + n + nblocks;
     const int* chunkFG = work + n + nblocks + 1;
-    return object_stats(vtype, sn, negate, labels, H, W, maxObjects, stats, chunkFG, s, count);
+    return object_stats(vtype, sn, negate, labels, H, W, maxObjects, stats, chunkFG, s, count, true);
 }
 
 // ---------------------------------------------------------------------------------------------------

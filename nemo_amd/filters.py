@@ -371,6 +371,7 @@ class MapFilter(object):
         medWeights = self.engine.median_weights(self._dWeights)
         if self._shared is not None:
             self._shared['medWeights'] = medWeights
+            self._shared['noiseTablesToken'] = object()      # stands for these weights (nf_noise_map's kept block tables)
         return medWeights
 
     def _noiseMapDevice(self, dMap):
@@ -624,8 +625,8 @@ class MatchedFilter(MapFilter):
             sc.snChunkRange_d = snChunks.data_ptr() + g * nch * 8
         # the noise block tables a lane's workspace holds stay good for this tile's weights and grid (one token per tile cache)
         noiseKey = None
-        if first._shared is not None:
-            noiseKey = (first._shared.setdefault('noiseTablesToken', object()), H, W, ncy, ncx, overlap, nb, est)
+        if first._shared is not None and 'noiseTablesToken' in first._shared:
+            noiseKey = (first._shared['noiseTablesToken'], H, W, ncy, ncx, overlap, nb, est)
         eng.matched_filter_scales(tile, scales, lanes, noiseKey=noiseKey)
         del keep
         _scaleEntryStats['calls'] += 1

@@ -124,7 +124,8 @@ int nf_cross_power_half(int prec, const void* F_d, void* NP_d, int N, int H, int
 int nf_build_filter_half(int covType, int sigType, const void* cov_d, const void* S_d, const double* w, float* filt_d,
                          int N, int H, int W, void* stream);
 /* nf_build_filter_half and nf_symmetrise_filter in one pass: the same filter cube filt_d and the same symmetrised form
- * filtSym_d, bit for bit, without reading the cube back (a thread computes a mode and its mirror mode together). */
+ * filtSym_d, bit for bit, without reading the cube back (a thread computes a mode and its mirror mode together).  filt_d may
+ * be NULL: a caller that only applies the filter (and neither saves nor returns the cube) gets the symmetrised form alone. */
 int nf_build_filter_sym_half(int covType, int sigType, const void* cov_d, const void* S_d, const double* w, float* filt_d,
                              double* filtSym_d, int N, int H, int W, void* stream);
 
@@ -466,7 +467,7 @@ typedef struct nf_mf_scale {
     double r0[NF_MF_MAXFREQ], dlnr[NF_MF_MAXFREQ];
     double amp[NF_MF_MAXFREQ], sign[NF_MF_MAXFREQ], templateScale[NF_MF_MAXFREQ];
     /* outputs */
-    float* filt_d;                     /* [N][H][W] the filter */
+    float* filt_d;                     /* [N][H][W] the filter, or NULL: the cube is not wanted (it is applied all the same) */
     double* signalNorm_d;              /* 1 double (uK: the float32 value, widened) */
     double* relWeights_d;              /* yc, N > 1: N + 1 doubles (see above); else unused, may be NULL */
     void* data_d;                      /* [H][W] filtered map; yc float64, uK float32 */

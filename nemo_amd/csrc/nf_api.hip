@@ -384,7 +384,7 @@ int nf_build_filter_half(int covType, int sigType, const void* cov, const void* 
 
 int nf_build_filter_sym_half(int covType, int sigType, const void* cov, const void* Sg, const double* w, float* filt, double* filtSym,
                              int N, int H, int W, void* stream) {
-    if (!cov || !Sg || !w || !filt || !filtSym || N < 1 || N > 6 || H < 1 || W < 1) {
+    if (!cov || !Sg || !w || !filtSym || N < 1 || N > 6 || H < 1 || W < 1) {
         nf_set_error("nf_build_filter_sym_half: bad arguments (1 <= N <= 6)");
         return NF_ERR_ARG;
     }
@@ -393,8 +393,8 @@ int nf_build_filter_sym_half(int covType, int sigType, const void* cov, const vo
     memset(&wv, 0, sizeof(wv));
     for (int i = 0; i < N; ++i) wv.v[i] = w[i];
     nf::ProfScope ps(nf::PT_BUILD_FILTER, S(stream),
-                     (double)npix * ((double)N * N * (covType == NF_F32 ? 4.0 : 8.0) + N * (sigType == NF_F32 ? 4.0 : 8.0) + N * 4.0 +
-                                     N * 4.0));
+                     (double)npix * ((double)N * N * (covType == NF_F32 ? 4.0 : 8.0) + N * (sigType == NF_F32 ? 4.0 : 8.0) +
+                                     (filt ? N * 4.0 : 0.0) + N * 4.0));
     return nf::build_filter_sym(covType, sigType, cov, Sg, wv, filt, filtSym, N, H, W, S(stream));
 }
 

@@ -214,8 +214,10 @@ __global__ void k_build_filter_sym(const T* __restrict__ cov, const cpx<TS>* __r
             }
 #pragma unroll
             for (int i = 0; i < N; ++i) {
-                filt[(long long)i * npix + p] = o1[i];
-                if (!selfColumn) filt[(long long)i * npix + pm] = o2[i];
+                if (filt != nullptr) {
+                    filt[(long long)i * npix + p] = o1[i];
+                    if (!selfColumn) filt[(long long)i * npix + pm] = o2[i];
+                }
                 sym[(long long)i * npix + p] = 0.5 * ((double)o1[i] + (double)o2[i]);
             }
         }

@@ -141,7 +141,7 @@ int run_scale(nf_plan* plan, const nf_mf_tile& t, const nf_mf_scale& sc, const L
     double* mapMax = (double*)(ws + L.mapMax);
     double* peak = (double*)(ws + L.peak);
     void* S = (void*)st;
-    if (!sc.filt_d || !sc.signalNorm_d || !sc.data_d || !sc.sn_d || !sc.rms_d || !sc.mask_d || (yc && N > 1 && !sc.relWeights_d)) {
+    if (!sc.signalNorm_d || !sc.data_d || !sc.sn_d || !sc.rms_d || !sc.mask_d || (yc && N > 1 && !sc.relWeights_d)) {
         nf_set_error("nf_matched_filter_scales: a scale lacks an output buffer");
         return NF_ERR_ARG;
     }

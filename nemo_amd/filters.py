@@ -57,11 +57,13 @@ def filterMaps(unfilteredMapsDictList, filterParams, tileName, diagnosticsDir='.
 
 
 def filterMapsGroup(unfilteredMapsDictList, filterParamsList, tileName, diagnosticsDir='.', selFnDir='.', verbose=True,
-                    undoPixelWindow=True, useCachedFilter=False, tileCache=None, lanes=1):
+                    undoPixelWindow=True, useCachedFilter=False, tileCache=None, lanes=1, keepFilters=None):
     """filterMaps for several filters of one tile: [(filteredMapDict, filterObj), ...] in the order given.  Consecutive
     matched filters that share their maps and their noise / trim settings (the scales of a filter bank) go to the library in
     one call, dealt to ``lanes`` HIP streams that run side by side (nf_matched_filter_scales); everything else runs filter
-    by filter exactly as filterMaps does."""
+    by filter exactly as filterMaps does.  ``keepFilters`` (None = all): the labels whose filter cube the caller will still read
+    from the returned object (``filterObj.filt``, an in-memory cached filter); the other scales of such a call apply their filter
+    without storing the cube (``saveFilter`` is honoured regardless)."""
     if tileCache is None:
         tileCache = {}          # what the filters of this call share (maps in HBM, data spectra, noise covariance)
     objs = []
@@ -80,7 +82,7 @@ def filterMapsGroup(unfilteredMapsDictList, filterParamsList, tileName, diagnost
             while run[-1] + 1 < len(objs) and isinstance(objs[run[-1] + 1], MatchedFilter) and \
                     objs[run[-1] + 1]._scaleKey(useCachedFilter) == key:
                 run.append(run[-1] + 1)
-            dicts = MatchedFilter._runScales([objs[i] for i in run], undoPixelWindow, lanes)
+            dicts = MatchedFilter._runScales([objs[i] for i in run], undoPixelWindow, lanes, keepFilters)
         else:
             dicts = None
         if dicts is None:
@@ -539,7 +541,7 @@ class MatchedFilter(MapFilter):
                 tuple(float(v) for v in self._frequencyWeights()))
 
     @staticmethod
-    def _runScales(objs, undoPixelWindow, lanes):
+    def _runScales(objs, undoPixelWindow, lanes, keepFilters=None):
         """buildAndApply of every filter in ``objs`` (equal _scaleKey) through nf_matched_filter_scales.  Returns
         ([filteredMapDict, ...], pixel window undone?) or None if the tile has no noise cell (the caller falls back)."""
         first = objs[0]
@@ -597,7 +599,8 @@ class MatchedFilter(MapFilter):
 
         G = len(objs)
         odt = t.float64 if yc else t.float32
-        filt = t.empty((G, N, H, W), dtype=t.float32, device=eng.dev)
+        wantCube = [keepFilters is None or obj.label in keepFilters or obj.params.get('saveFilter', False) == True for obj in objs]
+        cubes = [t.empty((N, H, W), dtype=t.float32, device=eng.dev) if want else None for want in wantCube]
         data = t.empty((G, H, W), dtype=odt, device=eng.dev)
         sn = t.empty((G, H, W), dtype=odt, device=eng.dev)
         rms = t.empty((G, H, W), dtype=t.float32, device=eng.dev)
@@ -615,7 +618,7 @@ class MatchedFilter(MapFilter):
                 sc.r_d[i], sc.prof_d[i], sc.slope_d[i] = r.data_ptr(), prof.data_ptr(), slope.data_ptr()
                 sc.ntab[i], sc.r0[i], sc.dlnr[i], sc.amp[i], sc.sign[i] = len(t1.r), t1.r0, t1.dlnr, t1.amp, t1.sign
                 sc.templateScale[i] = scale
-            sc.filt_d = filt.data_ptr() + g * N * H * W * 4
+            sc.filt_d = cubes[g].data_ptr() if cubes[g] is not None else None
             sc.signalNorm_d = scal.data_ptr() + g * (N + 2) * 8
             sc.relWeights_d = scal.data_ptr() + (g * (N + 2) + 1) * 8
             sc.data_d = data.data_ptr() + g * H * W * es
@@ -634,7 +637,7 @@ class MatchedFilter(MapFilter):
 
         out = []
         for g, obj in enumerate(objs):
-            obj._dFilt = filt[g]
+            obj._dFilt = cubes[g]
             obj._signalNorm = engine.DeviceScalar(scal[g, 0:1], wide=yc)
             obj.fRelWeights = {}
             if yc:

@@ -437,7 +437,8 @@ def _filterMapsAndMakeCatalogs(config, rootOutDir=None, useCachedFilters=False, 
                     toFilter = [f for f in group if f['label'] not in cached]
                     res = filters.filterMapsGroup(config.unfilteredMapsDictList, toFilter, tileName, diagnosticsDir=diagnosticsDir,
                                                   selFnDir=config.selFnDir, verbose=verbose, undoPixelWindow=undoPixelWindow,
-                                                  useCachedFilter=useCachedFilters, tileCache=tileCache, lanes=lanes) if toFilter else []
+                                                  useCachedFilter=useCachedFilters, tileCache=tileCache, lanes=lanes,
+                                                  keepFilters={photFilter}) if toFilter else []     # (the one cube kept below)
                     for k, f in enumerate(group):
                         last = k == len(group) - 1
                         if f['label'] in cached:

@@ -105,3 +105,33 @@ def test_scale_entry_mixed_group_and_fallbacks():
         for key in ('filt', 'data', 'SNMap', 'RMSMap', 'surveyMask'):
             assert np.array_equal(got[k][key], one[key]), (k, key)
         assert got[k]['signalNorm'] == one['signalNorm']
+
+
+def test_scale_entry_without_the_filter_cube():
+    """keepFilters: the scales whose filter cube nobody will read apply their filter without storing it - same maps bit for
+    bit, ``filt`` is None for them and present for the kept label."""
+    shape = (211, 256)
+    mapsL, wcs, truth = helpers.make_tile(shape, freqs=(150.0, 98.0), fwhm=(1.4, 2.1), noise=(15.0, 20.0), seed=11, numSources=4,
+                                          kind='clusters', dtype=np.float64, holes=True)
+    base = {'noiseParams': {'method': 'dataMap', 'noiseGridArcmin': 20., 'numNoiseBins': 1}, 'outputUnits': 'yc'}
+    filtersList = []
+    for k, (z, m) in enumerate([(0.4, 2e14), (0.2, 4e14), (0.8, 1e14)]):
+        p = dict(base)
+        p.update({'z': z, 'M500MSun': m})
+        filtersList.append({'label': 'scale%d' % k, 'class': 'ArnaudModelMatchedFilter', 'params': p})
+    ref = _run(mapsL, filtersList, True, 2, True)
+    keepDev = filters.RETURN_DEVICE_ARRAYS
+    filters.RETURN_DEVICE_ARRAYS = True
+    try:
+        res = filters.filterMapsGroup(helpers.product_maps(mapsL), filtersList, 'PRIMARY', diagnosticsDir=None, selFnDir=None,
+                                      verbose=False, undoPixelWindow=True, tileCache={}, lanes=2, keepFilters={'scale1'})
+        for k, (d, fobj) in enumerate(res):
+            for key in ('data', 'SNMap', 'RMSMap', 'surveyMask'):
+                assert np.array_equal(d[key].cpu().numpy(), ref[k][key]), (k, key)
+            assert fobj.signalNorm == ref[k]['signalNorm']
+            if k == 1:
+                assert np.array_equal(fobj.filt, ref[k]['filt'])
+            else:
+                assert fobj.filt is None
+    finally:
+        filters.RETURN_DEVICE_ARRAYS = keepDev

@@ -677,6 +677,76 @@ __global__ void __launch_bounds__(NF_MAXRED_THREADS) k_map_max_finish(const doub
     }
 }
 
+// nf_sum_planes and the first half of nf_map_max in one pass over the planes (the per-scale call with several frequencies:
+// nemo/filters.py:847 then :661): out = in[0] + ... + in[N-1] in plane order, and per workgroup the maximum of out with its
+// first index.
+__global__ void __launch_bounds__(NF_MAXRED_THREADS) k_sum_planes_max(const float* __restrict__ in, float* __restrict__ out, int N,
+                                                                       long long n, double* __restrict__ pv, long long* __restrict__ pi) {
+    double best = -INFINITY;
+    long long arg = 0x7FFFFFFFFFFFFFFFLL;
+    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x) {
+        float acc = in[p];
+        for (int i = 1; i < N; ++i) acc = __fadd_rn(acc, in[(long long)i * n + p]);
+        out[p] = acc;
+        const double v = (double)acc;
+        if (v > best) {
+            best = v;
+            arg = p;
+        }
+    }
+    block_max_first(best, arg);
+    if (threadIdx.x == 0) {
+        pv[blockIdx.x] = best;
+        pi[blockIdx.x] = arg;
+    }
+}
+
+// the second half of nf_map_max, the relative-weight gather (nemo/filters.py:661-667: the N planes at the position of the
+// maximum, then the maximum) and signalNorm = y0 / peak (:659) as one finishing kernel
+__global__ void __launch_bounds__(NF_MAXRED_THREADS) k_map_max_finish_weights(const double* __restrict__ pv, const long long* __restrict__ pi,
+                                                                               int nPart, double* __restrict__ out,
+                                                                               const float* __restrict__ planes, int N, long long npix,
+                                                                               double* __restrict__ relOut, const double* __restrict__ peak,
+                                                                               double y0, double* __restrict__ normOut) {
+    double best = -INFINITY;
+    long long arg = 0x7FFFFFFFFFFFFFFFLL;
+    for (int k = threadIdx.x; k < nPart; k += blockDim.x) max_first(best, arg, pv[k], pi[k]);
+    block_max_first(best, arg);
+    __shared__ long long at;
+    if (threadIdx.x == 0) {
+        out[0] = best;
+        out[1] = (double)arg;
+        at = arg;
+        relOut[N] = best;
+        normOut[0] = __ddiv_rn(y0, peak[0]);
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < N) relOut[threadIdx.x] = (double)planes[(long long)threadIdx.x * npix + at];
+}
+
+static int map_max_parts(long long n) {
+    long long want = (n + NF_MAXRED_THREADS * 8LL - 1) / (NF_MAXRED_THREADS * 8LL);
+    return (int)(want < 1 ? 1 : (want > NF_MAXRED_BLOCKS ? NF_MAXRED_BLOCKS : want));
+}
+
+int sum_planes_max(const float* in, float* out, int N, long long n, double* mapMax, hipStream_t s) {
+    double* pv = mapMax + 4;
+    long long* pi = (long long*)(pv + NF_MAXRED_BLOCKS);
+    hipLaunchKernelGGL(k_sum_planes_max, dim3(map_max_parts(n)), dim3(NF_MAXRED_THREADS), 0, s, in, out, N, n, pv, pi);
+    NF_CHECK_LAUNCH("k_sum_planes_max");
+    return NF_OK;
+}
+
+int map_max_finish_weights(double* mapMax, long long n, const float* planes, int N, double* relOut, const double* peak, double y0,
+                           double* normOut, hipStream_t s) {
+    double* pv = mapMax + 4;
+    long long* pi = (long long*)(pv + NF_MAXRED_BLOCKS);
+    hipLaunchKernelGGL(k_map_max_finish_weights, dim3(1), dim3(NF_MAXRED_THREADS), 0, s, pv, pi, map_max_parts(n), mapMax, planes, N, n,
+                       relOut, peak, y0, normOut);
+    NF_CHECK_LAUNCH("k_map_max_finish_weights");
+    return NF_OK;
+}
+
 // out: NF_MAP_MAX_DOUBLES (= 4 + 2 * 2048) doubles on the device, owned by the caller: [0] max value, [1] first index of
 // the max, [4..] per-workgroup partials (values, then indices)
 int map_max(int vtype, const void* m, long long n, double* out, hipStream_t s) {

@@ -29,6 +29,17 @@ int window_mul(void* F, const double* wy, const double* wx, int H, int W, int ba
 int paint_radial(float* out, int H, int W, const double* A, const double* B, const double* C, const double* r,
                  const double* prof, const double* slope, int ntab, double r0, double dlnr, double amp, double sign,
                  hipStream_t s);
+struct PaintPlanes {       // per plane: the radial table as paint_radial takes it (log2r0 / invDlog2 as that function forms them)
+    int n;
+    const double* r[8];
+    const double* prof[8];
+    const double* slope[8];
+    int ntab[8];
+    float log2r0[8], invDlog2[8], sign[8];
+    double amp[8];
+};
+int paint_radial_planes(float* out, int H, int W, const double* A, const double* B, const double* C, const PaintPlanes& P,
+                        hipStream_t s);
 int paint_radial2(float* out, float* out2, int H, int W, const double* A, const double* B, const double* C, const double* r,
                   const double* prof, const double* slope, const double* prof2, const double* slope2, int ntab, double r0,
                   double dlnr, double amp, double sign, double amp2, double sign2, hipStream_t s);
@@ -93,6 +104,9 @@ int rms_table(const float* rms, const unsigned char* areaMask, const int* flagMa
               const unsigned long long* rowAreaFix, int H, int W, unsigned* keys, unsigned long long* cnt, unsigned long long* area,
               int tableSize, int* overflow, hipStream_t s);
 int map_max(int vtype, const void* m, long long n, double* out, hipStream_t s);
+int sum_planes_max(const float* in, float* out, int N, long long n, double* mapMax, hipStream_t s);
+int map_max_finish_weights(double* mapMax, long long n, const float* planes, int N, double* relOut, const double* peak, double y0,
+                           double* normOut, hipStream_t s);
 int ring_flags(const int* ringLabels, const double* ringStats, int numRing, int minRingPix, int H, int W, unsigned char* isRing,
                hipStream_t s);
 int spline_eval(int vtype, const void* map, int negate, int H, int W, const double* yx, int nPts, int halfWin, int pointsClass, const int* edgeSel, int nEdge,

@@ -444,6 +444,57 @@ int paint_radial(float* out, int H, int W, const double* A, const double* B, con
     return NF_OK;
 }
 
+// The templates of several frequency maps of one tile in one launch: the angular distance of a pixel (the costly part) is the
+// same for all of them, only the radial tables differ.  Plane i goes to out + i * H * W; per plane exactly the arithmetic of
+// k_paint_radial<false>.
+__global__ void __launch_bounds__(256) k_paint_radial_planes(float* __restrict__ out, int H, int W, const double* __restrict__ A,
+                                                             const double* __restrict__ B, const double* __restrict__ C,
+                                                             PaintPlanes P) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= W) return;
+    const double cx = C[x];
+    const long long npix = (long long)H * W;
+    for (int y = blockIdx.y; y < H; y += gridDim.y) {
+        const double h = __dadd_rn(A[y], __dmul_rn(B[y], cx));
+        const double th = theta_from_hav(h);
+        const float lth = __log2f((float)th);
+        for (int i = 0; i < P.n; ++i) {
+            const double* __restrict__ r = P.r[i];
+            const double* __restrict__ prof = P.prof[i];
+            const double* __restrict__ slope = P.slope[i];
+            const int ntab = P.ntab[i];
+            const double rlast = r[ntab - 1], rfirst = r[0];
+            double val;
+            if (th < rfirst) {
+                val = prof[0];
+            } else if (th > rlast) {
+                val = 0.0;
+            } else if (th == rlast) {
+                val = prof[ntab - 1];
+            } else {
+                int j = (int)((lth - P.log2r0[i]) * P.invDlog2[i]);
+                if (j < 0) j = 0;
+                if (j > ntab - 2) j = ntab - 2;
+                while (j > 0 && r[j] > th) --j;
+                while (j < ntab - 2 && r[j + 1] <= th) ++j;
+                const double dr = __dsub_rn(th, r[j]);
+                const double sl = slope != nullptr ? slope[j] : __ddiv_rn(__dsub_rn(prof[j + 1], prof[j]), __dsub_rn(r[j + 1], r[j]));
+                val = __dadd_rn(__dmul_rn(sl, dr), prof[j]);
+            }
+            const float v = (float)__dmul_rn(P.amp[i], val);
+            out[(long long)i * npix + (long long)y * W + x] = (P.sign[i] < 0.0f) ? v * -1.0f : v;
+        }
+    }
+}
+
+int paint_radial_planes(float* out, int H, int W, const double* A, const double* B, const double* C, const PaintPlanes& P,
+                        hipStream_t s) {
+    const int gy = H < 1024 ? H : 1024;
+    hipLaunchKernelGGL(k_paint_radial_planes, dim3((W + 255) / 256, gy), dim3(256), 0, s, out, H, W, A, B, C, P);
+    NF_CHECK_LAUNCH("k_paint_radial_planes");
+    return NF_OK;
+}
+
 int paint_radial2(float* out, float* out2, int H, int W, const double* A, const double* B, const double* C, const double* r,
                   const double* prof, const double* slope, const double* prof2, const double* slope2, int ntab, double r0,
                   double dlnr, double amp, double sign, double amp2, double sign2, hipStream_t s) {

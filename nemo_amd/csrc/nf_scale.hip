@@ -1,11 +1,12 @@
 // One matched-filter scale per call (nf_matched_filter_scales, include/nemofilt.h): the statements of
 // MatchedFilter.buildAndApply (nemo/filters.py:521-777) and of filterMaps' pixel-window undo (:98-101) as a fixed sequence of
-// this library's own entry points, enqueued from C++ instead of from the interpreter.  No kernel of its own beyond the two
-// scalar steps between them (signalNorm, the relative-weight gather); scales of a tile are independent of each other, so
+// this library's own entry points, enqueued from C++ instead of from the interpreter.  No kernel of its own beyond the
+// scalar step between them (signalNorm); scales of a tile are independent of each other, so
 // they are dealt to lanes (HIP streams) that run side by side - small tiles do not fill the chip one kernel at a time.
 #include "../../include/nemofilt.h"
 
 #include "nf_common.h"
+#include "nf_kernels.h"
 
 #include <map>
 #include <mutex>
@@ -26,16 +27,6 @@ __global__ void k_signal_norm(int mode, const double* __restrict__ src, double y
     }
 }
 
-// nemo/filters.py:661-667: the N per-frequency filtered planes at the position of the summed map's maximum, then the maximum
-__global__ void k_rel_weights(const float* __restrict__ planes, const double* __restrict__ mapMax, int N, long long npix,
-                              double* __restrict__ out) {
-    const int i = threadIdx.x;
-    const long long at = (long long)mapMax[1];
-    if (i < N) out[i] = (double)planes[(long long)i * npix + at];
-    if (i == N) out[N] = mapMax[0];
-}
-
-// ---- workspace layout -------------------------------------------------------------------------------------------
 struct Layout {
     size_t T, F, filtSym, work, sig, planes, pre, zeroRows, noise, noiseBytes, edgeTmp, edgeOut, mapMax, peak, total;
 };
@@ -146,9 +137,30 @@ int run_scale(nf_plan* plan, const nf_mf_tile& t, const nf_mf_scale& sc, const L
         return NF_ERR_ARG;
     }
     // unit templates (nemo/filters.py:611-618) and their spectra, all planes in one transform
-    for (int i = 0; i < N; ++i)
-        NF_TRY(nf_paint_radial(T + (size_t)i * npix, H, W, t.A_d, t.B_d, t.C_d, sc.r_d[i], sc.prof_d[i], sc.slope_d[i], sc.ntab[i],
-                               sc.r0[i], sc.dlnr[i], sc.amp[i], sc.sign[i], S));
+    if (N == 1) {
+        NF_TRY(nf_paint_radial(T, H, W, t.A_d, t.B_d, t.C_d, sc.r_d[0], sc.prof_d[0], sc.slope_d[0], sc.ntab[0], sc.r0[0], sc.dlnr[0],
+                               sc.amp[0], sc.sign[0], S));
+    } else {
+        // all frequencies in one launch: the pixel's angular distance is formed once (same values as N nf_paint_radial calls)
+        nf::PaintPlanes P;
+        P.n = N;
+        for (int i = 0; i < N; ++i) {
+            if (!sc.r_d[i] || !sc.prof_d[i] || sc.ntab[i] < 2 || !(sc.dlnr[i] > 0) || !(sc.r0[i] > 0)) {
+                nf_set_error("nf_matched_filter_scales: bad radial table");
+                return NF_ERR_ARG;
+            }
+            P.r[i] = sc.r_d[i];
+            P.prof[i] = sc.prof_d[i];
+            P.slope[i] = sc.slope_d[i];
+            P.ntab[i] = sc.ntab[i];
+            P.log2r0[i] = (float)(log(sc.r0[i]) / log(2.0));
+            P.invDlog2[i] = (float)(1.0 / (sc.dlnr[i] / log(2.0)));
+            P.amp[i] = sc.amp[i];
+            P.sign[i] = (float)sc.sign[i];
+        }
+        nf::ProfScope ps(nf::PT_PAINT, st, (double)npix * 4.0 * N);
+        NF_TRY(nf::paint_radial_planes(T, H, W, t.A_d, t.B_d, t.C_d, P, st));
+    }
     NF_TRY(nf_fft2_forward_half(plan, NF_F32, T, NF_IN_REAL32, F, N, nullptr, nullptr, 1, S));
     // the filter (:621-627) and its symmetrised form for the half-spectrum inverse
     NF_TRY(nf_build_filter_sym_half(t.covType, NF_F32, t.noiseCov_d, F, t.w, sc.filt_d, filtSym, N, H, W, S));
@@ -164,15 +176,18 @@ int run_scale(nf_plan* plan, const nf_mf_tile& t, const nf_mf_scale& sc, const L
             // plane order, is the filtered template (:647 -> :847 sums after the inverse transforms)
             NF_TRY(nf_fft2_inverse_half(plan, NF_F32, F, filtSym, 1, 1, t.winY_d, t.winX_d, sc.templateScale, work, planes,
                                         NF_IN_REAL32, N, 0, 0, 0, S));
-            NF_TRY(nf_sum_planes(planes, sig, N, npix, S));
+            // (the sum pass also leaves the per-workgroup maxima of the summed map: the first half of nf_map_max)
+            nf::ProfScope ps(nf::PT_APPLY_FILTER, st, (double)npix * (N + 1) * 4.0);
+            NF_TRY(nf::sum_planes_max(planes, sig, N, npix, mapMax, st));
         }
         NF_TRY(nf_spline_eval(NF_F32, sig, 0, H, W, t.centreYX_d, 1, t.halfWin, t.centreClass, nullptr, 0, peak, S));
-        hipLaunchKernelGGL(k_signal_norm, dim3(1), dim3(64), 0, st, 0, peak, t.y0, sc.signalNorm_d);
-        NF_CHECK_LAUNCH("k_signal_norm");
         if (N > 1) {
-            NF_TRY(nf_map_max(NF_F32, sig, npix, mapMax, S));
-            hipLaunchKernelGGL(k_rel_weights, dim3(1), dim3(64), 0, st, planes, mapMax, N, npix, sc.relWeights_d);
-            NF_CHECK_LAUNCH("k_rel_weights");
+            // one finishing kernel: the maximum and its position (:661), the N planes there (:662-667), signalNorm (:659)
+            nf::ProfScope ps(nf::PT_MAP_MAX, st, 0.0);
+            NF_TRY(nf::map_max_finish_weights(mapMax, npix, planes, N, sc.relWeights_d, peak, t.y0, sc.signalNorm_d, st));
+        } else {
+            hipLaunchKernelGGL(k_signal_norm, dim3(1), dim3(64), 0, st, 0, peak, t.y0, sc.signalNorm_d);
+            NF_CHECK_LAUNCH("k_signal_norm");
         }
     } else {
         NF_TRY(nf_fft2_inverse_half(plan, NF_F32, F, filtSym, N, 0, nullptr, nullptr, nullptr, work, sig, NF_IN_REAL32, 1, 0, 0, 0, S));

@@ -160,15 +160,19 @@ def vstack(tables):
             t._materialiseNames()
     # columns: the union, in order of first appearance (astropy's outer join masks what a table lacks; here -99, the
     # catalogue's own "no value", or the empty string)
-    keys = []
+    keys, seen = [], set()
+    keySets = [set(t.keys()) for t in tables]
     for t in tables:
-        keys += [k for k in t.keys() if k not in keys]
+        for k in t.keys():
+            if k not in seen:
+                seen.add(k)
+                keys.append(k)
     for k in keys:
         if k == 'name' and out._nameSpec is not None:
             continue
-        have = [t[k] for t in tables if k in t.keys()]
-        fill = '' if have[0].dtype.kind in 'US' else -99
-        out._cols[k] = np.concatenate([t[k] if k in t.keys() else np.full(len(t), fill) for t in tables])
+        first = next(t for t, ks in zip(tables, keySets) if k in ks)[k]
+        fill = '' if first.dtype.kind in 'US' else -99
+        out._cols[k] = np.concatenate([t[k] if k in ks else np.full(len(t), fill) for t, ks in zip(tables, keySets)])
     return out
 
 

@@ -261,7 +261,11 @@ class MapFilter(object):
 
     # -- geometry ---------------------------------------------------------------------------------------------
     def makeRadiansMap(self):
-        """nemo/filters.py:211-236."""
+        """nemo/filters.py:211-236 (the same for every filter of a tile: kept in the tile cache)."""
+        if self._shared is not None and 'radians' in self._shared:
+            self.degPerPixX, self.degPerPixY, self._xRad, self._yRad = self._shared['radians']
+            self._radiansMap = None
+            return
         H, W = self.shape
         x0 = int(W / 2)
         y0 = int(H / 2)
@@ -273,6 +277,8 @@ class MapFilter(object):
         yRad = np.arange(int(np.floor(-H / 2)), int(H / 2), dtype=np.float64) * np.radians(self.degPerPixY)
         self._xRad, self._yRad = xRad, yRad
         self._radiansMap = None
+        if self._shared is not None:
+            self._shared['radians'] = (self.degPerPixX, self.degPerPixY, xRad, yRad)
 
     @property
     def radiansMap(self):

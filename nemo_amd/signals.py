@@ -233,9 +233,14 @@ class BeamProfile(object):
         self.ell = ell
 
     def cacheKey(self):
-        if self.beamFileName is not None:
-            return os.path.abspath(self.beamFileName)
-        return ('arrays', len(self.rDeg), float(np.sum(self.profile1d)), float(self.rDeg[-1]))
+        key = getattr(self, '_cacheKey', None)
+        if key is None:
+            if self.beamFileName is not None:
+                key = os.path.abspath(self.beamFileName)
+            else:
+                key = ('arrays', len(self.rDeg), float(np.sum(self.profile1d)), float(self.rDeg[-1]))
+            self._cacheKey = key
+        return key
 
 
 _beamCache = {}

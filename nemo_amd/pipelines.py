@@ -479,8 +479,11 @@ def _filterMapsAndMakeCatalogs(config, rootOutDir=None, useCachedFilters=False, 
                     config.areaMaskDict[tileName] = filteredMapDict['surveyMask']
                 if writeFlagMask == True and tileName not in config.flagMaskDict.keys():
                     config.flagMaskDict[tileName] = filteredMapDict['flagMask']
-                ready = t.cuda.Event()
-                ready.record(t.cuda.current_stream())
+                # (the worker waits for the group's last event only: the others are not made)
+                ready = None
+                if lastOfGroup:
+                    ready = t.cuda.Event()
+                    ready.record(t.cuda.current_stream())
                 groupJobs.append((label, f, filteredMapDict, photFilteredMapDict, ready))
                 del filteredMapDict, filterObj
                 if not lastOfGroup:

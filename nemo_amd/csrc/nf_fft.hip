@@ -1025,13 +1025,26 @@ __global__ void __launch_bounds__(COLS ? NF_FFT_MAXTHREADS : 512) k_line_filter(
         if (G.nl > 0) {
             const size_t c0 = 2u * (size_t)(G.line0 + G.tl);
             const bool haveB = c0 + 1 < W;
+            // the lane's two columns as one 2-vector where the pitch and the pointer allow it
+            const bool vecD = a.inType == 1 && (W & 1) == 0 && ((size_t)G.inP & 15) == 0;
+            const bool vecF = a.inType != 1 && (W & 1) == 0 && ((size_t)G.inP & 7) == 0;
             for (int e0 = G.tb; e0 < n; e0 += NB * G.TB) {
                 cpx<T> z[NB];
 #pragma unroll
                 for (int j = 0; j < NB; ++j) {
                     const int e = min(e0 + j * G.TB, n - 1);
-                    z[j].x = lf_load<T>(G.inP, a.inType, (size_t)e * W + c0);
-                    z[j].y = haveB ? lf_load<T>(G.inP, a.inType, (size_t)e * W + c0 + 1) : (T)0;
+                    if (vecD) {
+                        const double2 v = *(const double2*)((const double*)G.inP + (size_t)e * W + c0);
+                        z[j].x = (T)v.x;
+                        z[j].y = (T)v.y;
+                    } else if (vecF) {
+                        const float2 v = *(const float2*)((const float*)G.inP + (size_t)e * W + c0);
+                        z[j].x = (T)v.x;
+                        z[j].y = (T)v.y;
+                    } else {
+                        z[j].x = lf_load<T>(G.inP, a.inType, (size_t)e * W + c0);
+                        z[j].y = haveB ? lf_load<T>(G.inP, a.inType, (size_t)e * W + c0 + 1) : (T)0;
+                    }
                 }
 #pragma unroll
                 for (int j = 0; j < NB; ++j) {
@@ -1084,10 +1097,24 @@ __global__ void __launch_bounds__(COLS ? NF_FFT_MAXTHREADS : 512) k_line_filter(
             const size_t c0 = 2u * (size_t)(G.line0 + G.tl);
             const bool haveB = c0 + 1 < W;
             const bool useRef = a.epiZeroRef != nullptr;
+            const bool vecD = !useRef && a.outType == 1 && (W & 1) == 0 && ((size_t)G.outP & 15) == 0;
+            const bool vecF = !useRef && a.outType != 1 && (W & 1) == 0 && ((size_t)G.outP & 7) == 0;
             for (int e = G.tb; e < n; e += G.TB) {
                 const cpx<T> v = buf[(unsigned)swz(e) * (unsigned)G.TL + (unsigned)G.tl];
-                lf_store<T>(a, G.outP, (size_t)e * W + c0, v.x, useRef);
-                if (haveB) lf_store<T>(a, G.outP, (size_t)e * W + c0 + 1, -v.y, useRef);
+                if (vecD) {
+                    double2 o;
+                    o.x = (double)v.x;
+                    o.y = (double)-v.y;
+                    *(double2*)((double*)G.outP + (size_t)e * W + c0) = o;
+                } else if (vecF) {
+                    float2 o;
+                    o.x = (float)v.x;
+                    o.y = (float)-v.y;
+                    *(float2*)((float*)G.outP + (size_t)e * W + c0) = o;
+                } else {
+                    lf_store<T>(a, G.outP, (size_t)e * W + c0, v.x, useRef);
+                    if (haveB) lf_store<T>(a, G.outP, (size_t)e * W + c0 + 1, -v.y, useRef);
+                }
             }
         }
     } else {

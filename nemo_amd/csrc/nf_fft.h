@@ -54,6 +54,7 @@ struct LineArgs {
     long long sumStride;     // plane pitch of in / mul for the sum (elements)
     int storeLo, storeHi;    // columns kernel: only the elements (rows) storeLo <= e < storeHi are stored (storeHi == 0: all)
     int lineBase;            // rows kernel: first line of this launch (lines lineBase .. nLines - 1)
+    int colPair;             // columns kernel, float32: strides, types and table alignment allow two adjacent columns per thread
     int usePlaneScale;       // halfIn: plane pl of the sum (nSum > 1) / batch entry b (nSum <= 1) is also multiplied by planeScale[pl / b]
     double planeScale[8];
     const double* winLine;   // pixel-window table along the line index (columns kernel: wx[col]) and

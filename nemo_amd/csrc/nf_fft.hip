@@ -479,6 +479,148 @@ __device__ __forceinline__ void fft_stage_dispatch(cpx<T>* buf, const nf::LineAr
     }
 }
 
+// Columns kernel, float32, first (srcG) or last (!srcG) stage with TWO adjacent columns per thread: the pair travels as one
+// 16-byte access to global memory and to LDS (one complex64 per lane makes 8-byte accesses and 32-byte runs per tile row), the
+// twiddles are fetched once for both.  Same arithmetic per element as fft_stage (DIT, plain radices, complex in and out, SPEC
+// 0 or 3); the caller takes this path only for whole tiles of even width away from the packed column 0 / W/2, with even
+// pitches and 16-byte aligned planes.
+template <int R, int SPEC>
+__device__ __forceinline__ void fft_stage_colpair(cpx<float>* __restrict__ buf, const nf::LineArgs<float>& a, const nf::StageInfo st,
+                                                  const bool srcG, const Geo& G) {
+    const nf::LinePlan<float>& p = a.plan;
+    const unsigned L = (unsigned)st.L, LR = L * R;
+    const unsigned nb = (unsigned)p.m / R;
+    const unsigned TL = (unsigned)G.TL, P = TL >> 1;
+    const unsigned pl = threadIdx.x % P, tb2 = threadIdx.x / P, TB2 = blockDim.x / P;
+    const unsigned line = 2u * pl, col = (unsigned)G.line0 + line;
+    const cpx<float>* __restrict__ twp = p.stw + st.twOff;
+    cpx<float> wR[R];
+    if (R != 2 && R != 4 && R != 8 && R != 3) {
+#pragma unroll
+        for (int j = 0; j < R; ++j) wR[j] = p.stw[st.rootOff + j];
+    }
+    for (unsigned b = tb2; b < nb; b += TB2) {
+        unsigned g = b, q = 0;
+        if (L > 1) {
+            g = __umulhi(b, st.magic);
+            q = b - g * L;
+        }
+        const unsigned base = g * LR + q;
+        cpx<float> w[R - 1];
+        if (L > 1) {
+#pragma unroll
+            for (int k = 1; k < R; ++k) w[k - 1] = twp[(unsigned)(k - 1) * L + q];
+        }
+        cpx<float> x0[R], x1[R];
+        if (srcG) {
+            unsigned row[R];
+#pragma unroll
+            for (int k = 0; k < R; ++k) row[k] = (unsigned)p.src[base + (unsigned)k * L];
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const float4 v = *(const float4*)((const cpx<float>*)G.inP + (col + row[k] * (unsigned)a.inElemStride));
+                x0[k].x = v.x;
+                x0[k].y = v.y * (float)a.conjInSign;
+                x1[k].x = v.z;
+                x1[k].y = v.w * (float)a.conjInSign;
+            }
+            if (SPEC == 3) {
+                // the real factor filtSym * planeScale * (wy * wx) per element, formed in fft_stage's order
+                double2 m2[R];
+                if (a.mulSym != nullptr) {
+                    const double* __restrict__ ms = a.mulSym + (size_t)blockIdx.y * (size_t)a.mulBatchStride;
+#pragma unroll
+                    for (int k = 0; k < R; ++k) m2[k] = *(const double2*)(ms + (col + row[k] * (unsigned)a.inElemStride));
+                } else {
+#pragma unroll
+                    for (int k = 0; k < R; ++k) {
+                        m2[k].x = 1.0;
+                        m2[k].y = 1.0;
+                    }
+                }
+                const double ps = a.usePlaneScale ? a.planeScale[blockIdx.y & 7] : 1.0;
+                const bool win = a.winElem != nullptr;
+                const double wl0 = win ? a.winLine[col] : 1.0, wl1 = win ? a.winLine[col + 1] : 1.0;
+#pragma unroll
+                for (int k = 0; k < R; ++k) {
+                    double f0 = m2[k].x, f1 = m2[k].y;
+                    if (a.usePlaneScale) {
+                        f0 *= ps;
+                        f1 *= ps;
+                    }
+                    if (win) {
+                        const double we = a.winElem[row[k]];
+                        f0 *= we * wl0;
+                        f1 *= we * wl1;
+                    }
+                    x0[k].x = (float)((double)x0[k].x * f0);
+                    x0[k].y = (float)((double)x0[k].y * f0);
+                    x1[k].x = (float)((double)x1[k].x * f1);
+                    x1[k].y = (float)((double)x1[k].y * f1);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const float4 v = *(const float4*)(buf + ((unsigned)swz((int)(base + (unsigned)k * L)) * TL + line));
+                x0[k].x = v.x;
+                x0[k].y = v.y;
+                x1[k].x = v.z;
+                x1[k].y = v.w;
+            }
+        }
+        if (L > 1) {
+#pragma unroll
+            for (int k = 1; k < R; ++k) {
+                x0[k] = cmul(x0[k], w[k - 1]);
+                x1[k] = cmul(x1[k], w[k - 1]);
+            }
+        }
+        Dft<float, R>::run(x0, wR);
+        Dft<float, R>::run(x1, wR);
+        if (srcG) {
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                float4 v;
+                v.x = x0[k].x;
+                v.y = x0[k].y;
+                v.z = x1[k].x;
+                v.w = x1[k].y;
+                *(float4*)(buf + ((unsigned)swz((int)(base + (unsigned)k * L)) * TL + line)) = v;
+            }
+        } else {
+            const float r = (float)a.scale, ri = r * (float)a.conjOutSign;
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const unsigned e = base + (unsigned)k * L;
+                if (a.storeHi == 0 || (e >= (unsigned)a.storeLo && e < (unsigned)a.storeHi)) {
+                    float4 v;
+                    v.x = x0[k].x * r;
+                    v.y = x0[k].y * ri;
+                    v.z = x1[k].x * r;
+                    v.w = x1[k].y * ri;
+                    *(float4*)((cpx<float>*)G.outP + (col + e * (unsigned)a.outElemStride)) = v;
+                }
+            }
+        }
+    }
+    if (srcG) __syncthreads();
+}
+
+template <int SPEC>
+__device__ __forceinline__ bool fft_stage_colpair_dispatch(cpx<float>* buf, const nf::LineArgs<float>& a, int s, bool srcG, const Geo& G) {
+    const nf::StageInfo st = a.plan.st[s];
+    switch (st.R) {
+        case 2: fft_stage_colpair<2, SPEC>(buf, a, st, srcG, G); return true;
+        case 3: fft_stage_colpair<3, SPEC>(buf, a, st, srcG, G); return true;
+        case 4: fft_stage_colpair<4, SPEC>(buf, a, st, srcG, G); return true;
+        case 5: fft_stage_colpair<5, SPEC>(buf, a, st, srcG, G); return true;
+        case 7: fft_stage_colpair<7, SPEC>(buf, a, st, srcG, G); return true;
+        case 8: fft_stage_colpair<8, SPEC>(buf, a, st, srcG, G); return true;
+        default: return false;
+    }
+}
+
 // Bluestein middle: natural order data in LDS -> DIF -> multiply by the chirp spectrum (conjugated: the way back is a
 // forward transform of the conjugate) -> ready for the DIT stages.
 template <typename T, bool COLS, int MODE>
@@ -923,7 +1065,20 @@ __global__ void __launch_bounds__((MODE == 0 && SPEC == 3 && sizeof(T) == 8) ? 5
         // packNyq, forward: Z = FFT(c0 + i cN) is unpacked with its mirror element, G0[k] = (Z[k] + conj Z[-k]) / 2,
         // GN[k] = -i (Z[k] - conj Z[-k]) / 2 - tile 0 keeps its last stage in LDS and leaves through a store pass
         const bool unpack = SPEC <= 1 && a.packNyq && tile == 0;
-        for (int s = 0; s < p.nst; ++s) fft_stage_dispatch<T, true, MODE, SPEC>(buf, a, s, false, s == 0, s == p.nst - 1 && !unpack, G);
+        // float32, whole tiles away from the packed column: two adjacent columns per thread in the stages that touch global memory
+        bool pairOK = false;
+        if constexpr (sizeof(T) == 4 && MODE == 0 && (SPEC == 0 || SPEC == 3)) {
+            pairOK = a.colPair && G.TL >= 2 && nvalid == G.TL && !(a.packNyq && tile == 0) && p.nst >= 2 && (blockDim.x % (G.TL >> 1)) == 0 &&
+                     (((size_t)G.inP | (size_t)G.outP) & 15) == 0;
+        }
+        for (int s = 0; s < p.nst; ++s) {
+            const bool srcG = s == 0, dstG = s == p.nst - 1 && !unpack;
+            bool done = false;
+            if constexpr (sizeof(T) == 4 && MODE == 0 && (SPEC == 0 || SPEC == 3)) {
+                if (pairOK && (srcG || dstG)) done = fft_stage_colpair_dispatch<SPEC>((cpx<float>*)buf, a, s, srcG, G);
+            }
+            if (!done) fft_stage_dispatch<T, true, MODE, SPEC>(buf, a, s, false, srcG, dstG, G);
+        }
         if (SPEC <= 1 && unpack) {
             const unsigned n = (unsigned)p.n, TL = (unsigned)G.TL, colN = (unsigned)(a.realW / 2);
             const T r = (T)a.scale, ri = r * (T)a.conjOutSign, h = (T)0.5;
@@ -1370,6 +1525,13 @@ int launch_lines(const LineArgs<T>& a0, bool cols, int batch, int threads, hipSt
         nf_set_error("internal: the column pass takes complex input");
         return NF_ERR_ARG;
     }
+    static const int pairOn = env_int("NF_FFT_COL_PAIR", 1);
+    // (long columns only - one workgroup per CU; with short ones the narrower tiles' extra workgroups are worth more: 840-long
+    // columns 25.5 -> 28.3 us with pairs, 4096-long ones 81.9 -> 79.2 us)
+    a.colPair = (cols && pairOn && sizeof(T) == 4 && lds > 80 * 1024 && a.outType == 0 && a.inLineStride == 1 && a.outLineStride == 1 &&
+                 (a.inElemStride & 1) == 0 && (a.outElemStride & 1) == 0 && (a.inBatchStride & 1) == 0 && (a.outBatchStride & 1) == 0 &&
+                 (a.linesPerWG & 1) == 0 && ((size_t)a.mulSym & 15) == 0 && (a.mulBatchStride & 1) == 0)
+                    ? 1 : 0;
     static bool attrSet[2] = {false, false};
     int which = sizeof(T) == 8 ? 1 : 0;
     if (!attrSet[which]) {

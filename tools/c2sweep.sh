@@ -10,11 +10,12 @@ while read -r envs; do
   env $envs timeout -k 10 200 python bench.py --cpu-procs 0 --no-profile --steps 10 --warmup 3 2>/dev/null | python -c "import sys,json;b=json.loads(sys.stdin.readline());print(b['value'], b['ms_per_step'])" >> $O || { echo failed >> $O; exit 1; }
 done <<LIST
 NEMO_AMD_SCALE_LANES=2 NEMO_AMD_SCALE_GROUP=2
-NEMO_AMD_SCALE_LANES=2 NEMO_AMD_SCALE_GROUP=2 NEMO_AMD_ASYNC_WORKERS=2
-NEMO_AMD_SCALE_LANES=2 NEMO_AMD_SCALE_GROUP=2 NEMO_AMD_ASYNC_DEPTH=3
-NEMO_AMD_SCALE_LANES=4 NEMO_AMD_SCALE_GROUP=4
-NEMO_AMD_SCALE_LANES=3 NEMO_AMD_SCALE_GROUP=6
+NEMO_AMD_SCALE_LANES=1 NEMO_AMD_SCALE_GROUP=1
+NEMO_AMD_SCALE_LANES=2 NEMO_AMD_SCALE_GROUP=4
+NEMO_AMD_SCALE_LANES=3 NEMO_AMD_SCALE_GROUP=3
 NEMO_AMD_SCALE_LANES=2 NEMO_AMD_SCALE_GROUP=2
-NEMO_AMD_SCALE_LANES=5 NEMO_AMD_SCALE_GROUP=5
+NEMO_AMD_SCALE_LANES=1 NEMO_AMD_SCALE_GROUP=2
+NEMO_AMD_SCALE_LANES=2 NEMO_AMD_SCALE_GROUP=4
+NEMO_AMD_SCALE_LANES=3 NEMO_AMD_SCALE_GROUP=3
 LIST
 cat $O

@@ -581,3 +581,144 @@ def removeDuplicates(tab):
     keepTab = vstack([dupTab[keepMask], noDupTab])
     keepTab.sort('RADeg')
     return keepTab, len(dupTab), list(dupTab['name']) if 'name' in dupTab.keys() else []
+
+
+# ------------------------------------------------------------------------------------------------------------
+# Source-injection helpers (nemo/catalogs.py:849-1008)
+def _dilatedAreaMask(areaMask, maskDilationPix):
+    """``for i in range(n): m = 1 - binary_dilation(1 - m)`` (nemo/catalogs.py:899-900) in one pass: n dilations by the
+    4-connected cross grow the holes by the city-block ball of radius n, so a pixel survives when its taxicab distance to the
+    nearest zero pixel exceeds n (the map border is not a hole: binary_dilation pads with background)."""
+    from scipy import ndimage
+    m = np.asarray(areaMask) != 0
+    if maskDilationPix <= 0 or m.all():
+        return m
+    return ndimage.distance_transform_cdt(m, metric='taxicab') > maskDilationPix
+
+
+class AreaMasks(object):
+    """What generateTestCatalog reads of a ``completeness.SelFn`` (nemo/catalogs.py:882-897): ``tileNames``, ``areaMaskDict``
+    and ``WCSDict``.  Built from the area masks a pass left in memory (``config.areaMaskDict``) or on disk (selFn/areaMask.fits);
+    keeps, per tile, the valid pixels after dilation - they are the same in every iteration of an injection run."""
+
+    def __init__(self, tileNames, areaMaskDict, WCSDict):
+        self.tileNames = list(tileNames)
+        self.areaMaskDict = areaMaskDict
+        self.WCSDict = WCSDict
+        self._valid = {}
+
+    @classmethod
+    def fromConfig(cls, config, tileNames=None):
+        from . import completeness
+        tileNames = list(config.tileNames if tileNames is None else tileNames)
+        masks, wcss = {}, {}
+        for tileName in tileNames:
+            m = getattr(config, 'areaMaskDict', {}).get(tileName) if hasattr(config, 'areaMaskDict') else None
+            if m is not None:
+                m = m.cpu().numpy() if hasattr(m, 'is_cuda') else np.asarray(m)
+                wcs = config.tileCoordsDict[tileName]['wcs']
+            else:
+                if config.selFnDir is None:
+                    raise Exception("source injection needs the area mask of tile '%s': run the pipeline with writeAreaMask=True "
+                                    "first (or give a selFnDir that holds areaMask.fits)" % (tileName))
+                m, wcs = completeness.loadAreaMask(tileName, config.selFnDir)
+            masks[tileName], wcss[tileName] = m, wcs
+        return cls(tileNames, masks, wcss)
+
+    def validPixels(self, tileName, maskDilationPix):
+        key = (tileName, int(maskDilationPix))
+        if key not in self._valid:
+            self._valid[key] = np.where(_dilatedAreaMask(self.areaMaskDict[tileName], maskDilationPix))
+        return self._valid[key]
+
+
+def generateTestCatalog(config, numSourcesPerTile, amplitudeColumnName='fixed_y_c', amplitudeRange=[0.001, 1],
+                        amplitudeDistribution='linear', selFn=None, avoidanceRadiusArcmin=20.0, maskDilationPix=0, tileNames=None):
+    """Objects at random positions inside the area masks with random amplitudes (nemo/catalogs.py:849-947); at most
+    ``numSourcesPerTile`` per tile, none closer than ``avoidanceRadiusArcmin`` to an earlier one of its tile.  Draws from the
+    global ``np.random`` stream in the reference's order (two jitters per valid pixel, one index per valid pixel, then the
+    amplitudes), so that a seeded stream gives the reference's catalogue; only the positions the loop visits are converted to
+    sky coordinates.  ``selFn``: anything with ``tileNames`` / ``areaMaskDict`` / ``WCSDict`` (:class:`AreaMasks`)."""
+    if selFn is None:
+        selFn = AreaMasks.fromConfig(config, tileNames=tileNames)
+    if tileNames is None:
+        tileNames = selFn.tileNames
+    RAs, decs, amps, catTileNames = [], [], [], []
+    for tileName in tileNames:
+        mapData = selFn.areaMaskDict[tileName]
+        if np.asarray(mapData).sum() == 0:                       # :895
+            continue
+        wcs = selFn.WCSDict[tileName]
+        if hasattr(selFn, 'validPixels'):
+            ys, xs = selFn.validPixels(tileName, maskDilationPix)
+        else:
+            ys, xs = np.where(_dilatedAreaMask(mapData, maskDilationPix))
+        if len(ys) == 0:              # nothing left after the dilation (the reference's randint(0, 0) would raise here)
+            continue
+        ys = ys + np.random.uniform(0, 1, len(ys))
+        xs = xs + np.random.uniform(0, 1, len(xs))
+        indices = np.random.randint(0, len(ys), len(ys))
+        # the reference converts xs[indices], ys[indices] and then reads entry i of THAT list for i in indices (:905-912)
+        tileRAs, tileDecs, keepIndices = [], [], []
+        for i in indices:
+            rai, deci = wcs.pix2wcs(xs[indices[i]], ys[indices[i]])
+            rai, deci = float(rai), float(deci)
+            keepObj = True
+            if len(tileRAs) > 0:
+                keepObj = calcAngSepDeg(rai, deci, np.array(tileRAs), np.array(tileDecs)).min() * 60 > avoidanceRadiusArcmin
+            if keepObj:
+                tileRAs.append(rai)
+                tileDecs.append(deci)
+                keepIndices.append(i)
+            if len(keepIndices) == numSourcesPerTile:
+                break
+        RAs = RAs + tileRAs
+        decs = decs + tileDecs
+        if amplitudeDistribution == 'linear':
+            amp = np.random.uniform(amplitudeRange[0], amplitudeRange[1], len(keepIndices))
+        elif amplitudeDistribution == 'log':
+            amp = np.power(10, np.random.uniform(np.log10(amplitudeRange)[0], np.log10(amplitudeRange)[1], len(keepIndices)))
+        else:
+            raise Exception("Must be either 'linear' or 'log'.")
+        amps = amps + amp.tolist()
+        catTileNames = catTileNames + [tileName] * len(amp)
+    tab = Table()
+    tab['name'] = np.arange(0, len(amps)) + 1
+    tab['RADeg'] = np.array(RAs, dtype=np.float64)
+    tab['decDeg'] = np.array(decs, dtype=np.float64)
+    tab[amplitudeColumnName] = np.array(amps, dtype=np.float64)
+    tab['tileName'] = np.array(catTileNames, dtype='U30') if len(catTileNames) > 0 else np.zeros(0, dtype='U30')
+    return tab
+
+
+def _nearestNeighbour(RA1, dec1, RA2, dec2):
+    """astropy's match_coordinates_sky(cat1, cat2, nthneighbor=1): for every row of set 1 the index of the nearest row of
+    set 2 and the separation in degrees.  Nearest by chord length between unit vectors (monotonic in the angle); the
+    separation is then the great-circle formula.  astropy is absent offline: PARITY UNPINNED (ties, last-bit separations)."""
+    from scipy.spatial import cKDTree
+    u1, u2 = _unitVectors(RA1, dec1), _unitVectors(RA2, dec2)
+    _, idx = cKDTree(u2).query(u1, k=1)
+    idx = np.asarray(idx, dtype=np.int64)
+    rDeg = calcAngSepDeg(np.asarray(RA1, dtype=np.float64), np.asarray(dec1, dtype=np.float64),
+                         np.asarray(RA2, dtype=np.float64)[idx], np.asarray(dec2, dtype=np.float64)[idx])
+    return idx, np.atleast_1d(rDeg)
+
+
+def crossMatch(refCatalog, matchCatalog, radiusArcmin=2.5):
+    """nemo/catalogs.py:950-980: every row of ``refCatalog`` whose nearest row of ``matchCatalog`` lies closer than the radius,
+    that nearest row, and the separations in degrees - three outputs in matching row order."""
+    RAKey1, decKey1 = getTableRADecKeys(refCatalog)
+    RAKey2, decKey2 = getTableRADecKeys(matchCatalog)
+    xIndices, rDeg = _nearestNeighbour(refCatalog[RAKey1], refCatalog[decKey1], matchCatalog[RAKey2], matchCatalog[decKey2])
+    mask = np.less(rDeg, radiusArcmin / 60.)
+    return refCatalog[mask], matchCatalog[xIndices][mask], rDeg[mask]
+
+
+def removeCrossMatched(refCatalog, matchCatalog, radiusArcmin=2.5):
+    """nemo/catalogs.py:983-1008: ``refCatalog`` without the rows that have a row of ``matchCatalog`` within the radius."""
+    if len(matchCatalog) == 0:
+        return refCatalog                 # (the reference would fail inside astropy on an empty catalogue)
+    RAKey1, decKey1 = getTableRADecKeys(refCatalog)
+    RAKey2, decKey2 = getTableRADecKeys(matchCatalog)
+    xIndices, rDeg = _nearestNeighbour(refCatalog[RAKey1], refCatalog[decKey1], matchCatalog[RAKey2], matchCatalog[decKey2])
+    return refCatalog[np.greater(rDeg, radiusArcmin / 60.)]

@@ -428,7 +428,12 @@ class MapFilter(object):
     def _finish(self, dFiltered, trimSizePix, fourierVariant):
         """Noise map, S/N, edge trim, masks (nemo/filters.py:716-756 / :1111-1157); all on the device."""
         eng = self.engine
-        rms = self._noiseMapDevice(dFiltered)
+        if self._tileCache is not None and self._tileCache.get('discardRMS', False):
+            # the driver replaces the S/N map with filtered / cached noise map and never reads this pass's noise map
+            # (nemo/pipelines.py:234-250, the re-filters of maps.sourceInjectionTest): the noise map is not made, 'RMSMap' is zero
+            rms = engine.torch().zeros(self.shape, dtype=engine.torch().float32, device=eng.dev)
+        else:
+            rms = self._noiseMapDevice(dFiltered)
         edge = None
         if trimSizePix > 0:
             edge = eng.edge_check(dFiltered, self._dPSMask, trimSizePix)

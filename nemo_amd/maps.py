@@ -546,3 +546,150 @@ def subtractBackground(data, wcs, RADeg='centre', decDeg='centre', smoothScaleDe
     eng = engine.TileEngine.get(data.shape)
     d = engine.to_dev(data)
     return eng.subtract_background(d, (smoothScaleDeg / yPixScale, smoothScaleDeg / xPixScale))
+
+
+def sourceInjectionTest(config, realCatalog=None, areaMasks=None, verbose=True):
+    """Source injection and recovery at the reference filter scale (nemo/maps.py:1856-2153): for every injection model and
+    iteration a random catalogue is drawn inside the area masks (catalogs.generateTestCatalog), painted into the maps while
+    they are preprocessed (``injectSources``, nemo/maps.py:326-344), the maps are filtered again with the reference filter and
+    noise map an earlier pass left behind (``useCachedFilters`` / ``useCachedRMSMap``: no filter build, no noise map), and
+    what the finder brings back is matched to what went in.  Returns the table of recovered objects: RADeg, decDeg,
+    sourceInjectionModel, theta500Arcmin (clusters), SNR, rArcmin, inFlux, outFlux, noiseLevel, tileName.
+
+    ``realCatalog``: the catalogue of the real run - rows near its objects are left out (:2057-2059); read from
+    <rootOutDir>/<name>_optimalCatalog.fits as in the reference when not given.  ``areaMasks``: a catalogs.AreaMasks (made from
+    the area masks of the last pass, in memory or under selFn/, when not given).  With several ranks every rank draws the
+    objects of its own tiles and the rows are exchanged (the reference draws all of them on rank 0 and broadcasts, :2030-2035)."""
+    from . import signals, catalogs, pipelines
+    realExclusionRadiusArcmin = 5.0
+    if verbose:
+        print(">>> Position recovery test [rank = %d] ..." % (config.rank))
+    numIterations = config.parDict.get('sourceInjectionIterations', 1)
+    if 'sourceInjectionModels' in config.parDict.keys():
+        clusterMode = True
+        sourceInjectionModelList = config.parDict['sourceInjectionModels']
+        SNRCol, fluxCol, noiseLevelCol = 'SNR', 'y_c', 'err_y_c'
+        for model in sourceInjectionModelList:
+            theta500Arcmin = signals.calcTheta500Arcmin(model['redshift'], model['M500'], signals.fiducialCosmoModel)
+            model['label'] = '%.2f' % (theta500Arcmin)
+            model['theta500Arcmin'] = theta500Arcmin
+    else:
+        clusterMode = False
+        sourceInjectionModelList = [{'label': 'pointSource'}]
+        SNRCol, fluxCol, noiseLevelCol = 'SNR', 'deltaT_c', 'err_deltaT_c'
+    numSourcesPerTile = config.parDict.get('sourcesPerTile', 300)
+
+    if realCatalog is None:
+        if config.rootOutDir is None:
+            raise Exception("source injection test: give realCatalog (the catalogue of the real run) for a run without outputDir")
+        catFileName = config.rootOutDir + os.path.sep + "%s_optimalCatalog.fits" % (os.path.split(config.rootOutDir)[-1])
+        if os.path.exists(catFileName) == False:
+            raise Exception("Catalog file '%s' not found - needed to do source injection test." % (catFileName))
+        realCatalog = catalogs.readCatalog(catFileName)
+    if areaMasks is None:
+        areaMasks = catalogs.AreaMasks.fromConfig(config)
+
+    collected = {}          # model label -> lists per output column
+    cols = ('RADeg', 'decDeg', 'SNR', 'rArcmin', 'inFlux', 'outFlux', 'noiseLevel', 'tileName')
+    allInputCatalogs = []
+    for modelCount, model in enumerate(sourceInjectionModelList):
+        if verbose:
+            print(">>> Source injection model: %d/%d" % (modelCount + 1, len(sourceInjectionModelList)))
+        got = collected[model['label']] = {k: [] for k in cols}
+        for i in range(numIterations):
+            if verbose:
+                print(">>> Source injection and recovery test %d/%d [rank = %d]" % (i + 1, numIterations, config.rank))
+            if 'GNFWParams' not in config.parDict.keys():
+                config.parDict['GNFWParams'] = 'default'
+            for filtDict in config.parDict['mapFilters']:
+                filtDict['params']['GNFWParams'] = config.parDict['GNFWParams']
+                for key in ['saveFilteredMaps', 'savePlots']:
+                    filtDict['params'][key] = False
+            # only the reference filter is run (:1973-1979; without a photFilter the last filter listed is what is left)
+            for filtDict in config.parDict['mapFilters']:
+                if filtDict['label'] == config.parDict['photFilter']:
+                    break
+            config.parDict['mapFilters'] = [filtDict]
+
+            if filtDict['class'].find("ArnaudModel") != -1:
+                amplitudeRange = config.parDict.get('sourceInjectionAmplitudeRange', [0.001, 10])
+                if amplitudeRange == 'auto':
+                    amplitudeRange = [np.asarray(realCatalog['fixed_y_c']).min() * 0.5, np.asarray(realCatalog['fixed_y_c']).max()]
+                distribution = config.parDict.get('sourceInjectionDistribution', 'linear')
+                extra = {'GNFWParams': config.parDict['GNFWParams'], 'profile': 'A10'}
+            elif filtDict['class'].find("Beam") != -1:
+                amplitudeRange = config.parDict.get('sourceInjectionAmplitudeRange', [1, 1000])
+                distribution = config.parDict.get('sourceInjectionDistribution', 'log')
+                extra = {'profile': None}
+            else:
+                raise Exception("Don't know how to generate injected source catalogs for filterClass '%s'" % (filtDict['class']))
+            mockCatalog = catalogs.generateTestCatalog(config, numSourcesPerTile, amplitudeColumnName=fluxCol,
+                                                       amplitudeRange=amplitudeRange, amplitudeDistribution=distribution,
+                                                       selFn=areaMasks, maskDilationPix=20, tileNames=areaMasks.tileNames)
+            if config.MPIEnabled == True and config.size > 1:
+                import torch.distributed as dist
+                parts = [None] * config.size
+                dist.all_gather_object(parts, {k: np.asarray(mockCatalog[k]) for k in mockCatalog.keys()})
+                mockCatalog = catalogs.vstack([catalogs.Table(cols=p) for p in parts if len(p['RADeg']) > 0])
+                if len(mockCatalog) > 0:
+                    mockCatalog['name'] = np.arange(0, len(mockCatalog)) + 1
+            if 'theta500Arcmin' in model.keys() and len(mockCatalog) > 0:
+                mockCatalog['theta500Arcmin'] = model['theta500Arcmin']
+            injectSources = dict(extra, catalog=mockCatalog, override=model)
+            allInputCatalogs.append(mockCatalog)
+            for mapDict in config.unfilteredMapsDictList:
+                mapDict['injectSources'] = injectSources
+            if len(mockCatalog) == 0:
+                continue
+            recCatalog = pipelines.filterMapsAndMakeCatalogs(config, useCachedFilters=True, useCachedRMSMap=True,
+                                                             writeAreaMask=False, writeFlagMask=False, verbose=False)
+            if len(recCatalog) > 0:
+                recCatalog = catalogs.removeCrossMatched(recCatalog, realCatalog, radiusArcmin=realExclusionRadiusArcmin)
+            if len(recCatalog) > 0:
+                x_mockCatalog, x_recCatalog, rDeg = catalogs.crossMatch(mockCatalog, recCatalog, radiusArcmin=realExclusionRadiusArcmin)
+                # a bright point source recovered far from where it went in (:2068-2084; the reference would write debugging
+                # region files there through names it never defines)
+                if clusterMode == False and np.logical_and(rDeg > 1.5 / 60, np.asarray(x_recCatalog['SNR']) > 10).sum() > 0:
+                    msg = "Caught recovered source at large offset"
+                    if config.parDict.get('haltOnPositionRecoveryProblem', False) == True:
+                        raise Exception(msg)
+                    print("... Warning: %s ..." % (msg))
+                got['RADeg'] += np.asarray(x_recCatalog['RADeg']).tolist()
+                got['decDeg'] += np.asarray(x_recCatalog['decDeg']).tolist()
+                got['SNR'] += np.asarray(x_recCatalog[SNRCol]).tolist()
+                got['rArcmin'] += (rDeg * 60).tolist()
+                got['inFlux'] += np.asarray(x_mockCatalog[fluxCol]).tolist()
+                got['outFlux'] += np.asarray(x_recCatalog[fluxCol]).tolist()
+                got['noiseLevel'] += np.asarray(x_recCatalog[noiseLevelCol]).tolist()
+                got['tileName'] += np.asarray(x_recCatalog['tileName']).astype(str).tolist()
+
+    models, theta500s = [], []
+    out = {k: [] for k in cols}
+    for model in sourceInjectionModelList:
+        got = collected[model['label']]
+        if 'theta500Arcmin' in model.keys():
+            theta500s += [model['theta500Arcmin']] * len(got['SNR'])
+        models += [model['label']] * len(got['SNR'])
+        for k in cols:
+            out[k] += got[k]
+    resultsTable = catalogs.Table()
+    resultsTable['RADeg'] = np.array(out['RADeg'], dtype=np.float64)
+    resultsTable['decDeg'] = np.array(out['decDeg'], dtype=np.float64)
+    resultsTable['sourceInjectionModel'] = np.array(models, dtype='U30') if models else np.zeros(0, dtype='U30')
+    if len(theta500s) == len(resultsTable):
+        resultsTable['theta500Arcmin'] = np.array(theta500s, dtype=np.float64)
+    for k in ('SNR', 'rArcmin', 'inFlux', 'outFlux', 'noiseLevel'):
+        resultsTable[SNRCol if k == 'SNR' else k] = np.array(out[k], dtype=np.float64)
+    resultsTable['tileName'] = np.array(out['tileName'], dtype='U30') if out['tileName'] else np.zeros(0, dtype='U30')
+
+    if config.rank == 0 and config.selFnDir is not None:                                   # :2142-2148
+        nonEmpty = [c for c in allInputCatalogs if len(c) > 0]
+        if len(nonEmpty) > 0:
+            allInputTab = catalogs.vstack([c.copy() for c in nonEmpty])
+            allInputTab['inFlux'] = allInputTab[fluxCol]
+            allInputTab.remove_column(fluxCol)
+            allInputTab = catalogs.removeCrossMatched(allInputTab, realCatalog, radiusArcmin=realExclusionRadiusArcmin)
+            os.makedirs(config.selFnDir, exist_ok=True)
+            catalogs.writeCatalog(allInputTab, config.selFnDir + os.path.sep + "sourceInjectionInputCatalog.fits")
+    config.restoreConfig()
+    return resultsTable

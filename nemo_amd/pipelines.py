@@ -422,6 +422,11 @@ def _filterMapsAndMakeCatalogs(config, rootOutDir=None, useCachedFilters=False, 
                 # the reference filter object of an earlier pass, still holding its cube in HBM (the reference rereads
                 # diagnostics/<tile>/filter_<label>#<tile>.fits; that file is used when present)
                 tileCache[('cachedFilter', config.cachedFilters[tileName].label)] = config.cachedFilters[tileName]
+            if useCachedRMSMap == True and photFilter is not None and \
+                    not any(f['params'].get('saveFilteredMaps', False) == True for f in filtersList):
+                # the S/N map of this pass comes from the cached noise map (below) and nothing keeps the pass's own noise map:
+                # it is not computed (the reference computes it and drops it; every output is unchanged)
+                tileCache['discardRMS'] = True
             lanes, groupSize = _scaleGrouping(config, tileName, len(filtersList))
             def filteredScales():
                 # the filters of this tile, `groupSize` of them per library call (filters.filterMapsGroup); with

@@ -118,13 +118,22 @@ def make_workload_tiled(tileShape, tilesPerGPU, numFreqs, seed, dtype):
     return out, wcs, tileDefs
 
 
-def make_config(mapsList, numScales, tileDefs=None):
-    """The DR5 cluster-search configuration (examples/ACT-DR5-clusters/DR5ClusterSearch.yml:26-38,82-129) over in-memory maps."""
+INJECTION_MODELS = [{'redshift': 0.8, 'M500': 2.0e+14}, {'redshift': 0.4, 'M500': 2.0e+14}, {'redshift': 0.2, 'M500': 2.0e+14},
+                    {'redshift': 0.1, 'M500': 2.0e+14}]          # examples/ACT-DR6-clusters/DR6ClusterSearch.yml:221-229
+
+
+def make_config(mapsList, numScales, tileDefs=None, inject=False):
+    """The DR5 cluster-search configuration (examples/ACT-DR5-clusters/DR5ClusterSearch.yml:26-38,82-129) over in-memory maps;
+    ``inject``: with the source-injection keys of the DR6 configuration (one iteration per call of maps.sourceInjectionTest)."""
     from nemo_amd import startUp
     parDict = {'unfilteredMaps': [dict(m) for m in mapsList], 'thresholdSigma': 4.0, 'minObjPix': 1, 'findCenterOfMass': True,
                'useInterpolator': True, 'optimalCatalogMethod': 'ref-forced', 'rejectBorder': 0, 'objIdent': 'ACT-CL',
                'longNames': False, 'photFilter': PHOT_FILTER, 'mapFilters': filter_list(numScales), 'useTiling': False,
                'outputDir': None}
+    if inject:
+        parDict.update({'sourceInjectionIterations': 1, 'sourcesPerTile': 50, 'sourceInjectionDistribution': 'linear',
+                        'sourceInjectionAmplitudeRange': [0.001, 10],
+                        'sourceInjectionModels': [dict(m) for m in INJECTION_MODELS]})
     if tileDefs is not None:
         parDict.update({'useTiling': True, 'tileDefinitions': tileDefs, 'tileOverlapDeg': 1.0})
     return startUp.NemoConfig(parDict, makeOutputDirs=False, verbose=False)
@@ -144,6 +153,19 @@ def run_step(config):
     if len(cat) > 0:
         cat['name']          # names are formatted lazily: make them part of the timed work
     return cat
+
+
+def run_inject_step(config, realCatalog, areaMasks):
+    """One iteration of the injection / recovery loop (maps.sourceInjectionTest, nemo/maps.py:1856-2153) over this rank's
+    tiles: for each of the four DR6 injection models a catalogue is drawn and painted into the maps, the maps are filtered
+    again with the cached reference filter and noise map, objects are found, measured and matched to what went in."""
+    from nemo_amd import maps as pmaps
+    keep = config.size
+    config.size = 1            # (every rank injects into its own tiles: nothing is exchanged inside the loop)
+    try:
+        return pmaps.sourceInjectionTest(config, realCatalog=realCatalog, areaMasks=areaMasks, verbose=False)
+    finally:
+        config.size = keep
 
 
 def _cpu_run(procs, size, faithful):
@@ -213,6 +235,9 @@ def main():
     ap.add_argument("--tiles-per-gpu", type=int, default=1, help="tiles each GPU filters per step (with --tile)")
     ap.add_argument("--freqs", type=int, default=1, choices=[1, 2, 3], help="frequency maps per tile (with --tile)")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--mode", default="search", choices=["search", "inject"],
+                    help="search: the cluster search (headline).  inject: config C5's injection / recovery loop - with --tile, "
+                         "e.g. --mode inject --tile 480x3240 --freqs 3 --tiles-per-gpu 4 (a step = 4 injection models x the tiles)")
     ap.add_argument("--cpu-procs", type=int, default=-1, help="processes for the CPU baseline (0 = skip; -1 = auto)")
     ap.add_argument("--cpu-size", type=int, default=2048)
     ap.add_argument("--no-profile", action="store_true", help="do not record per-entry-point HIP events")
@@ -237,10 +262,13 @@ def main():
     torch.cuda.set_device(local % torch.cuda.device_count())
     lib = _lib.load()
     tiled = args.tile is not None
+    inject = args.mode == "inject"
+    if inject and not tiled:
+        raise SystemExit("--mode inject needs --tile HxW (e.g. 480x3240)")
     if tiled:
         shape = tuple(int(v) for v in args.tile.lower().split('x'))
         mapsList, wcs, tileDefs = make_workload_tiled(shape, args.tiles_per_gpu, args.freqs, 1234 + rank, args.dtype)
-        config = make_config(mapsList, args.scales, tileDefs)
+        config = make_config(mapsList, args.scales, tileDefs, inject=inject)
     else:
         shape = (args.size, args.size)
         mapsList, wcs, truth = make_workload(shape, 1234 + rank, args.dtype)
@@ -250,6 +278,17 @@ def main():
     config.rank, config.size = rank, world
     N, S = len(mapsList), len(config.parDict['mapFilters'])
     T = len(config.tileNames)
+    step = lambda: run_step(config)      # noqa: E731
+    if inject:
+        # set-up, untimed: the search pass of the reference filter alone leaves what the loop reuses - the filter cube, the noise
+        # map and the area mask of every tile in HBM - and the catalogue of real objects
+        from nemo_amd import catalogs
+        config.parDict['mapFilters'] = [f for f in config.parDict['mapFilters'] if f['label'] == PHOT_FILTER]
+        config._origParDict = config._copyParDict(config.parDict)
+        realCatalog = pipelines.filterMapsAndMakeCatalogs(config, verbose=False, writeAreaMask=True)
+        areaMasks = catalogs.AreaMasks.fromConfig(config)
+        S = len(INJECTION_MODELS)         # re-filters per tile and step
+        step = lambda: run_inject_step(config, realCatalog, areaMasks)      # noqa: E731
     if tiled:
         for tn in config.tileNames:
             cs = config.tileCoordsDict[tn]['clippedSection']
@@ -280,7 +319,7 @@ def main():
     # 1200 event pairs per step cost ~2 ms of queue time, which would be measured as lost throughput.
     survey = {}
     for k in range(args.warmup):
-        cat = run_step(config)
+        cat = step()
     if not args.no_profile:
         # the SURVEY step: one more untimed step after the warm-up in which every entry point records its event pair.  It runs
         # one scale at a time on one stream, detection included (scaleLanes / scaleGroup 1, asyncDetection off), so that an
@@ -292,12 +331,16 @@ def main():
         keepSched = {k: config.parDict.get(k, None) for k in ('scaleLanes', 'scaleGroup', 'asyncDetection')}
         config.parDict['scaleLanes'], config.parDict['scaleGroup'] = 1, (1 if not tiled else 16)
         config.parDict['asyncDetection'] = False
-        cat = run_step(config)
+        if inject:
+            config._origParDict['asyncDetection'] = False
+        cat = step()
         for k, v in keepSched.items():
             if v is None:
                 config.parDict.pop(k, None)
             else:
                 config.parDict[k] = v
+        if inject:
+            config._origParDict.pop('asyncDetection', None)
         barrier()
         survey = read_profile()
         lib.nf_profile_enable(0)
@@ -309,7 +352,7 @@ def main():
         lib.nf_profile_enable(1)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        cat = run_step(config)
+        cat = step()
     barrier()
     elapsed = time.perf_counter() - t0
     tmax = torch.tensor([elapsed], dtype=torch.float64, device='cuda' if (world == 1 or dist.get_backend() == 'nccl') else 'cpu')
@@ -338,6 +381,17 @@ def main():
                                       "pixel-window undo, findObjects 4 sigma" % (S),
                           "tile": list(shape), "frequencies": N, "scales": S, "tiles_per_gpu": T,
                           "objects_in_optimal_catalog": int(len(cat))}}
+        if inject:
+            out["config"]["workload"] = ("C5 injection / recovery loop: %d tiles of %dx%d (1 deg overlap included) per GPU, %d frequency "
+                                         "map(s); a step = maps.sourceInjectionTest over %d injection models x 1 iteration: draw 50 "
+                                         "clusters per tile, paint them into the maps, re-filter with the cached reference filter "
+                                         "and noise map (no filter build, no noise map), pixel-window undo, findObjects 4 sigma, "
+                                         "measureFluxes, cross-match" % (T, shape[0], shape[1], N, S))
+            out["config"]["scales"] = 1
+            out["config"]["injection_models"] = S
+            out["config"].pop("objects_in_optimal_catalog")
+            out["config"]["recovered_rows_last_step"] = int(len(cat))
+            out["refilters_per_s"] = round(S * T * args.steps * world / elapsed, 2)
         if kernels:
             if dom is None:
                 dom = max(kernels, key=lambda k: kernels[k]['ms_total'])

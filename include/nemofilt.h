@@ -230,6 +230,15 @@ int nf_sn_chunks(int H, int W);
  * (float32) where that is positive. */
 int nf_sn_cached(int vtype, const void* data_d, const float* rms_d, double* sn_d, long long n, void* stream);
 
+/* The tail of buildAndApply followed by the driver's cached-noise branch, in one pass (nemo/filters.py:725-748 then
+ * nemo/pipelines.py:243-247; the re-filters of maps.sourceInjectionTest, nemo/maps.py:2047-2049): filtered_d is masked in place
+ * as nf_finalize masks it, maskOut_d is nf_finalize's, and sn_d (float64) = the masked filtered map divided by the cached
+ * noise map cachedRms_d (float32, not modified) where that is positive.  This pass's own noise map - which the reference
+ * computes (nemo/filters.py:717) and the driver then drops - is not made.  snChunkRange_d / zeroRows_d as for nf_finalize. */
+int nf_finalize_cached(int vtype, void* filtered_d, const float* cachedRms_d, const unsigned char* surveyMask_d,
+                       const unsigned char* psMask_d, const unsigned char* edgeCheck_d, double* sn_d, unsigned char* maskOut_d,
+                       int H, int W, int apodPix, int mulSurvey, unsigned long long* snChunkRange_d, int* zeroRows_d, void* stream);
+
 /* nemo/filters.py:99-101: data[ref == 0] = 0 after the pixel-window deconvolution. */
 int nf_restore_zeros(int vtype, void* data_d, const void* ref_d, long long n, void* stream);
 
@@ -281,6 +290,12 @@ int nf_paint_catalog(float* out_d, int H, int W, int nObj, const double* obj_d, 
  * fractional source positions yIdx_d[H2] x xIdx_d[W2] (outside the grid: the edge value) -> out_d [N, H2, W2]. */
 int nf_resample_bilinear(const float* in_d, float* out_d, int N, int H, int W, int H2, int W2, const double* yIdx_d,
                          const double* xIdx_d, void* stream);
+
+/* Source injection, nemo/maps.py:341-344: out = base + (weights == 0 ? 0 : model), n pixels; base / model float32 or float64
+ * (NF_F32 / NF_F64), out_d float32 when both are float32, else float64 (numpy's promotion); weights_d (wType) may be NULL;
+ * base_d is not modified (out_d may be base_d when the types agree). */
+int nf_inject_model(int baseType, const void* base_d, int modelType, const void* model_d, int wType, const void* weights_d,
+                    void* out_d, long long n, void* stream);
 
 /* nemo/maps.py:435-437 (subtract != 0: data -= model, flagMask += (model > 1); flagMask_d may be NULL) and :344 (subtract == 0:
  * data += model). */

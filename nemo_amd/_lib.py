@@ -97,6 +97,9 @@ SIGNATURES = {
                             c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'nf_sn_chunks': (c_int, [c_int, c_int]),
     'nf_sn_cached': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_ll, c_void_p]),
+    'nf_finalize_cached': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                   c_int, c_void_p, c_void_p, c_void_p]),
+    'nf_inject_model': (c_int, [c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_ll, c_void_p]),
     'nf_restore_zeros': (c_int, [c_int, c_void_p, c_void_p, c_ll, c_void_p]),
     'nf_subtract': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_ll, c_void_p]),
     'nf_convolve2d': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),

@@ -632,13 +632,57 @@ class AreaMasks(object):
         return self._valid[key]
 
 
+def _drawTilePositions(ys, xs, wcs, numSourcesPerTile, avoidanceRadiusArcmin, referenceStream):
+    """Sky positions of up to ``numSourcesPerTile`` objects on the valid pixels (ys, xs) of one tile, each candidate a
+    uniformly drawn valid pixel plus a uniform sub-pixel offset, kept when farther than the avoidance radius from every
+    object kept before it (nemo/catalogs.py:901-925).
+
+    ``referenceStream``: consume the global ``np.random`` stream exactly as the reference does - two offsets and one index per
+    VALID PIXEL of the tile (1.5 million draws x 3 for a DR6 tile, ~30 ms), of which the loop then visits a few hundred -
+    so that a seeded stream reproduces the reference's catalogue.  Otherwise candidates are drawn in batches as they are
+    needed: the same distribution from far fewer draws (the injection loop's default; its host time would otherwise exceed
+    the GPU's re-filter time forty-fold)."""
+    n = len(ys)
+    tileRAs, tileDecs = [], []
+    if referenceStream:
+        ysj = ys + np.random.uniform(0, 1, n)
+        xsj = xs + np.random.uniform(0, 1, n)
+        indices = np.random.randint(0, n, n)
+
+        def batches():
+            # the reference converts xs[indices], ys[indices] and then reads entry i of THAT list for i in indices (:905-912)
+            for a in range(0, n, 512):
+                pick = indices[indices[a:a + 512]]
+                yield wcs.pix2wcs(xsj[pick], ysj[pick])
+    else:
+        def batches():
+            tried = 0
+            size = max(64, 4 * numSourcesPerTile)
+            while tried < n:
+                pick = np.random.randint(0, n, size)
+                yield wcs.pix2wcs(xs[pick] + np.random.uniform(0, 1, size), ys[pick] + np.random.uniform(0, 1, size))
+                tried += size
+    for ra, dec in batches():
+        ra, dec = np.atleast_1d(ra), np.atleast_1d(dec)
+        for rai, deci in zip(ra.tolist(), dec.tolist()):
+            if len(tileRAs) > 0 and not calcAngSepDeg(rai, deci, np.array(tileRAs), np.array(tileDecs)).min() * 60 > avoidanceRadiusArcmin:
+                continue
+            tileRAs.append(rai)
+            tileDecs.append(deci)
+            if len(tileRAs) == numSourcesPerTile:
+                return tileRAs, tileDecs
+    return tileRAs, tileDecs
+
+
 def generateTestCatalog(config, numSourcesPerTile, amplitudeColumnName='fixed_y_c', amplitudeRange=[0.001, 1],
-                        amplitudeDistribution='linear', selFn=None, avoidanceRadiusArcmin=20.0, maskDilationPix=0, tileNames=None):
+                        amplitudeDistribution='linear', selFn=None, avoidanceRadiusArcmin=20.0, maskDilationPix=0, tileNames=None,
+                        referenceStream=True):
     """Objects at random positions inside the area masks with random amplitudes (nemo/catalogs.py:849-947); at most
-    ``numSourcesPerTile`` per tile, none closer than ``avoidanceRadiusArcmin`` to an earlier one of its tile.  Draws from the
-    global ``np.random`` stream in the reference's order (two jitters per valid pixel, one index per valid pixel, then the
-    amplitudes), so that a seeded stream gives the reference's catalogue; only the positions the loop visits are converted to
-    sky coordinates.  ``selFn``: anything with ``tileNames`` / ``areaMaskDict`` / ``WCSDict`` (:class:`AreaMasks`)."""
+    ``numSourcesPerTile`` per tile, none closer than ``avoidanceRadiusArcmin`` to an earlier one of its tile.  With
+    ``referenceStream`` (the default here; maps.sourceInjectionTest turns it off unless the configuration asks) the global
+    ``np.random`` stream is consumed in the reference's order, so a seeded stream gives the reference's catalogue
+    (tests/golden/injection.npz); see :func:`_drawTilePositions`.  ``selFn``: anything with ``tileNames`` / ``areaMaskDict`` /
+    ``WCSDict`` (:class:`AreaMasks`)."""
     if selFn is None:
         selFn = AreaMasks.fromConfig(config, tileNames=tileNames)
     if tileNames is None:
@@ -646,38 +690,23 @@ def generateTestCatalog(config, numSourcesPerTile, amplitudeColumnName='fixed_y_
     RAs, decs, amps, catTileNames = [], [], [], []
     for tileName in tileNames:
         mapData = selFn.areaMaskDict[tileName]
-        if np.asarray(mapData).sum() == 0:                       # :895
-            continue
-        wcs = selFn.WCSDict[tileName]
         if hasattr(selFn, 'validPixels'):
             ys, xs = selFn.validPixels(tileName, maskDilationPix)
+            empty = len(ys) == 0
         else:
-            ys, xs = np.where(_dilatedAreaMask(mapData, maskDilationPix))
-        if len(ys) == 0:              # nothing left after the dilation (the reference's randint(0, 0) would raise here)
+            empty = np.asarray(mapData).sum() == 0                      # :895
+            if not empty:
+                ys, xs = np.where(_dilatedAreaMask(mapData, maskDilationPix))
+        if empty or len(ys) == 0:         # nothing (left after the dilation; the reference's randint(0, 0) would raise there)
             continue
-        ys = ys + np.random.uniform(0, 1, len(ys))
-        xs = xs + np.random.uniform(0, 1, len(xs))
-        indices = np.random.randint(0, len(ys), len(ys))
-        # the reference converts xs[indices], ys[indices] and then reads entry i of THAT list for i in indices (:905-912)
-        tileRAs, tileDecs, keepIndices = [], [], []
-        for i in indices:
-            rai, deci = wcs.pix2wcs(xs[indices[i]], ys[indices[i]])
-            rai, deci = float(rai), float(deci)
-            keepObj = True
-            if len(tileRAs) > 0:
-                keepObj = calcAngSepDeg(rai, deci, np.array(tileRAs), np.array(tileDecs)).min() * 60 > avoidanceRadiusArcmin
-            if keepObj:
-                tileRAs.append(rai)
-                tileDecs.append(deci)
-                keepIndices.append(i)
-            if len(keepIndices) == numSourcesPerTile:
-                break
+        tileRAs, tileDecs = _drawTilePositions(ys, xs, selFn.WCSDict[tileName], numSourcesPerTile, avoidanceRadiusArcmin,
+                                               referenceStream)
         RAs = RAs + tileRAs
         decs = decs + tileDecs
         if amplitudeDistribution == 'linear':
-            amp = np.random.uniform(amplitudeRange[0], amplitudeRange[1], len(keepIndices))
+            amp = np.random.uniform(amplitudeRange[0], amplitudeRange[1], len(tileRAs))
         elif amplitudeDistribution == 'log':
-            amp = np.power(10, np.random.uniform(np.log10(amplitudeRange)[0], np.log10(amplitudeRange)[1], len(keepIndices)))
+            amp = np.power(10, np.random.uniform(np.log10(amplitudeRange)[0], np.log10(amplitudeRange)[1], len(tileRAs)))
         else:
             raise Exception("Must be either 'linear' or 'log'.")
         amps = amps + amp.tolist()

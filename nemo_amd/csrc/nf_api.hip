@@ -557,6 +557,28 @@ int nf_finalize(int vtype, void* filtered, const float* rms, const unsigned char
                         snChunkRange, zeroRows, S(stream));
 }
 
+int nf_finalize_cached(int vtype, void* filtered, const float* cachedRms, const unsigned char* surveyMask, const unsigned char* psMask,
+                       const unsigned char* edgeCheck, double* sn, unsigned char* maskOut, int H, int W, int apodPix, int mulSurvey,
+                       unsigned long long* snChunkRange, int* zeroRows, void* stream) {
+    if (!filtered || !cachedRms || !sn || !maskOut || H < 1 || W < 1 || (vtype != NF_F32 && vtype != NF_F64)) {
+        nf_set_error("nf_finalize_cached: bad arguments");
+        return NF_ERR_ARG;
+    }
+    nf::ProfScope ps(nf::PT_FINALIZE, S(stream), (double)H * W * ((vtype == NF_F32 ? 4.0 : 8.0) + 4.0 + 3.0 + 8.0 + 1.0));
+    return nf::finalize_cached(vtype, filtered, cachedRms, surveyMask, psMask, edgeCheck, sn, maskOut, H, W, apodPix, mulSurvey,
+                               snChunkRange, zeroRows, S(stream));
+}
+
+int nf_inject_model(int baseType, const void* base, int modelType, const void* model, int wType, const void* weights, void* out,
+                    long long n, void* stream) {
+    if (!base || !model || !out || n < 1 || (baseType != NF_F32 && baseType != NF_F64) || (modelType != NF_F32 && modelType != NF_F64) ||
+        (weights && wType != NF_F32 && wType != NF_F64)) {
+        nf_set_error("nf_inject_model: bad arguments");
+        return NF_ERR_ARG;
+    }
+    return nf::inject_model(baseType, base, modelType, model, wType, weights, out, n, S(stream));
+}
+
 int nf_sn_chunks(int H, int W) { return (H < 1 || W < 1) ? 0 : nf_div_up((long long)H * W, NF_SN_CHUNK); }
 
 int nf_restore_zeros(int vtype, void* data, const void* ref, long long n, void* stream) {

@@ -68,6 +68,11 @@ int disc_apply(int rtype, void* data, const void* bck, unsigned char* surveyMask
 int paint_catalog(float* out, int H, int W, int nObj, const double* obj, const int* win, const double* geom, const double* prof,
                   int ntab, int accumulate, hipStream_t s);
 int add_model(int rtype, void* data, const float* model, unsigned char* flagMask, long long n, int subtract, hipStream_t s);
+int inject_model(int baseType, const void* base, int modelType, const void* model, int wType, const void* weights, void* out, long long n,
+                 hipStream_t s);
+int finalize_cached(int vtype, void* filtered, const float* rms, const unsigned char* surveyMask, const unsigned char* psMask,
+                    const unsigned char* edgeCheck, double* snOut, unsigned char* maskOut, int H, int W, int apodPix, int mulSurvey,
+                    unsigned long long* chunkRange, int* zeroRows, hipStream_t s);
 
 // nf_noise.hip
 struct NoiseGrid {

@@ -658,6 +658,85 @@ int finalize(int vtype, void* filtered, const float* rms, const unsigned char* s
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Tail of buildAndApply followed by the driver's cached-noise branch (nemo/filters.py:725-748 then nemo/pipelines.py:243-247), for
+// the re-filters of an injection run: the masks exactly as k_finalize forms them, no noise map of this pass, and
+//   SN (float64) = filtered' / cachedRMS where cachedRMS > 0, else filtered'      (filtered' = the masked filtered map)
+template <typename VT>
+__global__ void __launch_bounds__(256) k_finalize_cached(VT* __restrict__ filtered, const float* __restrict__ rms,
+                                                         const unsigned char* __restrict__ surveyMask, const unsigned char* __restrict__ psMask,
+                                                         const unsigned char* __restrict__ edgeCheck, double* __restrict__ snOut,
+                                                         unsigned char* __restrict__ maskOut, int H, int W, int apodPix, int mulSurvey,
+                                                         unsigned long long* __restrict__ chunkRange, int nchunks, int* __restrict__ zeroRows) {
+    const long long n = (long long)H * W;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wavesPerWG = blockDim.x >> 6;
+    for (long long c = (long long)blockIdx.x * wavesPerWG + wave; c < nchunks; c += (long long)gridDim.x * wavesPerWG) {
+        double mx = -INFINITY, mn = INFINITY;
+        const unsigned p0 = (unsigned)c * NF_SN_CHUNK + (unsigned)lane;
+        int y = (int)(p0 / (unsigned)W), x = (int)(p0 - (unsigned)y * (unsigned)W);
+        const int ay = min(apodPix, H), ax = min(apodPix, W);
+#pragma unroll 4
+        for (int it = 0; it < NF_SN_CHUNK / 64; ++it) {
+            const unsigned p = p0 + (unsigned)it * 64u;
+            if (it > 0) {
+                x += 64;
+                while (x >= W) {
+                    x -= W;
+                    ++y;
+                }
+            }
+            if (p >= (unsigned)n) continue;
+            const VT fIn = filtered[p];
+            VT f = fIn;
+            unsigned char e = edgeCheck ? edgeCheck[p] : (unsigned char)1;
+            unsigned char sm = (unsigned char)(e * (surveyMask ? surveyMask[p] : 1) * (psMask ? psMask[p] : 1));
+            f = f * (VT)e;
+            if (mulSurvey) f = f * (VT)sm;
+            bool inside = (ay <= 0 || (y >= ay - 1 && y <= H - ay)) && (ax <= 0 || (x >= ax - 1 && x <= W - ax));
+            if (f != fIn || f != f) filtered[p] = f;
+            if (zeroRows != nullptr && f == (VT)0) zeroRows[y] = 1;
+            double sn = (double)f;
+            const float r = rms[p];
+            if (r > 0.0f) sn = sn / (double)r;
+            snOut[p] = sn;
+            maskOut[p] = inside ? sm : (unsigned char)0;
+            // (a NaN never exceeds a threshold: it stays out of the chunk's range, as fmax / fmin leave it out)
+            mx = fmax(mx, sn);
+            mn = fmin(mn, sn);
+        }
+        if (chunkRange != nullptr) {
+            for (int off = 32; off > 0; off >>= 1) {
+                mx = fmax(mx, __shfl_xor(mx, off, 64));
+                mn = fmin(mn, __shfl_xor(mn, off, 64));
+            }
+            if (lane == 0) {
+                chunkRange[c] = nf_ordered_key(mx);
+                chunkRange[nchunks + c] = nf_ordered_key(mn);
+            }
+        }
+    }
+}
+
+int finalize_cached(int vtype, void* filtered, const float* rms, const unsigned char* surveyMask, const unsigned char* psMask,
+                    const unsigned char* edgeCheck, double* snOut, unsigned char* maskOut, int H, int W, int apodPix, int mulSurvey,
+                    unsigned long long* chunkRange, int* zeroRows, hipStream_t s) {
+    if ((long long)H * W >= 2147483647LL) {
+        nf_set_error("finalize_cached: map too large for 32-bit pixel indices");
+        return NF_ERR_SIZE;
+    }
+    const int nchunks = nf_div_up((long long)H * W, NF_SN_CHUNK);
+    if (zeroRows != nullptr) NF_HIP(hipMemsetAsync(zeroRows, 0, (size_t)H * sizeof(int), s));
+    dim3 g(grid_for((long long)nchunks * 64, 256)), b(256);
+    if (vtype == NF_F64)
+        hipLaunchKernelGGL(k_finalize_cached<double>, g, b, 0, s, (double*)filtered, rms, surveyMask, psMask, edgeCheck, snOut, maskOut, H,
+                           W, apodPix, mulSurvey, chunkRange, nchunks, zeroRows);
+    else
+        hipLaunchKernelGGL(k_finalize_cached<float>, g, b, 0, s, (float*)filtered, rms, surveyMask, psMask, edgeCheck, snOut, maskOut, H, W,
+                           apodPix, mulSurvey, chunkRange, nchunks, zeroRows);
+    NF_CHECK_LAUNCH("k_finalize_cached");
+    return NF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // zero-restore after the pixel-window deconvolution (nemo/filters.py:99-101): out = (ref == 0) ? 0 : in
 template <typename VT>
 __global__ void k_restore_zeros(VT* __restrict__ data, const VT* __restrict__ ref, long long n) {

@@ -293,6 +293,38 @@ int add_model(int rtype, void* data, const float* model, unsigned char* flagMask
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Source injection (nemo/maps.py:341-344): modelMap[weights == 0] = 0; data = data + modelMap - with numpy's promotion
+// (float32 + float32 stays float32; a float64 operand makes the sum float64).  `base` is left as it is: an injection run
+// paints thousands of catalogues into the same preprocessed tile.
+template <typename TB, typename TM, typename TO>
+__global__ void k_inject_model(const TB* __restrict__ base, const TM* __restrict__ model, const void* __restrict__ weights, int wIsF64,
+                               TO* __restrict__ out, long long n) {
+    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x) {
+        bool dead = false;
+        if (weights != nullptr) dead = wIsF64 ? (((const double*)weights)[p] == 0.0) : (((const float*)weights)[p] == 0.0f);
+        const TO m = dead ? (TO)0 : (TO)model[p];
+        out[p] = (TO)base[p] + m;
+    }
+}
+
+int inject_model(int baseType, const void* base, int modelType, const void* model, int wType, const void* weights, void* out, long long n,
+                 hipStream_t s) {
+    long long gl = (n + 255) / 256;
+    dim3 g((unsigned)(gl > 8192 ? 8192 : gl)), b(256);
+    const int w64 = wType == NF_F64 ? 1 : 0;
+    if (baseType == NF_F32 && modelType == NF_F32)
+        hipLaunchKernelGGL((k_inject_model<float, float, float>), g, b, 0, s, (const float*)base, (const float*)model, weights, w64, (float*)out, n);
+    else if (baseType == NF_F32)
+        hipLaunchKernelGGL((k_inject_model<float, double, double>), g, b, 0, s, (const float*)base, (const double*)model, weights, w64, (double*)out, n);
+    else if (modelType == NF_F32)
+        hipLaunchKernelGGL((k_inject_model<double, float, double>), g, b, 0, s, (const double*)base, (const float*)model, weights, w64, (double*)out, n);
+    else
+        hipLaunchKernelGGL((k_inject_model<double, double, double>), g, b, 0, s, (const double*)base, (const double*)model, weights, w64, (double*)out, n);
+    NF_CHECK_LAUNCH("k_inject_model");
+    return NF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // MatchedFilter.reshapeFilter (nemo/filters.py:793-817): the float32 filter planes sampled by linear interpolation at
 // fractional index positions yIdx[y'] / xIdx[x'] of the source grid (positions outside it take the edge value).
 __global__ void k_resample_bilinear(const float* __restrict__ in, float* __restrict__ out, int H, int W, int H2, int W2,

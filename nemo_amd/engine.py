@@ -444,7 +444,7 @@ class TileEngine(object):
             self._axisWin[key] = tabs
         return self._axisWin[key]
 
-    def apply_window(self, m, pow, zero_ref=None):
+    def apply_window(self, m, pow, zero_ref=None, zeroRows=None):
         """enmap.apply_window(m, pow): real [H,W] (or [N,H,W]) maps in, real maps of the same dtype out.  The window is a product
         of a function of ky and one of kx: two 1-D circular filters, one pass over the map each (nf_axis_filter); the 2-D
         transform pair with the window fused into the inverse's load where a side's length needs Bluestein's algorithm.
@@ -472,7 +472,7 @@ class TileEngine(object):
         check(self.lib.nf_axis_filter(self.plan, prec, 1, ptr(m3), ty, ptr(out), ty, m3.shape[0], ptr(tabs[1]), None, None, stream_ptr()),
               "nf_axis_filter")
         check(self.lib.nf_axis_filter(self.plan, prec, 0, ptr(out), ty, ptr(out), ty, m3.shape[0], ptr(tabs[0]), ptr(zero_ref),
-                                      None, stream_ptr()), "nf_axis_filter")
+                                      ptr(zeroRows) if zero_ref is not None else None, stream_ptr()), "nf_axis_filter")
         return out.reshape(m.shape)
 
     # ---- templates -----------------------------------------------------------------------------------------
@@ -671,6 +671,33 @@ class TileEngine(object):
         self.lastSNChunks = (sn, snChunks)
         return filtered, sn, rmsOut, maskOut
 
+    def finalize_cached(self, filtered, cachedRMS, surveyMask, psMask, edgeCheck, mulSurvey):
+        """nf_finalize_cached: the masks of :meth:`finalize` and the S/N map of the driver's cached-noise branch in one pass.
+        Returns (filtered map masked in place, float64 S/N map, mask, rows-with-a-zero table for the window undo)."""
+        t = self.t
+        sn = t.empty((self.H, self.W), dtype=t.float64, device=self.dev)
+        maskOut = t.empty((self.H, self.W), dtype=t.uint8, device=self.dev)
+        snChunks = t.empty(2 * ((self.npix + 1023) // 1024), dtype=t.int64, device=self.dev)
+        zeroRows = t.empty(self.H, dtype=t.int32, device=self.dev)
+        check(self.lib.nf_finalize_cached(prec_of(filtered), ptr(filtered), ptr(cachedRMS), ptr(surveyMask), ptr(psMask), ptr(edgeCheck),
+                                          ptr(sn), ptr(maskOut), self.H, self.W, self.APOD_PIX, 1 if mulSurvey else 0, ptr(snChunks),
+                                          ptr(zeroRows), stream_ptr()), "nf_finalize_cached")
+        self.lastSNChunks = (sn, snChunks)
+        return filtered, sn, maskOut, zeroRows
+
+    def inject_model(self, base, model, weights=None, out=None):
+        """nf_inject_model: base + (weights == 0 ? 0 : model) with numpy's dtype promotion (nemo/maps.py:341-344); ``base`` is
+        not modified.  ``out``: a contiguous map of the promoted dtype to write into."""
+        t = self.t
+        odt = t.float32 if (base.dtype == t.float32 and model.dtype == t.float32) else t.float64
+        if out is None:
+            out = t.empty((self.H, self.W), dtype=odt, device=self.dev)
+        elif out.dtype != odt or not out.is_contiguous():
+            raise NemoFiltError("inject_model: out must be a contiguous map of the promoted dtype")
+        check(self.lib.nf_inject_model(prec_of(base), ptr(base), prec_of(model), ptr(model), prec_of(weights) if weights is not None else 0,
+                                       ptr(weights), ptr(out), self.npix, stream_ptr()), "nf_inject_model")
+        return out
+
     def sn_cached(self, data, rms32):
         """nemo/pipelines.py:244-247: float64 S/N map from a filtered map and a cached float32 RMS map."""
         t = self.t
@@ -678,10 +705,11 @@ class TileEngine(object):
         check(self.lib.nf_sn_cached(prec_of(data), ptr(data), ptr(rms32), ptr(sn), self.npix, stream_ptr()), "nf_sn_cached")
         return sn
 
-    def undo_pixel_window(self, data):
+    def undo_pixel_window(self, data, zeroRows=None):
         """filterMaps' last step (nemo/filters.py:98-101): apply_window(data, -1), zeros of ``data`` kept (restored while the
-        inverse transform stores its rows)."""
-        return self.apply_window(data, -1.0, zero_ref=data)
+        inverse transform stores its rows).  ``zeroRows``: the rows-with-a-zero table nf_finalize / nf_finalize_cached made for
+        this very map (the zero reference is then looked up in those rows only)."""
+        return self.apply_window(data, -1.0, zero_ref=data, zeroRows=zeroRows)
 
     def ifft_half_epi(self, X, filtSym=None, sum=False, window=None, unitary=False, out='f32', scale=None, mask=None,
                       zero_ref=None, clobber=False):

@@ -73,6 +73,7 @@ def filterMapsGroup(unfilteredMapsDictList, filterParamsList, tileName, diagnost
         filterClass = _FILTER_CLASSES[f['class']]
         objs.append(filterClass(f['label'], unfilteredMapsDictList, f['params'], tileName=tileName,
                                 diagnosticsDir=diagnosticsDir, selFnDir=selFnDir, tileCache=tileCache))
+        objs[-1]._verbose = verbose
     results = [None] * len(objs)
     k = 0
     while k < len(objs):
@@ -204,15 +205,25 @@ class MapFilter(object):
         if shared is not None and 'dFlagMask' in shared:
             self._dFlagMask = shared['dFlagMask']
         else:
-            self._dFlagMask = None
-            for mapDict, i in zip(self.unfilteredMapsDictList, range(len(self.unfilteredMapsDictList))):
-                term = engine.to_dev(mapDict['flagMask']).to(t.int32) * (i + 1)
-                self._dFlagMask = term if self._dFlagMask is None else self._dFlagMask + term
-            if shared is not None:
-                shared['dFlagMask'] = self._dFlagMask
+            # (an injection run hands over the same flag masks pass after pass - maps.MapDict's '_preprocCache': their sum is kept)
+            runCache = self.unfilteredMapsDictList[0].get('_preprocCache', None)
+            fkey = ('flagSum', tileName) + tuple(id(m['flagMask']) for m in self.unfilteredMapsDictList)
+            held = runCache.get(fkey) if runCache is not None else None
+            if held is not None:
+                self._dFlagMask, flagAny = held[0], held[1]
+            else:
+                self._dFlagMask = None
+                for mapDict, i in zip(self.unfilteredMapsDictList, range(len(self.unfilteredMapsDictList))):
+                    term = engine.to_dev(mapDict['flagMask']).to(t.int32) * (i + 1)
+                    self._dFlagMask = term if self._dFlagMask is None else self._dFlagMask + term
                 # "does the tile have any flagged pixel": asked once per tile on the device, read by photometry.findObjects
                 # together with its first fetch - a tile without flags needs no flag lookups at the objects
-                shared['flagAny'] = (self._dFlagMask, (self._dFlagMask != 0).any().to(t.float64).reshape(1))
+                flagAny = (self._dFlagMask, (self._dFlagMask != 0).any().to(t.float64).reshape(1))
+                if runCache is not None and all(hasattr(m['flagMask'], 'is_cuda') for m in self.unfilteredMapsDictList):
+                    runCache[fkey] = (self._dFlagMask, flagAny, [m['flagMask'] for m in self.unfilteredMapsDictList])
+            if shared is not None:
+                shared['dFlagMask'] = self._dFlagMask
+                shared['flagAny'] = flagAny
         self._flagMaskHost = None
 
         # Beam solid angles in nanosteradians (nemo/filters.py:170-189)
@@ -428,15 +439,19 @@ class MapFilter(object):
     def _finish(self, dFiltered, trimSizePix, fourierVariant):
         """Noise map, S/N, edge trim, masks (nemo/filters.py:716-756 / :1111-1157); all on the device."""
         eng = self.engine
-        if self._tileCache is not None and self._tileCache.get('discardRMS', False):
-            # the driver replaces the S/N map with filtered / cached noise map and never reads this pass's noise map
-            # (nemo/pipelines.py:234-250, the re-filters of maps.sourceInjectionTest): the noise map is not made, 'RMSMap' is zero
-            rms = engine.torch().zeros(self.shape, dtype=engine.torch().float32, device=eng.dev)
-        else:
-            rms = self._noiseMapDevice(dFiltered)
         edge = None
         if trimSizePix > 0:
             edge = eng.edge_check(dFiltered, self._dPSMask, trimSizePix)
+        cachedRMS = self._tileCache.get('cachedRMS', None) if self._tileCache is not None else None
+        if cachedRMS is not None:
+            # The driver replaces the S/N map of this pass with filtered / cached noise map and never reads the pass's own noise
+            # map (nemo/pipelines.py:234-250, the re-filters of maps.sourceInjectionTest): that S/N map is made here, together
+            # with the masks, and no noise map is computed; 'RMSMap' of the result is the cached one.
+            data, sn, mask, zeroRows = eng.finalize_cached(dFiltered, cachedRMS, self._dSurveyMask, self._dPSMask, edge, fourierVariant)
+            self._snChunks = eng.lastSNChunks
+            self._cachedTail = zeroRows
+            return data, sn, cachedRMS, mask, trimSizePix > 0
+        rms = self._noiseMapDevice(dFiltered)
         data, sn, rmsOut, mask = eng.finalize(dFiltered, rms, self._dSurveyMask, self._dPSMask, edge, fourierVariant)
         self._snChunks = eng.lastSNChunks
         return data, sn, rmsOut, mask, trimSizePix > 0
@@ -457,6 +472,8 @@ class MapFilter(object):
                    'SNMap': _asnumpy(sn).astype(np.result_type(_asnumpy(sn).dtype, mdt)),
                    'RMSMap': _asnumpy(rms).astype(np.result_type(np.float32, mdt)),
                    'surveyMask': _asnumpy(mask).astype(mdt)}
+        if getattr(self, '_cachedTail', None) is not None:
+            out['_snFromCachedRMS'], out['_zeroRows'] = True, self._cachedTail
         out.update({'wcs': self.wcs, 'obsFreqGHz': combinedObsFreqGHz,
                     'flagMask': self._dFlagMask if RETURN_DEVICE_ARRAYS else self.flagMask, 'mapUnits': mapUnits,
                     'beamSolidAngle_nsr': beamSolidAngle_nsr, 'label': self.label, 'tileName': self.tileName})
@@ -478,7 +495,11 @@ class MatchedFilter(MapFilter):
         shared = self._shared
         if shared is not None and 'fMapsToFilter' in shared:
             return shared['fMapsToFilter']
-        dCube = t.stack(self._dData).contiguous() if N > 1 else self._dData[0].reshape(1, *self.shape)
+        views = [m.get('_cubeView', None) for m in self.unfilteredMapsDictList]
+        if all(v is not None and v[0] is views[0][0] and v[1] == i for i, v in enumerate(views)) and views[0][0].shape[0] == N:
+            dCube = views[0][0]            # an injection run wrote this pass's maps into one cube already (maps.MapDict)
+        else:
+            dCube = t.stack(self._dData).contiguous() if N > 1 else self._dData[0].reshape(1, *self.shape)
         fMapsToFilter = self.engine.fft(dCube, apod=True, half=True)                      # :523-526  K1+K2
         if shared is not None:
             shared['fMapsToFilter'] = fMapsToFilter
@@ -686,6 +707,8 @@ class MatchedFilter(MapFilter):
             cached = self._tileCache.get(('cachedFilter', self.label), None)
             if cached is not None and tuple(cached.shape) == tuple(self.shape):
                 self._dFilt, self._signalNorm, self.fRelWeights = cached._dFilt, cached._signalNorm, dict(cached.fRelWeights.items())
+                cached._filtFor(True)                    # (the symmetrised form is made once, on the kept object)
+                self._dFiltSymOf = cached._dFiltSymOf
         if haveFile == False and useCachedFilter == False:
             noiseCov = self._noiseCovariance(fMapsToFilter)
 
@@ -754,7 +777,8 @@ class MatchedFilter(MapFilter):
                 raise Exception('need to specify "outputUnits" ("yc" or "uK") in filter params')
             del fSignals
         else:
-            print("... loading cached filter")
+            if getattr(self, '_verbose', True):
+                print("... loading cached filter")
             if self._dFilt is None or haveFile:
                 self.loadFilter()
             self.params['saveRMSMap'] = False

@@ -90,6 +90,17 @@ class MapDict(dict):
             if k in self and self[k] not in (None, False):
                 raise NotImplementedError("MapDict key '%s' (nemo/maps.py:252-262,294-323,346-379) is not part of this build" % (k))
         onDevice = any(k in self and self[k] is not None for k in _DEVICE_KEYS)
+        # An injection run preprocesses the same tile thousands of times with nothing changed but the catalogue to paint in
+        # (maps.sourceInjectionTest): what comes before the catalogue steps is kept in HBM, per tile, in the dictionary the
+        # run hung on its maps ('_preprocCache'), and is never written to afterwards.
+        cache = self.get('_preprocCache', None) if onDevice else None
+        ckey = ('tile', tileName, self.get('label', None), self.get('obsFreqGHz', None))
+        if cache is not None and ckey in cache:
+            data, weights, wcs, surveyMask, psMask, flagMask = cache[ckey]
+            data, surveyMask, psMask, flagMask = self._catalogueSteps(data, weights, wcs, surveyMask, psMask, flagMask, tileName,
+                                                                      sharedInputs=True)
+            self._setPreprocessed(data, weights, wcs, surveyMask, psMask, flagMask, tileName)
+            return
         data, wcs = self.loadTile('mapFileName', tileName, returnWCS=True)
         if onDevice:
             data = engine.to_dev(data)
@@ -145,7 +156,16 @@ class MapDict(dict):
             if data.shape[0] == 0 or data.shape[1] == 0:
                 raise Exception("Clipping using RADecSection returned empty array - check RADecSection in config .yml file is in map")
         if onDevice:
-            data, surveyMask, psMask, flagMask = self._catalogueSteps(data, weights, wcs, surveyMask, psMask, flagMask, tileName)
+            if cache is not None:
+                t = engine.torch()
+                cache[ckey] = (data.contiguous(), weights, wcs, surveyMask.to(t.uint8).contiguous(), psMask.to(t.uint8).contiguous(),
+                               flagMask.to(t.uint8).contiguous())
+                data, weights, wcs, surveyMask, psMask, flagMask = cache[ckey]
+            data, surveyMask, psMask, flagMask = self._catalogueSteps(data, weights, wcs, surveyMask, psMask, flagMask, tileName,
+                                                                      sharedInputs=cache is not None)
+        self._setPreprocessed(data, weights, wcs, surveyMask, psMask, flagMask, tileName)
+
+    def _setPreprocessed(self, data, weights, wcs, surveyMask, psMask, flagMask, tileName):
         self['data'] = data
         self['weights'] = weights
         self['wcs'] = wcs
@@ -166,28 +186,43 @@ def _holeTable(entry):
     return entry
 
 
-def _mapDictCatalogueSteps(self, data, weights, wcs, surveyMask, psMask, flagMask, tileName):
+def _mapDictCatalogueSteps(self, data, weights, wcs, surveyMask, psMask, flagMask, tileName, sharedInputs=False):
     """nemo/maps.py:325-465 on device tensors: source injection, the median-filtered background, holes at catalogue
-    positions (masked in both masks, filled with the background), model subtraction with its flag."""
+    positions (masked in both masks, filled with the background), model subtraction with its flag.  ``sharedInputs``: the
+    tensors handed in belong to the tile cache of an injection run and are not written to (steps that work in place get
+    copies)."""
     t = engine.torch()
     from . import catalogs
     eng = engine.TileEngine.get(tuple(data.shape))
     shape = tuple(data.shape)
     data = data.contiguous()
-    surveyMask = surveyMask.to(t.uint8).contiguous().clone()
-    psMask = psMask.to(t.uint8).contiguous().clone()
-    flagMask = flagMask.to(t.uint8).contiguous().clone()
+    inPlaceSteps = any(self.get(h) is not None for h in ['maskPointSourcesFromCatalog', 'maskAndFillFromCatalog', 'subtractModelFromCatalog'])
+    if not sharedInputs or inPlaceSteps:
+        surveyMask = surveyMask.to(t.uint8).contiguous().clone()
+        psMask = psMask.to(t.uint8).contiguous().clone()
+        flagMask = flagMask.to(t.uint8).contiguous().clone()
+    dataIsShared = sharedInputs
     if self.get('injectSources') is not None:                                     # :326-344
         inj = self['injectSources']
         GNFWParams, obsFreqGHz = (inj['GNFWParams'], self['obsFreqGHz']) if 'GNFWParams' in inj.keys() else (None, None)
         valid = self.tileCoordsDict[tileName]['areaMaskInClipSection'] if self.tileCoordsDict is not None else None
+        # (the object windows and their haversine tables are the same for every frequency map of a tile: kept with the request)
         modelMap = makeModelImage(shape, wcs, inj['catalog'], self['beamFileName'], obsFreqGHz=obsFreqGHz, GNFWParams=GNFWParams,
-                                  profile=inj['profile'], validAreaSection=valid, override=inj['override'])
+                                  profile=inj['profile'], validAreaSection=valid, override=inj['override'],
+                                  _geomCache=inj.setdefault('_paintCache', {}))
         if modelMap is not None:
-            modelMap = t.where(weights == 0, t.zeros((), dtype=modelMap.dtype, device=modelMap.device), modelMap)
-            data = (data + modelMap).contiguous()           # dtype promotes as numpy's does (float64 model in the override branch)
-    holeFilling = any(h in self.keys() for h in ['maskPointSourcesFromCatalog', 'maskAndFillFromCatalog', 'extendedMask'])
-    if holeFilling:                                                               # :360-368
+            # modelMap[weights == 0] = 0; data = data + modelMap - one pass, into a new map (or into this map's plane of the cube
+            # the run keeps for the tile's frequency maps); dtype promotes as numpy's does (float64 model in the override branch)
+            data = eng.inject_model(data, modelMap.contiguous(), weights if weights.dtype in (t.float32, t.float64) else weights.to(t.float64),
+                                    out=self._injectionPlane(tileName, shape, data.dtype, modelMap.dtype))
+            dataIsShared = False
+    if dataIsShared and inPlaceSteps:
+        data = data.clone()
+    # The reference takes the median background whenever one of these keys EXISTS (:360-368) - and startUp puts
+    # 'maskPointSourcesFromCatalog': None into every map dictionary (nemo/startUp.py:43-50), so it always does.  The background
+    # is only read where holes are cut (:419-424, 459-465): it is made when a catalogue will cut some.
+    holeFilling = any(self.get(h) is not None for h in ['maskPointSourcesFromCatalog', 'maskAndFillFromCatalog', 'extendedMask'])
+    if holeFilling:
         pixRad = (10.0 / 60.0) / wcs.getPixelSizeDeg()
         bckData = eng.median_filter(data, int(pixRad))
     if self.get('maskPointSourcesFromCatalog') is not None:                       # :383-424
@@ -251,7 +286,25 @@ def _mapDictCatalogueSteps(self, data, weights, wcs, surveyMask, psMask, flagMas
     return data, surveyMask, psMask, flagMask
 
 
+def _mapDictInjectionPlane(self, tileName, shape, dataDtype, modelDtype):
+    """Where the injected map of this frequency is written in an injection run: plane '_planeIndex' of a cube [N, H, W] kept per
+    tile in '_preprocCache' - the filter then transforms the cube as it is instead of stacking N maps again.  None outside such a
+    run (a new map is made)."""
+    cache, index = self.get('_preprocCache', None), self.get('_planeIndex', None)
+    if cache is None or index is None:
+        return None
+    t = engine.torch()
+    odt = t.float32 if (dataDtype == t.float32 and modelDtype == t.float32) else t.float64
+    key = ('cube', tileName, tuple(shape), odt)
+    if key not in cache:
+        cache[key] = t.empty((int(self['_numPlanes']),) + tuple(shape), dtype=odt, device=engine.require_gpu())
+    cube = cache[key]
+    self['_cubeView'] = (cube, int(index))
+    return cube[int(index)]
+
+
 MapDict._catalogueSteps = _mapDictCatalogueSteps
+MapDict._injectionPlane = _mapDictInjectionPlane
 
 
 def degreesDistanceBox(shape, wcs, RADeg, decDeg, maxDistDegrees):
@@ -278,15 +331,26 @@ def _modelObjects(catalog, beam, obsFreqGHz, GNFWParams, profile, override, TCMB
     from . import signals
     out = []
     keys = catalog.keys()
+    RAs, decs = np.asarray(catalog['RADeg'], dtype=np.float64).tolist(), np.asarray(catalog['decDeg'], dtype=np.float64).tolist()
     if 'y_c' in keys or 'true_y_c' in keys:
         kind = {'A10': 'arnaud', 'B12': 'battaglia'}.get(profile)
         if kind is None:
             raise Exception("Didn't understand profile - should be A10 or B12.")
         gp = 'default' if GNFWParams in (None, 'default') else GNFWParams
+        if override is not None:
+            # one model for every row (:1752-1758): one table, one size, one spectral factor - only the amplitudes differ
+            z, M500 = override['redshift'], override['M500']
+            theta500Arcmin = signals.calcTheta500Arcmin(z, M500, cosmoModel)
+            maxSizeDeg = 5 * (theta500Arcmin / 60)
+            base = signals.clusterModelTable(kind, beam, z, M500, gp, 1.0, maxSizeDeg, baseOnly=True)
+            factors = None
+            if obsFreqGHz is not None:
+                factors = (float(signals.fSZ(obsFreqGHz, TCMBAlpha=TCMBAlpha, z=z)), signals.TCMB * 1e6)
+            for RADeg, decDeg, y_c in zip(RAs, decs, np.asarray(catalog['y_c'], dtype=np.float64).tolist()):
+                out.append((RADeg, decDeg, signals.scaledTable(base, float(y_c * 1e-4)), maxSizeDeg, factors))
+            return out
         for row in catalog:
-            if override is not None:
-                z, M500, y0 = override['redshift'], override['M500'], row['y_c'] * 1e-4
-            elif 'true_M500c' in keys:
+            if 'true_M500c' in keys:
                 M500, z, y0 = row['true_M500c'] * 1e14, row['redshift'], row['true_y_c'] * 1e-4
             else:
                 if 'template' not in keys:
@@ -298,7 +362,7 @@ def _modelObjects(catalog, beam, obsFreqGHz, GNFWParams, profile, override, TCMB
                 if z == 0:
                     raise Exception("z = 0 template? template = %s, tileName = %s" % (row['template'], row['tileName']))
             theta500Arcmin = signals.calcTheta500Arcmin(z, M500, cosmoModel)
-            maxSizeDeg = (5 if override is not None else maxSizeDegMultiplier) * (theta500Arcmin / 60)
+            maxSizeDeg = maxSizeDegMultiplier * (theta500Arcmin / 60)
             table = signals.clusterModelTable(kind, beam, z, M500, gp, float(y0), maxSizeDeg)
             factors = None
             if obsFreqGHz is not None:
@@ -306,8 +370,8 @@ def _modelObjects(catalog, beam, obsFreqGHz, GNFWParams, profile, override, TCMB
             out.append((row['RADeg'], row['decDeg'], table, maxSizeDeg, factors))
     else:
         base = signals.templateTables('beam', beam, {}, amplitude=1.0)       # nemo/signals.py:595-627; one table, many amplitudes
-        for row in catalog:
-            out.append((row['RADeg'], row['decDeg'], signals.scaledTable(base, row['deltaT_c']), 1.0, None))
+        for RADeg, decDeg, amp in zip(RAs, decs, np.asarray(catalog['deltaT_c'], dtype=np.float64).tolist()):
+            out.append((RADeg, decDeg, signals.scaledTable(base, amp), 1.0, None))
     return out
 
 
@@ -325,7 +389,7 @@ def modelWindow(shape, wcs, RADeg, decDeg, maxSizeDeg):
 
 def makeModelImage(shape, wcs, catalog, beamFileName, obsFreqGHz=None, GNFWParams='default', profile='A10', cosmoModel=None,
                    applyPixelWindow=True, override=None, validAreaSection=None, minSNR=-99, TCMBAlpha=0, reportTimingInfo=False,
-                   maxSizeDegMultiplier=5, useInferredSZProperties=False):
+                   maxSizeDegMultiplier=5, useInferredSZProperties=False, _geomCache=None):
     """Map of model clusters / point sources at the catalogue's positions (nemo/maps.py:1658-1853), float32, on the device;
     None when no object lies inside the map.  The painter is this build's (signals.RadialTable + nf_paint_catalog): every
     object inside its own +- maxSizeDeg window, summed in float32 in catalogue order."""
@@ -349,11 +413,18 @@ def makeModelImage(shape, wcs, catalog, beamFileName, obsFreqGHz=None, GNFWParam
     objects = _modelObjects(catalog, beam, obsFreqGHz, GNFWParams, profile, override, TCMBAlpha, maxSizeDegMultiplier, cosmoModel)
     perObjectFactors = override is None          # the override branch converts the summed map instead (:1786-1788)
     objs, wins, geomParts, profTabs, profIndex, off = [], [], [], [], {}, 0
+    tileKey = (tuple(shape), wcs._crval1, wcs._crpix1, wcs._crpix2, wcs._cdelt1, wcs._cdelt2)
     for RADeg, decDeg, table, maxSizeDeg, factors in objects:
-        wx0, wx1, wy0, wy1 = modelWindow(shape, wcs, RADeg, decDeg, maxSizeDeg)
-        A, B, C = signals.paintGeometry(shape, wcs, RADeg, decDeg)
+        gkey = (tileKey, float(RADeg), float(decDeg), float(maxSizeDeg))
+        held = _geomCache.get(gkey) if _geomCache is not None else None
+        if held is None:
+            win = modelWindow(shape, wcs, RADeg, decDeg, maxSizeDeg)
+            held = (win, signals.paintGeometry(shape, wcs, RADeg, decDeg, window=win))
+            if _geomCache is not None:
+                _geomCache[gkey] = held
+        (wx0, wx1, wy0, wy1), (A, B, C) = held
         nrow, ncol = wy1 - wy0, wx1 - wx0
-        geomParts += [A[wy0:wy1], B[wy0:wy1], C[wx0:wx1]]
+        geomParts += [A, B, C]
         pid = profIndex.get(id(table.prof))
         if pid is None:
             pid = profIndex[id(table.prof)] = len(profTabs)
@@ -559,7 +630,9 @@ def sourceInjectionTest(config, realCatalog=None, areaMasks=None, verbose=True):
     ``realCatalog``: the catalogue of the real run - rows near its objects are left out (:2057-2059); read from
     <rootOutDir>/<name>_optimalCatalog.fits as in the reference when not given.  ``areaMasks``: a catalogs.AreaMasks (made from
     the area masks of the last pass, in memory or under selFn/, when not given).  With several ranks every rank draws the
-    objects of its own tiles and the rows are exchanged (the reference draws all of them on rank 0 and broadcasts, :2030-2035)."""
+    objects of its own tiles and the rows are exchanged (the reference draws all of them on rank 0 and broadcasts, :2030-2035).
+    Configuration key of this build: ``sourceInjectionReferenceStream`` (default False) - draw the catalogues from ``np.random``
+    with the reference's own (much longer) sequence of draws, see catalogs.generateTestCatalog."""
     from . import signals, catalogs, pipelines
     realExclusionRadiusArcmin = 5.0
     if verbose:
@@ -589,6 +662,9 @@ def sourceInjectionTest(config, realCatalog=None, areaMasks=None, verbose=True):
     if areaMasks is None:
         areaMasks = catalogs.AreaMasks.fromConfig(config)
 
+    preprocCache = {}       # per tile: the preprocessed maps before the catalogue steps, the cube the injected maps are written to
+    for k, mapDict in enumerate(config.unfilteredMapsDictList):
+        mapDict['_preprocCache'], mapDict['_planeIndex'], mapDict['_numPlanes'] = preprocCache, k, len(config.unfilteredMapsDictList)
     collected = {}          # model label -> lists per output column
     cols = ('RADeg', 'decDeg', 'SNR', 'rArcmin', 'inFlux', 'outFlux', 'noiseLevel', 'tileName')
     allInputCatalogs = []
@@ -625,7 +701,8 @@ def sourceInjectionTest(config, realCatalog=None, areaMasks=None, verbose=True):
                 raise Exception("Don't know how to generate injected source catalogs for filterClass '%s'" % (filtDict['class']))
             mockCatalog = catalogs.generateTestCatalog(config, numSourcesPerTile, amplitudeColumnName=fluxCol,
                                                        amplitudeRange=amplitudeRange, amplitudeDistribution=distribution,
-                                                       selFn=areaMasks, maskDilationPix=20, tileNames=areaMasks.tileNames)
+                                                       selFn=areaMasks, maskDilationPix=20, tileNames=areaMasks.tileNames,
+                                                       referenceStream=config.parDict.get('sourceInjectionReferenceStream', False))
             if config.MPIEnabled == True and config.size > 1:
                 import torch.distributed as dist
                 parts = [None] * config.size

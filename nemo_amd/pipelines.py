@@ -426,7 +426,7 @@ def _filterMapsAndMakeCatalogs(config, rootOutDir=None, useCachedFilters=False, 
                     not any(f['params'].get('saveFilteredMaps', False) == True for f in filtersList):
                 # the S/N map of this pass comes from the cached noise map (below) and nothing keeps the pass's own noise map:
                 # it is not computed (the reference computes it and drops it; every output is unchanged)
-                tileCache['discardRMS'] = True
+                tileCache['cachedRMS'] = _loadCachedRMSMap(config, tileName, photFilter)
             lanes, groupSize = _scaleGrouping(config, tileName, len(filtersList))
             def filteredScales():
                 # the filters of this tile, `groupSize` of them per library call (filters.filterMapsGroup); with
@@ -467,10 +467,11 @@ def _filterMapsAndMakeCatalogs(config, rootOutDir=None, useCachedFilters=False, 
                         fitsio.writeFITS(rmsDir + os.path.sep + "RMSMap_%s#%s.fits" % (photFilter, tileName),
                                          filteredMapDict['RMSMap'].cpu().numpy(), {})
                 if useCachedRMSMap == True and photFilter is not None:            # nemo/pipelines.py:234-250
-                    RMSMap = _loadCachedRMSMap(config, tileName, photFilter)
                     eng = engine.TileEngine.get(tuple(filteredMapDict['data'].shape))
-                    filteredMapDict['SNMap'] = eng.sn_cached(filteredMapDict['data'], RMSMap)
-                    filteredMapDict['data'] = eng.undo_pixel_window(filteredMapDict['data'])
+                    if not filteredMapDict.get('_snFromCachedRMS', False):          # (else the filter's tail made it already)
+                        RMSMap = _loadCachedRMSMap(config, tileName, photFilter)
+                        filteredMapDict['SNMap'] = eng.sn_cached(filteredMapDict['data'], RMSMap)
+                    filteredMapDict['data'] = eng.undo_pixel_window(filteredMapDict['data'], zeroRows=filteredMapDict.get('_zeroRows'))
                 if 'saveFilteredMaps' in f['params'] and f['params']['saveFilteredMaps'] == True:
                     t = engine.torch()
                     config.stitchedFilteredMapDict[tileName] = filteredMapDict['data'].to(t.float32)

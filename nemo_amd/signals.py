@@ -101,7 +101,21 @@ def calcR500Mpc(z, M500c, cosmoModel):
     return calcRDeltaMpc(z, M500c, cosmoModel, delta=500, wrt='critical')
 
 
+_theta500Cache = {}
+
+
 def calcTheta500Arcmin(z, M500, cosmoModel):
+    """(kept per (z, M500, cosmology): maps.makeModelImage asks once per catalogue row, an injection run for the same few
+    models thousands of times)"""
+    key = (float(z), float(M500), id(cosmoModel))
+    if key not in _theta500Cache:
+        if len(_theta500Cache) > 4096:
+            _theta500Cache.clear()
+        _theta500Cache[key] = _calcTheta500Arcmin(z, M500, cosmoModel)
+    return _theta500Cache[key]
+
+
+def _calcTheta500Arcmin(z, M500, cosmoModel):
     """nemo/signals.py:429-447."""
     R500Mpc = calcR500Mpc(z, M500, cosmoModel)
     return np.degrees(np.arctan(R500Mpc / cosmoModel.angular_diameter_distance(1 / (1 + z)))) * 60.0
@@ -377,11 +391,18 @@ def makeRadialTable(tckP, beam=None, amplitude=None, maxSizeDeg=10.0, convolveWi
     return table
 
 
-def paintGeometry(shape, wcs, RADeg, decDeg):
+def paintGeometry(shape, wcs, RADeg, decDeg, window=None):
     """Per-row / per-column haversine tables shared verbatim by the oracle painter and the GPU painter:
-    hav(theta) = A[y] + B[y] * C[x].  Painter semantics are ours (pixell.pointsrcs.sim_objects is absent)."""
-    dec = wcs.rowDecRad()[:shape[0]]
-    ra = wcs.colRARad()[:shape[1]]
+    hav(theta) = A[y] + B[y] * C[x].  Painter semantics are ours (pixell.pointsrcs.sim_objects is absent).
+    ``window`` = (x0, x1, y0, y1): only the tables' slices A[y0:y1], B[y0:y1], C[x0:x1] (the same values element for element:
+    every step is elementwise)."""
+    if window is None:
+        dec = wcs.rowDecRad()[:shape[0]]
+        ra = wcs.colRARad()[:shape[1]]
+    else:
+        x0, x1, y0, y1 = window
+        dec = wcs.rowDecRad()[y0:y1]
+        ra = wcs.colRARad()[x0:x1]
     dec0 = np.radians(decDeg)
     ra0 = np.radians(RADeg)
     dra = (ra - ra0 + np.pi) % (2 * np.pi) - np.pi
@@ -394,7 +415,7 @@ def paintGeometry(shape, wcs, RADeg, decDeg):
 _modelProfileCache = {}
 
 
-def clusterModelTable(kind, beam, z, M500, GNFWParams, amplitude, maxSizeDeg):
+def clusterModelTable(kind, beam, z, M500, GNFWParams, amplitude, maxSizeDeg, baseOnly=False):
     """Radial table of one model cluster of maps.makeModelImage (nemo/maps.py:1821-1831 -> make*ModelSignalMap,
     nemo/signals.py:751-770): the beam-convolved projected GNFW profile out to ``maxSizeDeg``, central amplitude ``amplitude``."""
     beam = _asBeam(beam)
@@ -409,6 +430,8 @@ def clusterModelTable(kind, beam, z, M500, GNFWParams, amplitude, maxSizeDeg):
     if base is None:
         base = _modelProfileCache[key] = makeRadialTable(_profileCache[ckey]['tckP'], beam=beam, amplitude=1.0,
                                                          maxSizeDeg=float(maxSizeDeg), convolveWithBeam=True, cacheKey=ckey)
+    if baseOnly:
+        return base               # the amplitude-1 table: scaledTable(base, amplitude) gives a row's table
     return scaledTable(base, amplitude)
 
 

@@ -113,12 +113,20 @@ class CARWCS(object):
 
     # -- helpers used by the template painter (tables shared verbatim by oracle and GPU paths) ----
     def rowDecRad(self):
-        H = self.header['NAXIS2']
-        return np.radians((np.arange(H, dtype=np.float64) + 1.0 - self._crpix2) * self._cdelt2)
+        key = ('rowDec', self.header['NAXIS2'], self._crpix2, self._cdelt2)
+        if getattr(self, '_rowDecKey', None) != key:
+            H = self.header['NAXIS2']
+            self._rowDec = np.radians((np.arange(H, dtype=np.float64) + 1.0 - self._crpix2) * self._cdelt2)
+            self._rowDecKey = key
+        return self._rowDec
 
     def colRARad(self):
-        W = self.header['NAXIS1']
-        return np.radians(self._crval1 + (np.arange(W, dtype=np.float64) + 1.0 - self._crpix1) * self._cdelt1)
+        key = ('colRA', self.header['NAXIS1'], self._crval1, self._crpix1, self._cdelt1)
+        if getattr(self, '_colRAKey', None) != key:
+            W = self.header['NAXIS1']
+            self._colRA = np.radians(self._crval1 + (np.arange(W, dtype=np.float64) + 1.0 - self._crpix1) * self._cdelt1)
+            self._colRAKey = key
+        return self._colRA
 
 
 def calcAngSepDeg(RADeg1, decDeg1, RADeg2, decDeg2):

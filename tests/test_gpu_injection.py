@@ -29,7 +29,8 @@ def _cluster_filters():
 def _config(mapsL, mapFilters, photFilter, **extra):
     parDict = {'unfilteredMaps': [dict(m) for m in mapsL], 'thresholdSigma': THRESH, 'minObjPix': 1, 'findCenterOfMass': True,
                'useInterpolator': True, 'optimalCatalogMethod': 'ref-forced', 'rejectBorder': 0, 'objIdent': 'ACT-CL',
-               'longNames': False, 'photFilter': photFilter, 'mapFilters': mapFilters, 'useTiling': False, 'outputDir': None}
+               'longNames': False, 'photFilter': photFilter, 'mapFilters': mapFilters, 'useTiling': False, 'outputDir': None,
+               'sourceInjectionReferenceStream': True}
     parDict.update(extra)
     return startUp.NemoConfig(parDict, makeOutputDirs=False, verbose=False)
 

@@ -382,7 +382,9 @@ int nf_xmatch_self(const double* unit_d, const double* snr_d, int n, double radi
  * results as nf_xmatch_self, but the per-slice partial results live in a file-scope device array of the library (6 MiB on
  * each GPU the library runs on, held until the process ends) instead of a caller workspace, so n is limited to
  * nf_xmatch_static_max_rows() = 16384 rows; more is refused with NF_ERR_SIZE.  The call allocates nothing.  Every call on
- * one GPU shares that GPU's array: calls that overlap on one GPU (two streams, two threads) race - serialise them. */
+ * one GPU shares that GPU's array: calls that overlap on one GPU (two streams, two threads) race - serialise them.
+ * The array's address on a GPU is looked up once per device, by nf_plan_create (any plan) made with that device current - make
+ * one before capturing; a call on a device that never saw nf_plan_create does the look-up itself (not capture-safe). */
 int nf_xmatch_static_max_rows(void);
 int nf_xmatch_self_static(const double* unit_d, const double* snr_d, int n, double radiusDeg, int* count_d, int* best_d,
                           unsigned char* drop_d, int* nearFlag_d, void* stream);
@@ -435,10 +437,15 @@ int nf_spline_eval_batch(int vtype, int nJobs, const void* const* maps_d, const 
  *   the pixel-window undo as two nf_axis_filter passes (tables for pow = -1 as that entry point wants them).
  * Scales are dealt round-robin to nLanes lanes; lane 0 runs on `stream`, the others on streams the library keeps per device,
  * forked from and joined back into `stream` with events - so for the caller the whole call is ordinary work on `stream`.
- * work_d: nLanes device buffers of nf_matched_filter_workspace_bytes(tile) bytes each (256-byte aligned). */
-#define NF_MF_MAXFREQ 8
+ * work_d: nLanes device buffers of nf_matched_filter_workspace_bytes(tile) bytes each (256-byte aligned).
+ * At most nf_matched_filter_max_lanes() lanes are used (4: MI355X boxes give a process 4 hardware queues).  The lane streams
+ * and their events are made once per device, by the first nf_matched_filter_workspace_bytes call on it.  Threads: calls on one
+ * device may come from several host threads - a call holds the device's lane mutex from its fork to its join, so they take turns -
+ * but two calls in flight at once must not share a workspace buffer, and each orders its work by the stream it is given. */
+#define NF_MF_MAXFREQ 8                /* room in the per-frequency arrays of the two structs */
+#define NF_MF_MAXN 6                   /* most frequency maps a call takes: the limit of the filter build (nf_build_filter*) */
 typedef struct nf_mf_tile {
-    int H, W, N;                       /* map shape, number of frequency maps (<= NF_MF_MAXFREQ) */
+    int H, W, N;                       /* map shape, number of frequency maps (<= NF_MF_MAXN; NF_ERR_SIZE beyond) */
     int prec;                          /* NF_F32 / NF_F64: precision of fMaps_d */
     int covType;                       /* NF_F32 / NF_F64: type of noiseCov_d */
     int outputUnits;                   /* 0 = yc, 1 = uK */
@@ -493,6 +500,7 @@ typedef struct nf_mf_scale {
 } nf_mf_scale;
 
 size_t nf_matched_filter_workspace_bytes(const nf_mf_tile* tile);
+int nf_matched_filter_max_lanes(void);
 /* The scalar step between the filtered template and the filtered map, on the device so that the host does not wait for it:
  * outputUnits 0: out_d[0] = y0 / src_d[0] in float64 (nemo/filters.py:659, src_d = spline value of the filtered template at the
  * tile centre); 1: out_d[0] = 1 / float32(src_d[0]) in float32 arithmetic, widened (:684, src_d = nf_map_max result). */

@@ -27,6 +27,7 @@ c_double = ctypes.c_double
 c_size_t = ctypes.c_size_t
 
 NF_MF_MAXFREQ = 8
+NF_MF_MAXN = 6          # most frequency maps nf_matched_filter_scales / nf_build_filter* take
 _PD8 = c_void_p * NF_MF_MAXFREQ
 _D8 = c_double * NF_MF_MAXFREQ
 
@@ -141,6 +142,7 @@ SIGNATURES = {
     'nf_spline_eval': (c_int, [c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     'nf_signal_norm': (c_int, [c_int, c_void_p, c_double, c_void_p, c_void_p]),
     'nf_matched_filter_workspace_bytes': (c_size_t, [ctypes.POINTER(MfTile)]),
+    'nf_matched_filter_max_lanes': (c_int, []),
     'nf_matched_filter_scales': (c_int, [c_void_p, ctypes.POINTER(MfTile), ctypes.POINTER(MfScale), c_int, ctypes.POINTER(c_void_p),
                                          c_int, c_void_p]),
 }

@@ -166,6 +166,14 @@ int nf_plan_create(int H, int W, nf_plan** plan) {
     p->W = W;
     p->haveF = p->haveD = false;
     // (new nf_plan() value-initialises both Plan2D members: numbers and pointers zero, the host tables empty)
+    // set-up that must not happen inside somebody's launch sequence or graph capture: the per-device address of the static
+    // scratch array of nf_xmatch_self_static is resolved here, with this device current (it may load the code object)
+    void* scratch = nullptr;
+    int rc = nf::xmatch_static_scratch(&scratch);
+    if (rc != NF_OK) {
+        delete p;
+        return rc;
+    }
     *plan = p;
     return NF_OK;
 }

@@ -15,6 +15,7 @@ size_t xmatch_workspace_bytes(int n);
 int xmatch_self(const double* u, const double* snr, int n, double lo2, double hi2, int* count, int* best, unsigned char* drop,
                 int* nearFlag, void* work, size_t workBytes, hipStream_t s);
 #define NF_XM_STATIC_MAX_ROWS 16384
+int xmatch_static_scratch(void** ptr);
 int xmatch_self_static(const double* u, const double* snr, int n, double lo2, double hi2, int* count, int* best, unsigned char* drop,
                        int* nearFlag, hipStream_t s);
 int symmetrise_filter(const float* filt, double* filtSym, int N, int H, int W, hipStream_t s);

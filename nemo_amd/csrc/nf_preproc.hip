@@ -176,15 +176,20 @@ int disc_fill(double* rmap, int W, const double* rec, const int* box, int boxPix
 
 int disc_apply(int rtype, void* data, const void* bck, unsigned char* surveyMask, unsigned char* psMask, int W, const double* recs,
                const int* boxes, int nBoxes, double limit, int times60, const double* rmap, hipStream_t s) {
-    if (nBoxes < 1) return NF_OK;
-    dim3 g(16, nBoxes), b(256);
-    if (rtype == NF_F64)
-        hipLaunchKernelGGL(k_disc_apply<double>, g, b, 0, s, (double*)data, (const double*)bck, surveyMask, psMask, W, recs, boxes, limit,
-                           times60, rmap);
-    else
-        hipLaunchKernelGGL(k_disc_apply<float>, g, b, 0, s, (float*)data, (const float*)bck, surveyMask, psMask, W, recs, boxes, limit,
-                           times60, rmap);
-    NF_CHECK_LAUNCH("k_disc_apply");
+    // gridDim.y holds at most 65535 boxes: a longer catalogue goes out in pieces, in catalogue order on the stream
+    for (int b0 = 0; b0 < nBoxes; b0 += 65535) {
+        const int nb = nBoxes - b0 < 65535 ? nBoxes - b0 : 65535;
+        dim3 g(16, nb), b(256);
+        const double* rc = recs + (size_t)b0 * 5;
+        const int* bx = boxes + (size_t)b0 * 4;
+        if (rtype == NF_F64)
+            hipLaunchKernelGGL(k_disc_apply<double>, g, b, 0, s, (double*)data, (const double*)bck, surveyMask, psMask, W, rc, bx, limit,
+                               times60, rmap);
+        else
+            hipLaunchKernelGGL(k_disc_apply<float>, g, b, 0, s, (float*)data, (const float*)bck, surveyMask, psMask, W, rc, bx, limit,
+                               times60, rmap);
+        NF_CHECK_LAUNCH("k_disc_apply");
+    }
     return NF_OK;
 }
 

@@ -65,7 +65,11 @@ Layout layout_of(const nf_mf_tile& t) {
 }
 
 int check_tile(const nf_mf_tile* t) {
-    if (!t || t->H < 1 || t->W < 1 || t->N < 1 || t->N > NF_MF_MAXFREQ || !t->fMaps_d || !t->noiseCov_d || !t->A_d || !t->B_d ||
+    if (t && t->N > NF_MF_MAXN) {
+        nf_set_error("nf_matched_filter_scales: more than NF_MF_MAXN = 6 frequency maps (the limit of the filter build)");
+        return NF_ERR_SIZE;
+    }
+    if (!t || t->H < 1 || t->W < 1 || t->N < 1 || !t->fMaps_d || !t->noiseCov_d || !t->A_d || !t->B_d ||
         !t->C_d || !t->medWeights_d || !t->yEdges_d || !t->xEdges_d || !t->quantiles || t->ny < 1 || t->nx < 1 || t->numBins < 1 ||
         (t->outputUnits != 0 && t->outputUnits != 1) || (t->prec != NF_F32 && t->prec != NF_F64) ||
         ((t->axisWinY_d == nullptr) != (t->axisWinX_d == nullptr))) {
@@ -80,29 +84,39 @@ int check_tile(const nf_mf_tile* t) {
 }
 
 // ---- lanes: streams and events kept per device for the life of the process ------------------------------------
+// All of a device's lane streams and events are made in ONE place, the first time the device asks for its workspace size
+// (nf_matched_filter_workspace_bytes, which every caller makes before its first nf_matched_filter_scales) - never in the
+// middle of a launch sequence.  A call holds the device's mutex from its fork to its join: the fork / done events are shared
+// by all calls on the device, so two host threads enqueueing on one GPU take turns (each call only enqueues: milliseconds).
+#define NF_MF_MAXLANES 4            // lane 0 = the caller's stream + 3 library streams (GPU_MAX_HW_QUEUES is 4 on MI355X boxes)
 struct Lanes {
-    std::vector<hipStream_t> streams;     // lane l >= 1 runs on streams[l - 1]
-    std::vector<hipEvent_t> done;
+    std::mutex mu;                        // held for the whole enqueue of one nf_matched_filter_scales call
+    hipStream_t streams[NF_MF_MAXLANES - 1] = {};     // lane l >= 1 runs on streams[l - 1]
+    hipEvent_t done[NF_MF_MAXLANES - 1] = {};
     hipEvent_t fork = nullptr;
+    bool ready = false;
 };
-std::mutex g_laneMu;
+std::mutex g_laneMu;                      // guards the map only
 std::map<int, Lanes> g_lanes;
 
-int lanes_for(int nLanes, Lanes** out) {
+int lanes_for_device(Lanes** out) {
     int dev = 0;
     NF_HIP(hipGetDevice(&dev));
-    std::lock_guard<std::mutex> lock(g_laneMu);
-    Lanes& L = g_lanes[dev];
-    if (!L.fork) NF_HIP(hipEventCreateWithFlags(&L.fork, hipEventDisableTiming));
-    while ((int)L.streams.size() < nLanes - 1) {
-        hipStream_t s;
-        hipEvent_t e;
-        NF_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-        NF_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        L.streams.push_back(s);
-        L.done.push_back(e);
+    Lanes* L;
+    {
+        std::lock_guard<std::mutex> lock(g_laneMu);
+        L = &g_lanes[dev];                // (std::map nodes never move: the pointer stays good)
     }
-    *out = &L;
+    std::lock_guard<std::mutex> lock(L->mu);
+    if (!L->ready) {
+        NF_HIP(hipEventCreateWithFlags(&L->fork, hipEventDisableTiming));
+        for (int l = 0; l < NF_MF_MAXLANES - 1; ++l) {
+            NF_HIP(hipStreamCreateWithFlags(&L->streams[l], hipStreamNonBlocking));
+            NF_HIP(hipEventCreateWithFlags(&L->done[l], hipEventDisableTiming));
+        }
+        L->ready = true;
+    }
+    *out = L;
     return NF_OK;
 }
 
@@ -222,8 +236,12 @@ extern "C" {
 
 size_t nf_matched_filter_workspace_bytes(const nf_mf_tile* tile) {
     if (check_tile(tile) != NF_OK) return 0;
+    Lanes* lanes = nullptr;
+    if (lanes_for_device(&lanes) != NF_OK) return 0;      // the device's lane streams and events exist from here on
     return layout_of(*tile).total;
 }
+
+int nf_matched_filter_max_lanes(void) { return NF_MF_MAXLANES; }
 
 int nf_signal_norm(int outputUnits, const double* src_d, double y0, double* out_d, void* stream) {
     if (!src_d || !out_d || (outputUnits != 0 && outputUnits != 1)) {
@@ -244,6 +262,7 @@ int nf_matched_filter_scales(nf_plan* plan, const nf_mf_tile* tile, const nf_mf_
     }
     if (nScales == 0) return NF_OK;
     if (nLanes > nScales) nLanes = nScales;
+    if (nLanes > NF_MF_MAXLANES) nLanes = NF_MF_MAXLANES;
     for (int l = 0; l < nLanes; ++l)
         if (!work_d[l] || ((size_t)work_d[l] & 255)) {
             nf_set_error("nf_matched_filter_scales: a lane's workspace is missing or not 256-byte aligned");
@@ -252,8 +271,10 @@ int nf_matched_filter_scales(nf_plan* plan, const nf_mf_tile* tile, const nf_mf_
     const Layout L = layout_of(*tile);
     hipStream_t mainStream = (hipStream_t)stream;
     Lanes* lanes = nullptr;
+    NF_TRY(lanes_for_device(&lanes));
+    // from the fork to the join nobody else records or waits on this device's lane events
+    std::lock_guard<std::mutex> enqueue(lanes->mu);
     if (nLanes > 1) {
-        NF_TRY(lanes_for(nLanes, &lanes));
         NF_HIP(hipEventRecord(lanes->fork, mainStream));
         for (int l = 1; l < nLanes; ++l) NF_HIP(hipStreamWaitEvent(lanes->streams[l - 1], lanes->fork, 0));
     }

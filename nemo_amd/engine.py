@@ -219,8 +219,8 @@ class TileEngine(object):
         self._geomLast = None
         self._geom2 = {}
         self.statsCap = 2048        # room (labels) of the record table of label_and_stats; grows when a map has more
-        self._scaleWork = {}        # workspace bytes -> per-lane buffers of nf_matched_filter_scales
-        self._scaleWorkKeys = []    # per lane: the noiseKey its workspace's noise block tables belong to
+        self._scaleWork = {}        # raw stream handle -> (workspace bytes, per-lane buffers of nf_matched_filter_scales,
+                                    #                       per lane the noiseKey its workspace's noise block tables belong to)
 
     # ---- tables --------------------------------------------------------------------------------------------
     def window(self, pow):
@@ -540,22 +540,24 @@ class TileEngine(object):
         last used under an equal key keeps its noise block tables (``noiseTablesLanes`` of the tile struct)."""
         t = self.t
         n = len(scales)
-        lanes = max(1, min(int(lanes), n))
+        lanes = max(1, min(int(lanes), n, int(self.lib.nf_matched_filter_max_lanes())))
         nbytes = int(self.lib.nf_matched_filter_workspace_bytes(ctypes.byref(tile)))
         if nbytes == 0:
             check(-1, "nf_matched_filter_workspace_bytes")
-        work = self._scaleWork.get(nbytes, [])
+        # the lanes' workspaces belong to the stream the calls are made on (calls on one stream are ordered; two streams - two
+        # host threads - must not share them); one size at a time per stream: another configuration of the shape replaces it
+        sp = stream_ptr()
+        held = self._scaleWork.get(sp.value)
+        if held is None or held[0] != nbytes:
+            held = self._scaleWork[sp.value] = (nbytes, [], [])
+        work, keys = held[1], held[2]
         while len(work) < lanes:
             work.append(t.empty(nbytes, dtype=t.uint8, device=self.dev))
-        if nbytes not in self._scaleWork:
-            self._scaleWorkKeys = []
-        self._scaleWork = {nbytes: work}          # one size at a time: another configuration of the same shape replaces it
-        keys = self._scaleWorkKeys
-        keys.extend([None] * (len(work) - len(keys)))
+            keys.append(None)
         tile.noiseTablesLanes = sum(1 << l for l in range(min(lanes, 32)) if noiseKey is not None and keys[l] == noiseKey)
         keys[:lanes] = [None] * lanes             # (an error below leaves the lanes' tables in an unknown state)
         ptrs = (ctypes.c_void_p * lanes)(*[w.data_ptr() for w in work[:lanes]])
-        check(self.lib.nf_matched_filter_scales(self.plan, ctypes.byref(tile), scales, n, ptrs, lanes, stream_ptr()),
+        check(self.lib.nf_matched_filter_scales(self.plan, ctypes.byref(tile), scales, n, ptrs, lanes, sp),
               "nf_matched_filter_scales")
         keys[:lanes] = [noiseKey] * lanes
 

@@ -565,8 +565,8 @@ class MatchedFilter(MapFilter):
             return None
         if npar.get('noiseGridArcmin', None) == 'smart' or npar.get('RMSEstimator', None) not in (None, 'percentile'):
             return None
-        if len(self.unfilteredMapsDictList) > _lib.NF_MF_MAXFREQ:
-            return None
+        if len(self.unfilteredMapsDictList) > _lib.NF_MF_MAXN:
+            return None          # (the statement path then fails in nf_build_filter with its own '1 <= N <= 6' message)
         noiseCats = p.get('noiseModelCatalog', None)
         return (id(self._shared), type(self).templateKind, p['outputUnits'], npar.get('noiseGridArcmin', None), npar.get('numNoiseBins', 1),
                 npar.get('RMSEstimator', None), self._trimSizePix(), None if noiseCats is None else id(noiseCats),

@@ -200,11 +200,19 @@ def _loadCachedFilteredMap(config, f, tileName):
     d['SNMap'] = engine.to_dev(np.ascontiguousarray(fitsio.readFITS(stem + "_SNMap.fits")[0]))
     areaMask, wcs = completeness.loadAreaMask(tileName, config.selFnDir)
     d['surveyMask'] = engine.to_dev(np.ascontiguousarray(areaMask))
-    try:
+    # no flag mask file at all (a run made without writeFlagMask): no flags; a file that is there but unreadable or of another
+    # shape is an error, not "no flags"
+    sep = os.path.sep
+    candidates = [config.selFnDir + sep + "flagMask#%s.fits" % (tileName), config.selFnDir + sep + tileName + sep + "flagMask#%s.fits" % (tileName),
+                  config.selFnDir + sep + "flagMask.fits"]
+    if any(os.path.exists(c) for c in candidates):
         flagMask = completeness.loadFlagMask(tileName, config.selFnDir)[0]
-    except Exception:
+    else:
         flagMask = np.zeros(data.shape, dtype=np.int32)
     d['flagMask'] = engine.to_dev(np.ascontiguousarray(flagMask)).to(t.int32)
+    for key in ('SNMap', 'surveyMask', 'flagMask'):
+        if tuple(d[key].shape) != tuple(d['data'].shape):
+            raise Exception("cached filtered map %s: '%s' has shape %s, the filtered map %s" % (stem, key, tuple(d[key].shape), tuple(d['data'].shape)))
     d['label'] = f['label']
     d['tileName'] = tileName
     return d

@@ -512,65 +512,72 @@ class TileDict(dict):
         saveFITS(outFileName, self.stitch(stitchedWCS), stitchedWCS, compressionType=compressionType)
 
 
+def _decBands(wcs, rows, column, targetTileHeight):
+    """A mask region's declination range cut into bands of equal height, as many as fit at the wanted height; the height is
+    kept to a thousandth of a degree (nemo/maps.py:760-772).  -> [(band index, decLow, decHigh)]."""
+    decLow = wcs.pix2wcs(column, rows.start)[1]
+    decHigh = wcs.pix2wcs(column, rows.stop - 1)[1]
+    count = int((decHigh - decLow) / targetTileHeight)
+    if count == 0:
+        raise Exception("targetTileHeight is larger than the height of the map - edit your config file accordingly.")
+    height = np.round(((decHigh - decLow) / count) * 1000) / 1000
+    return [(i, decLow + i * height, decLow + (i + 1) * height) for i in range(count)]
+
+
+def _bandColumns(wcs, inRegion, column, decLow, decHigh, targetTileWidth, towardsLowerRA, wrapAt180, lastRADeg):
+    """One declination band of a region cut into tiles along RA (nemo/maps.py:773-822): the band's extent in x where the
+    region has pixels, widened by 1 / cos(dec) of the band's upper edge, split into equal widths kept to a hundredth of a
+    degree (rounded up); all tiles of the band at once.  -> (RAMin[], RAMax[]) per tile."""
+    RAHere = wcs.pix2wcs(column, 0)[0]
+    yLow, yHigh = int(wcs.wcs2pix(RAHere, decLow)[1]), int(wcs.wcs2pix(RAHere, decHigh)[1])
+    occupied = np.flatnonzero(inRegion[yLow:yHigh].any(axis=0))
+    xFirst, xLast = occupied[0], occupied[-1]
+    yMid = int((yHigh + yLow) / 2)
+    widthDeg = (xLast - xFirst) * wcs.getXPixelSizeDeg()
+    RAStart = wcs.pix2wcs(xFirst, yMid)[0]
+    count = int(widthDeg / (targetTileWidth * (1 / np.cos(np.radians(decHigh)))))
+    if count == 0:
+        return np.zeros(0), np.zeros(0)
+    step = np.ceil((widthDeg / count) * 100) / 100
+    j = np.arange(count)
+    edgeA = RAStart - towardsLowerRA * j * step              # the tile's edge nearer the band's first column
+    edgeB = RAStart - towardsLowerRA * (j + 1) * step
+    edgeA = np.where(edgeA < 0, edgeA + 360, edgeA)
+    edgeB = np.where(edgeB < 0, edgeB + 360, edgeB)
+    if wrapAt180:
+        # a tile that would straddle RA = 180 in a whole-sky map stops just past it
+        edgeB = np.where((edgeB < 180.01) & (edgeA < 180 + step) & (edgeA > 180.01), 180.01, edgeB)
+    if towardsLowerRA == -1:
+        edgeB = np.where(edgeB >= lastRADeg, lastRADeg, edgeB)
+        swap = edgeB > edgeA
+        edgeA, edgeB = np.where(swap, edgeB, edgeA), np.where(swap, edgeA, edgeB)
+    return edgeB, edgeA
+
+
 def autotiler(surveyMask, wcs, targetTileWidth, targetTileHeight):
     """Tile definitions ({tileName, RADecSection}) that cover the valid area of a survey mask with tiles of about the wanted
-    size in degrees (nemo/maps.py:700-825): every connected region of the mask taller than 1000 pixels is cut into rows of
-    equal height, every row into columns whose width grows with 1 / cos(dec).  Host code (once per run, on a mask)."""
+    size in degrees (what nemo/maps.py:700-825 produces; pinned by tests/golden/autotiler.json): every connected region of
+    the mask at least 1000 pixels tall is cut into declination bands of equal height, every band into RA tiles whose width
+    grows with 1 / cos(dec).  Tiles are named region_band_column.  Host code (once per run, on a mask)."""
     from scipy import ndimage
-    flipper = -1 if wcs.isFlipped() == 1 else 1
-    mapCentreRA, mapCentreDec = wcs.getCentreWCSCoords()
-    skyWidth, skyHeight = wcs.getFullSizeSkyDeg()
-    handle180Wrap = (mapCentreRA < 0.1 and skyWidth < 0.1) or skyWidth > 359.9
-    segMap, numObjects = ndimage.label(np.asarray(surveyMask) > 0)
-    leftEdgeRADeg, _ = wcs.pix2wcs(0, 0)
-    rightEdgeRADeg, _ = wcs.pix2wcs(surveyMask.shape[1], 0)
-    if rightEdgeRADeg > 359.999:
-        rightEdgeRADeg = 359.999
-    tileList = []
-    for maskSection, f in zip(ndimage.find_objects(segMap), np.arange(1, numObjects + 1)):
-        yMin, yMax = maskSection[0].start, maskSection[0].stop - 1
-        if yMax - yMin < 1000:
-            continue
-        xc = int((maskSection[1].start + (maskSection[1].stop - 1)) / 2)
-        RAc, decMin = wcs.pix2wcs(xc, yMin)
-        RAc, decMax = wcs.pix2wcs(xc, yMax)
-        numRows = int((decMax - decMin) / targetTileHeight)
-        if numRows == 0:
-            raise Exception("targetTileHeight is larger than the height of the map - edit your config file accordingly.")
-        tileHeight = np.round(((decMax - decMin) / numRows) * 1000) / 1000
-        for i in range(numRows):
-            decBottom = decMin + i * tileHeight
-            decTop = decMin + (i + 1) * tileHeight
-            _, yBottom = wcs.wcs2pix(RAc, decBottom)
-            _, yTop = wcs.wcs2pix(RAc, decTop)
-            yBottom, yTop = int(yBottom), int(yTop)
-            yc = int((yTop + yBottom) / 2)
-            ys, xs = np.where(segMap[yBottom:yTop] == f)
-            xMin, xMax = xs.min(), xs.max()
-            stripWidthDeg = (xMax - xMin) * wcs.getXPixelSizeDeg()
-            RAMax, _ = wcs.pix2wcs(xMin, yc)
-            RAMin, _ = wcs.pix2wcs(xMax, yc)
-            stretchFactor = 1 / np.cos(np.radians(decTop))
-            numCols = int(stripWidthDeg / (targetTileWidth * stretchFactor))
-            for j in range(numCols):
-                tileWidth = np.ceil((stripWidthDeg / numCols) * 100) / 100
-                RALeft = RAMax - flipper * j * tileWidth
-                RARight = RAMax - flipper * (j + 1) * tileWidth
-                if RALeft < 0:
-                    RALeft = RALeft + 360
-                if RARight < 0:
-                    RARight = RARight + 360
-                if handle180Wrap == True:
-                    if RARight < 180.01 and RALeft < 180 + tileWidth and RALeft > 180.01:
-                        RARight = 180.01
-                if flipper == -1:
-                    if RARight >= rightEdgeRADeg:
-                        RARight = rightEdgeRADeg
-                    if RARight > RALeft:
-                        RALeft, RARight = RARight, RALeft
-                tileList.append({'tileName': '%d_%d_%d' % (f, i, j),
-                                 'RADecSection': [float(RARight), float(RALeft), float(decBottom), float(decTop)]})
-    return tileList
+    towardsLowerRA = -1 if wcs.isFlipped() == 1 else 1
+    centreRA = wcs.getCentreWCSCoords()[0]
+    skyWidth = wcs.getFullSizeSkyDeg()[0]
+    wrapAt180 = (centreRA < 0.1 and skyWidth < 0.1) or skyWidth > 359.9
+    lastRADeg = min(wcs.pix2wcs(surveyMask.shape[1], 0)[0], 359.999)
+    labels, count = ndimage.label(np.asarray(surveyMask) > 0)
+    tiles = []
+    for region, (rows, cols) in enumerate(ndimage.find_objects(labels), start=1):
+        if (rows.stop - 1) - rows.start < 1000:
+            continue                                     # specks and slivers get no tiles
+        column = int((cols.start + (cols.stop - 1)) / 2)
+        inRegion = labels == region
+        for band, decLow, decHigh in _decBands(wcs, rows, column, targetTileHeight):
+            RAMin, RAMax = _bandColumns(wcs, inRegion, column, decLow, decHigh, targetTileWidth, towardsLowerRA, wrapAt180, lastRADeg)
+            for j in range(len(RAMin)):
+                tiles.append({'tileName': '%d_%d_%d' % (region, band, j),
+                              'RADecSection': [float(RAMin[j]), float(RAMax[j]), float(decLow), float(decHigh)]})
+    return tiles
 
 
 def getPixelAreaArcmin2Map(shape, wcs, rowsOnly=False):

@@ -59,14 +59,13 @@ def test_realspace_convolution_vs_reference():
     t = engine.torch()
     for k in range(int(g['ncases'])):
         cube, kern, ref = g['cube%d' % k], g['kern%d' % k], g['out%d' % k]
-        if cube.dtype != np.float32:
-            continue        # float64 maps with bckSub False are convolved in float64 by the reference: not on the GPU path yet
         eng = engine.TileEngine.get(cube.shape[1:])
+        # (float64 maps are convolved in float64, nf_convolve2d_f64; the planes' sum is cast to float32 either way, nemo/filters.py:1205)
         planes = [eng.convolve(engine.to_dev(cube[i]), kern[i]) for i in range(cube.shape[0])]
         total = planes[0]
         for p in planes[1:]:
             total = total + p
-        out = (total * float(np.float32(g['signalNorm']))).cpu().numpy()
+        out = (total.to(t.float32) * float(np.float32(g['signalNorm']))).cpu().numpy()
         # reference: float32 planes summed, .astype(float32), times a Python float -> float32 (numpy >= 2)
         assert out.dtype == ref.dtype
         assert np.array_equal(out, ref)

@@ -230,3 +230,47 @@ def test_rms_tables_through_the_driver():
     rmsMap = config.cachedRMSMapDict['PRIMARY'].cpu().numpy()
     assert ((rmsMap != 0) >= (areaMask != 0)).all()
     assert abs(np.asarray(tab['areaDeg2']).sum() / want - 1) < 1e-6
+
+
+@pytest.mark.parametrize("k", [k for k in range(12)])
+def test_catalogue_membership_from_reference_sn_maps(k):
+    """Float32 maps leave the S/N map 2e-3 (relative) from the reference's - wide enough to move objects across the threshold.
+    What must hold: every object the reference's S/N map gives (oracle findObjects on the fixture's map) whose S/N clears the
+    threshold by more than that margin is in the product's catalogue at the same place, and the product has nothing beyond
+    the margin that the reference lacks.  Float64 maps: same test at their own tolerance."""
+    from nemo_amd import photometry
+    g = np.load(os.path.join(GOLDEN, "matched_filter.npz"))
+    mapsL, wcs, meta = helpers.load_reference_case(g, k)
+    p = 'c%d_' % k
+    f64 = meta['dtype'] == 'float64'
+    margin = (5e-6 if f64 else 2e-3) * 3
+    thr = 3.5
+    f = {'label': 'ref%d' % k, 'class': meta['class'], 'params': dict(meta['params'])}
+    keep = filters.RETURN_DEVICE_ARRAYS
+    filters.RETURN_DEVICE_ARRAYS = True
+    try:
+        got = filters.filterMaps(helpers.product_maps(mapsL), f, 'PRIMARY', diagnosticsDir=None, selFnDir=None, verbose=False,
+                                 undoPixelWindow=False)
+        cat = photometry.findObjects(got, threshold=thr, minObjPix=1, rejectBorder=0, flagRings=False)
+    finally:
+        filters.RETURN_DEVICE_ARRAYS = keep
+    refSN = g[p + 'out_SNMap']
+    rows = helpers.oracle_find(refSN, np.zeros(refSN.shape, dtype=int), wcs, threshold=thr, minObjPix=1, flagRings=False)
+    peak = max(abs(float(refSN.max())), 1.0)
+    gx, gy, gs = np.asarray(cat['x'], dtype=float), np.asarray(cat['y'], dtype=float), np.asarray(cat['SNR'], dtype=float)
+    clear = 0
+    for r in rows:
+        if r['SNR'] < thr + margin * peak:
+            continue
+        clear += 1
+        d = np.hypot(gx - r['x'], gy - r['y']) if len(gx) else np.array([np.inf])
+        j = int(np.argmin(d))
+        # centroids are S/N-weighted means over the segment: a pixel entering or leaving it at the threshold moves them
+        assert d[j] < 0.5, (k, r, d[j])
+        assert abs(gs[j] - r['SNR']) < margin * peak, (k, r['SNR'], gs[j])
+    rx, ry = np.array([r['x'] for r in rows]), np.array([r['y'] for r in rows])
+    for x, y, s in zip(gx, gy, gs):
+        if s < thr + margin * peak:
+            continue
+        assert len(rx) > 0 and np.hypot(rx - x, ry - y).min() < 0.5, (k, x, y, s)
+    assert clear >= 1, (k, len(rows))

@@ -241,6 +241,9 @@ def main():
     ap.add_argument("--cpu-procs", type=int, default=-1, help="processes for the CPU baseline (0 = skip; -1 = auto)")
     ap.add_argument("--cpu-size", type=int, default=2048)
     ap.add_argument("--no-profile", action="store_true", help="do not record per-entry-point HIP events")
+    ap.add_argument("--dump-catalogs", default=None, metavar="DIR",
+                    help="after the timed steps, write each rank's own catalogue and the gathered one (rank 0) as .npz into DIR "
+                         "(the multi-rank rehearsal test reads them)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -367,6 +370,17 @@ def main():
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
+
+    if args.dump_catalogs is not None and not inject:
+        import numpy as np
+        os.makedirs(args.dump_catalogs, exist_ok=True)
+        own = pipelines.filterMapsAndMakeCatalogs(config, verbose=False)        # this rank's tiles only, nothing exchanged
+        both = run_step(config)                                                  # the step as timed: gathered, duplicates removed
+        cols = ('RADeg', 'decDeg', 'SNR')
+        np.savez(os.path.join(args.dump_catalogs, "rank%d.npz" % rank), **{"own_" + k: np.asarray(own[k], dtype=np.float64) for k in cols},
+                 **{"all_" + k: np.asarray(both[k], dtype=np.float64) for k in cols},
+                 own_tileName=np.asarray(own['tileName']).astype('U30'), all_tileName=np.asarray(both['tileName']).astype('U30'))
+        barrier()
 
     # ---- device time of the dominant entry point over the timed region, from the library's HIP events -------------
     timed = {}

@@ -1,4 +1,4 @@
-"""Minimal FITS image reader / writer (primary HDU only, no compression).
+"""Minimal FITS reader / writer: images, multi-extension files, binary tables, PLIO_1 tile-compressed integer images.
 
 The reference stores its filter cache as a FITS primary HDU (float32 [N,H,W] cube with SIGNORM / RWn header cards,
 nemo/filters.py:761-790; kernel with BCKSCALE / APP_RA / APP_DEC, nemo/filters.py:866-885,1025-1037) through
@@ -92,9 +92,17 @@ def readFITS(fileName, headerOnly=False):
                     break
                 if card[8:10] == '= ':
                     header[key] = _parse_value(card[10:])
+        naxis = header.get('NAXIS', 0)
+        if naxis == 0 and header.get('EXTEND', False) == True:
+            # an empty primary HDU: the image lives in the first extension (a tile-compressed mask, as maps.saveFITS and
+            # astropy's CompImageHDU write them)
+            f.close()
+            for name, data, h in readHDUs(fileName)[1:]:
+                if data is not None and not isinstance(data, dict):
+                    return (None if headerOnly else data), h
+            return None, header
         if headerOnly:
             return None, header
-        naxis = header.get('NAXIS', 0)
         shape = tuple(header['NAXIS%d' % (i)] for i in range(naxis, 0, -1))
         if naxis == 0:
             return None, header
@@ -148,12 +156,130 @@ def _imageHDU(name, data, header, primary=False):
     return _headerBytes(cards) + _pad(data.astype(_DTYPE[bitpix]).tobytes())
 
 
-def writeMEF(fileName, hdus):
-    """``hdus``: [(extension name, array, header dict)] -> an empty primary HDU followed by one IMAGE extension each."""
+# ---- PLIO_1 tile compression (FITS standard 4.0, section 10: tiled image compression; algorithm: the IRAF pixel-list "line
+# list" encoding, as cfitsio's pl_p2li / pl_l2pi implement it).  What the reference writes its masks with
+# (astropy CompImageHDU(compression_type='PLIO_1'), nemo/maps.py:539-571, 2436-2476).  A line list is a sequence of 16-bit words:
+# a 7-word header {0, 7, -100, length low, length high, 0, 0}, then instructions opcode << 12 | 12-bit operand acting on a
+# running "high value" (1 at the start of a line):
+#   0 ZN: n zeros            1 SH: high = operand + (next word << 12)      2 IH: high += n        3 DH: high -= n
+#   4 HN: n pixels of high   5 PN: n - 1 zeros, then one pixel of high     6 IS: high += n, one pixel       7 DS: high -= n, one pixel
+# Negative pixel values count as zero; values above 2^24 do not fit.  PARITY UNPINNED: neither astropy nor cfitsio is available
+# offline - the writer follows the published format, and the only check is the round trip through the reader below.
+def _plioEncodeLine(row):
+    row = np.maximum(np.asarray(row, dtype=np.int64), 0)
+    n = len(row)
+    words = [0, 7, -100, 0, 0, 0, 0]
+    if n > 0:
+        change = np.flatnonzero(row[1:] != row[:-1]) + 1
+        starts = np.concatenate([[0], change])
+        lengths = np.diff(np.concatenate([starts, [n]]))
+        values = row[starts]
+        hi = 1
+        nz = 0
+        for v, ln in zip(values.tolist(), lengths.tolist()):
+            if v == 0:
+                nz += ln                      # (zeros wait for the run that follows them, or for the end of the line)
+                continue
+            single = False
+            dv = v - hi
+            if dv != 0:
+                hi = v
+                if abs(dv) > 4095:
+                    words += [(v & 4095) + 4096, v // 4096]
+                else:
+                    words.append((-dv + 12288) if dv < 0 else (dv + 8192))
+                    if ln == 1 and nz == 0:
+                        words[-1] |= 16384    # IS / DS: change the high value and emit one pixel
+                        single = True
+            if not single:
+                if nz > 0:
+                    while nz > 0:
+                        words.append(min(4095, nz))
+                        nz -= 4095
+                    if ln == 1:
+                        words[-1] += 20481    # the last zero run becomes PN: its zeros, then this one pixel
+                        single = True
+                if not single:
+                    while ln > 0:
+                        words.append(min(4095, ln) + 16384)
+                        ln -= 4095
+            nz = 0
+        while nz > 0:                         # zeros that end the line
+            words.append(min(4095, nz))
+            nz -= 4095
+    words[3], words[4] = len(words) % 32768, len(words) // 32768
+    return np.array(words, dtype=np.int16)
+
+
+def _plioDecodeLine(words, n):
+    words = np.asarray(words, dtype=np.int64)
+    out = np.zeros(n, dtype=np.int64)
+    if len(words) == 0:
+        return out
+    if words[2] > 0:                         # old-style header: length in word 3, three header words
+        end, k = int(words[2]), 3
+    else:
+        end, k = int(words[4]) * 32768 + int(words[3]), int(words[1])
+    hi, x = 1, 0
+    while k < end:
+        op, data = int(words[k]) >> 12, int(words[k]) & 4095
+        k += 1
+        if op == 0:
+            x += data
+        elif op == 1:
+            hi = (int(words[k]) << 12) + data
+            k += 1
+        elif op == 2:
+            hi += data
+        elif op == 3:
+            hi -= data
+        elif op == 4:
+            out[x:x + data] = hi
+            x += data
+        elif op == 5:
+            x += data
+            out[x - 1] = hi
+        elif op in (6, 7):
+            hi = hi + data if op == 6 else hi - data
+            out[x] = hi
+            x += 1
+    return out
+
+
+def _compressedImageHDU(name, data, header):
+    """An integer image as a PLIO_1 tile-compressed binary-table extension, one tile per image row (the convention's default)."""
+    data = np.asarray(data)
+    if data.ndim != 2 or data.dtype.kind not in 'ui' or data.dtype.itemsize > 4:
+        raise Exception("PLIO_1 compresses 2-D integer images of at most 32 bits")
+    if data.size > 0 and int(data.max()) >= (1 << 24):
+        raise Exception("PLIO_1 holds pixel values below 2^24")
+    H, W = data.shape
+    lines = [_plioEncodeLine(data[y]) for y in range(H)]
+    lens = np.array([len(l) for l in lines], dtype=np.int64)
+    offsets = np.concatenate([[0], np.cumsum(lens * 2)[:-1]]) if H > 0 else np.zeros(0, dtype=np.int64)
+    desc = np.empty((H, 2), dtype='>i4')
+    desc[:, 0], desc[:, 1] = lens, offsets
+    heap = np.concatenate(lines).astype('>i2').tobytes() if H > 0 else b""
+    zbitpix = {1: 8, 2: 16, 4: 32}[data.dtype.itemsize]
+    cards = [_card('XTENSION', 'BINTABLE'), _card('BITPIX', 8), _card('NAXIS', 2), _card('NAXIS1', 8), _card('NAXIS2', H),
+             _card('PCOUNT', len(heap)), _card('GCOUNT', 1), _card('TFIELDS', 1), _card('TTYPE1', 'COMPRESSED_DATA'),
+             _card('TFORM1', '1PI(%d)' % (int(lens.max()) if H > 0 else 0)), _card('ZIMAGE', True), _card('ZTILE1', W), _card('ZTILE2', 1),
+             _card('ZCMPTYPE', 'PLIO_1'), _card('ZBITPIX', zbitpix), _card('ZNAXIS', 2), _card('ZNAXIS1', W), _card('ZNAXIS2', H)]
+    if name is not None:
+        cards.append(_card('EXTNAME', name))
+    cards += [c for c in _userCards(header) if not c.startswith(('ZIMAGE', 'ZTILE', 'ZCMPTYPE', 'ZBITPIX', 'ZNAXIS', 'TTYPE', 'TFORM', 'THEAP'))]
+    return _headerBytes(cards) + _pad(desc.tobytes() + heap)
+
+
+def writeMEF(fileName, hdus, compressionType=None):
+    """``hdus``: [(extension name, array, header dict)] -> an empty primary HDU followed by one IMAGE extension each - or, with
+    ``compressionType`` 'PLIO_1' (integer images: masks), one tile-compressed image extension each."""
+    if compressionType not in (None, 'PLIO_1'):
+        raise Exception("compressionType '%s' is not written here (PLIO_1 for masks, or none)" % (compressionType))
     with open(fileName, "wb") as f:
         f.write(_headerBytes([_card('SIMPLE', True), _card('BITPIX', 8), _card('NAXIS', 0), _card('EXTEND', True)]))
         for name, data, header in hdus:
-            f.write(_imageHDU(name, data, header))
+            f.write(_compressedImageHDU(name, data, header) if compressionType == 'PLIO_1' else _imageHDU(name, data, header))
 
 
 _TFORM = {'f8': ('D', '>f8'), 'f4': ('E', '>f4'), 'i8': ('K', '>i8'), 'i4': ('J', '>i4'), 'i2': ('I', '>i2'), 'u1': ('B', '>u1')}
@@ -227,9 +353,26 @@ def readHDUs(fileName):
             naxis = header.get('NAXIS', 0)
             shape = tuple(header['NAXIS%d' % (i)] for i in range(naxis, 0, -1))
             nbytes = (abs(header['BITPIX']) // 8) * int(np.prod(shape)) if naxis > 0 else 0
-            raw = f.read(nbytes + (2880 - nbytes % 2880) % 2880)[:nbytes]
+            total = nbytes + int(header.get('PCOUNT', 0) or 0)          # (a binary table's heap follows its rows)
+            block = f.read(total + (2880 - total % 2880) % 2880)
+            raw = block[:nbytes]
             data = None
-            if header.get('XTENSION', '').strip() == 'BINTABLE':
+            if header.get('XTENSION', '').strip() == 'BINTABLE' and header.get('ZIMAGE', False) == True:
+                if str(header.get('ZCMPTYPE', '')).strip() != 'PLIO_1':
+                    raise Exception("tile compression '%s' is not read here (PLIO_1 only)" % (header.get('ZCMPTYPE')))
+                H, W = int(header['ZNAXIS2']), int(header['ZNAXIS1'])
+                if int(header.get('ZTILE1', W)) != W or int(header.get('ZTILE2', 1)) != 1:
+                    raise Exception("PLIO_1 images are read with one tile per row only")
+                heap0 = int(header.get('THEAP', nbytes))
+                desc = np.frombuffer(raw, dtype='>i4').reshape(H, 2)
+                zdt = {8: np.uint8, 16: np.int16, 32: np.int32}[int(header['ZBITPIX'])]
+                data = np.zeros((H, W), dtype=zdt)
+                for y in range(H):
+                    n, off = int(desc[y, 0]), int(desc[y, 1])
+                    words = np.frombuffer(block[heap0 + off:heap0 + off + 2 * n], dtype='>i2')
+                    data[y] = _plioDecodeLine(words, W)
+                header = dict(header, NAXIS=2, NAXIS1=W, NAXIS2=H, BITPIX=int(header['ZBITPIX']))
+            elif header.get('XTENSION', '').strip() == 'BINTABLE':
                 fields = []
                 for i in range(1, header['TFIELDS'] + 1):
                     form = str(header['TFORM%d' % i]).strip()

@@ -449,13 +449,18 @@ def makeModelImage(shape, wcs, catalog, beamFileName, obsFreqGHz=None, GNFWParam
 
 
 def saveFITS(outputFileName, mapData, wcs, compressionType=None):
-    """A map and its WCS header as a FITS image (nemo/maps.py:2436-2476).  ``compressionType`` names what the reference would
-    tile-compress with (PLIO_1 for masks, RICE_1): masks are written as uint8, everything uncompressed (nemo_amd.fitsio)."""
+    """A map and its WCS header as a FITS image (nemo/maps.py:2436-2476).  ``compressionType`` 'PLIO_1' (masks): uint8, written as
+    a tile-compressed image extension behind an empty primary HDU, as astropy's CompImageHDU in an HDUList is; 'RICE_1' (lossy,
+    float maps) is not written here: such maps go out as float32 images."""
     from . import fitsio
     data = mapData.cpu().numpy() if _is_tensor(mapData) else np.asarray(mapData)
+    header = dict(wcs.header) if wcs is not None else {}
     if compressionType == 'PLIO_1':
-        data = np.array(data, dtype=np.uint8)
-    fitsio.writeFITS(outputFileName, data, dict(wcs.header) if wcs is not None else {})
+        fitsio.writeMEF(outputFileName, [('COMPRESSED_IMAGE', np.array(data, dtype=np.uint8), header)], compressionType='PLIO_1')
+        return
+    if compressionType is not None:
+        data = np.array(data, dtype=np.float32)
+    fitsio.writeFITS(outputFileName, data, header)
 
 
 class TileDict(dict):
@@ -483,7 +488,7 @@ class TileDict(dict):
             if compressionType is not None:
                 data = np.array(data, dtype=np.uint8 if compressionType == 'PLIO_1' else np.float32)
             hdus.append((tileName, data, self._tileHeader(tileName)))
-        fitsio.writeMEF(outFileName, hdus)
+        fitsio.writeMEF(outFileName, hdus, compressionType='PLIO_1' if compressionType == 'PLIO_1' else None)
 
     def stitch(self, stitchedWCS):
         """The monolithic float32 image of nemo/maps.py:592-612: tiles added into their clippedSection (overlaps add up:

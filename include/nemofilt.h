@@ -49,9 +49,9 @@ int nf_plan_destroy(nf_plan* plan);
  * them: y = IFFT(FFT(x) * w) along axis 0 (x, within rows) or 1 (y, within columns) of `batch` real [H, W] maps, in ONE pass
  * over the map (two real lines share one complex transform; the spectrum stays in LDS).  wperm_d: n doubles with
  * wperm[rev[k]] = w[k] / n, rev from nf_plan_digit_reversal (n = W for axis 0, H for axis 1); w must be real and even
- * (w[k] == w[n-k]).  zeroRef_d (optional, a map of the output type): where it is zero the output is zero
- * (nemo/filters.py:99-101); zeroRows_d (optional, with zeroRef_d, axis 0, batch 1): H ints, 0 = that row of zeroRef_d holds
- * no zero - such rows are not looked up (nf_finalize makes the table).  in_d == out_d is allowed.  Lengths with a prime factor above 13 are refused (NF_ERR_SIZE,
+ * (w[k] == w[n-k]).  zeroRef_d (optional, `batch` maps of the output type, laid out like the output): where map b of it is zero,
+ * map b of the output is zero (nemo/filters.py:99-101); zeroRows_d (optional, with zeroRef_d, axis 0): [batch][H] ints, 0 = that
+ * row of that map of zeroRef_d holds no zero - such rows are not looked up (nf_finalize makes the table).  in_d == out_d is allowed.  Lengths with a prime factor above 13 are refused (NF_ERR_SIZE,
  * *bluestein = 1 from nf_plan_digit_reversal): use the 2-D transforms there. */
 int nf_plan_digit_reversal(nf_plan* plan, int prec, int axis, unsigned short* rev_host, int* bluestein);
 int nf_axis_filter(nf_plan* plan, int prec, int axis, const void* in_d, int inType, void* out_d, int outType, int batch,
@@ -435,8 +435,10 @@ int nf_spline_eval_batch(int vtype, int nJobs, const void* const* maps_d, const 
  *   Then :696-756: inverse transform of the data spectra times the filter with the float32 cast, signalNorm and point-source
  *   mask applied at the store, noise map (grid mode), optional edge trim, nf_finalize; and, if axisWinY_d / axisWinX_d are given,
  *   the pixel-window undo as two nf_axis_filter passes (tables for pow = -1 as that entry point wants them).
- * Scales are dealt round-robin to nLanes lanes; lane 0 runs on `stream`, the others on streams the library keeps per device,
- * forked from and joined back into `stream` with events - so for the caller the whole call is ordinary work on `stream`.
+ * Scales run in groups of up to scaleBatch (consecutive scales whose data_d buffers lie map after map; at least as many groups
+ * as lanes): a group's stages are single launches with the scales as batch dimension, per scale the arithmetic of the entry
+ * points above.  Groups are dealt round-robin to nLanes lanes; lane 0 runs on `stream`, the others on streams the library keeps
+ * per device, forked from and joined back into `stream` with events - so for the caller the whole call is ordinary work on `stream`.
  * work_d: nLanes device buffers of nf_matched_filter_workspace_bytes(tile) bytes each (256-byte aligned).
  * At most nf_matched_filter_max_lanes() lanes are used (4: MI355X boxes give a process 4 hardware queues).  The lane streams
  * and their events are made once per device, by the first nf_matched_filter_workspace_bytes call on it.  Threads: calls on one
@@ -476,7 +478,10 @@ typedef struct nf_mf_tile {
     const double* axisWinY_d;          /* pixel-window undo (both or neither): nf_axis_filter tables for axis 1 and axis 0 */
     const double* axisWinX_d;
     unsigned int noiseTablesLanes;     /* bit l: work_d[l] still holds this tile's noise block tables (tablesValid of nf_noise_map
-                                        * for the first scale of lane l; later scales of a lane in one call always reuse) */
+                                        * for the first group of lane l; later groups of a lane in one call always reuse) */
+    int scaleBatch;                    /* scales that walk the sequence together, as the batch dimension of every launch (1..8;
+                                        * 0 = 1).  The workspace holds that many slots: its size grows in proportion.  Small tiles
+                                        * want 8 (the chip is filled by the batch, not by one map); a 16 Mpix tile fills it alone */
 } nf_mf_tile;
 
 typedef struct nf_mf_scale {

@@ -41,7 +41,7 @@ class MfTile(ctypes.Structure):
                 ('xEdges_d', c_void_p), ('overlap', c_int), ('numBins', c_int), ('estimator', c_int),
                 ('quantiles', ctypes.POINTER(c_double)), ('trimSizePix', c_int), ('apodPix', c_int), ('y0', c_double),
                 ('centreYX_d', c_void_p), ('centreClass', c_int), ('centreRowLo', c_int), ('centreRowHi', c_int), ('halfWin', c_int), ('winY_d', c_void_p), ('winX_d', c_void_p),
-                ('axisWinY_d', c_void_p), ('axisWinX_d', c_void_p), ('noiseTablesLanes', ctypes.c_uint)]
+                ('axisWinY_d', c_void_p), ('axisWinX_d', c_void_p), ('noiseTablesLanes', ctypes.c_uint), ('scaleBatch', c_int)]
 
 
 class MfScale(ctypes.Structure):

@@ -4,6 +4,7 @@
 #include "nf_common.h"
 #include "nf_fft.h"
 #include "nf_kernels.h"
+#include "nf_plan.h"
 
 #include <cmath>
 #include <cstring>
@@ -67,17 +68,7 @@ nf::ProfScope::~ProfScope() {
     (void)hipEventRecord(g_profRecs[slot].b, stream);
 }
 
-struct nf_plan {
-    int H, W;
-    bool haveF, haveD;
-    nf::Plan2D<float> pf;
-    nf::Plan2D<double> pd;
-    std::mutex mu;
-};
-
-namespace {
-
-int ensure_prec(nf_plan* p, int prec) {
+int nf_plan_ensure_prec(nf_plan* p, int prec) {
     std::lock_guard<std::mutex> lock(p->mu);
     if (prec == NF_F32) {
         if (!p->haveF) {
@@ -97,6 +88,10 @@ int ensure_prec(nf_plan* p, int prec) {
     }
     return NF_OK;
 }
+
+namespace {
+
+inline int ensure_prec(nf_plan* p, int prec) { return nf_plan_ensure_prec(p, prec); }
 
 inline hipStream_t S(void* s) { return (hipStream_t)s; }
 

@@ -14,6 +14,8 @@
 //                    ends, evaluated from a +-halfWin pixel window (the influence of samples further away decays
 //                    as 0.268^k; at 32 pixels it is below 1e-18).  A window that touches
 //                    the true map edge applies the not-a-knot condition there, as FITPACK does.
+#include "../../include/nemofilt.h"
+
 #include "nf_common.h"
 #include "nf_kernels.h"
 
@@ -647,9 +649,14 @@ __device__ __forceinline__ void block_max_first(double& best, long long& arg) {
     }
 }
 
+// blockIdx.y: one map per entry of a batch - maps lie entry after entry (mapStride elements apart), each entry has its own
+// NF_MAP_MAX_DOUBLES block of results and partials
 template <typename VT>
-__global__ void __launch_bounds__(NF_MAXRED_THREADS) k_map_max(const VT* __restrict__ m, long long n, double* __restrict__ pv,
-                                                                long long* __restrict__ pi) {
+__global__ void __launch_bounds__(NF_MAXRED_THREADS) k_map_max(const VT* __restrict__ m0, long long n, long long mapStride,
+                                                                double* __restrict__ mapMax0) {
+    const VT* __restrict__ m = m0 + (long long)blockIdx.y * mapStride;
+    double* __restrict__ pv = mapMax0 + (long long)blockIdx.y * NF_MAP_MAX_DOUBLES + 4;
+    long long* __restrict__ pi = (long long*)(pv + NF_MAXRED_BLOCKS);
     double best = -INFINITY;
     long long arg = 0x7FFFFFFFFFFFFFFFLL;
     for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x) {
@@ -665,8 +672,11 @@ __global__ void __launch_bounds__(NF_MAXRED_THREADS) k_map_max(const VT* __restr
         pi[blockIdx.x] = arg;
     }
 }
-__global__ void __launch_bounds__(NF_MAXRED_THREADS) k_map_max_finish(const double* __restrict__ pv, const long long* __restrict__ pi,
-                                                                       int nPart, double* __restrict__ out) {
+// blockIdx.x: batch entry
+__global__ void __launch_bounds__(NF_MAXRED_THREADS) k_map_max_finish(double* __restrict__ mapMax0, int nPart) {
+    double* __restrict__ out = mapMax0 + (long long)blockIdx.x * NF_MAP_MAX_DOUBLES;
+    const double* __restrict__ pv = out + 4;
+    const long long* __restrict__ pi = (const long long*)(pv + NF_MAXRED_BLOCKS);
     double best = -INFINITY;
     long long arg = 0x7FFFFFFFFFFFFFFFLL;
     for (int k = threadIdx.x; k < nPart; k += blockDim.x) max_first(best, arg, pv[k], pi[k]);
@@ -679,9 +689,13 @@ __global__ void __launch_bounds__(NF_MAXRED_THREADS) k_map_max_finish(const doub
 
 // nf_sum_planes and the first half of nf_map_max in one pass over the planes (the per-scale call with several frequencies:
 // nemo/filters.py:847 then :661): out = in[0] + ... + in[N-1] in plane order, and per workgroup the maximum of out with its
-// first index.
-__global__ void __launch_bounds__(NF_MAXRED_THREADS) k_sum_planes_max(const float* __restrict__ in, float* __restrict__ out, int N,
-                                                                       long long n, double* __restrict__ pv, long long* __restrict__ pi) {
+// first index.  blockIdx.y: batch entry ([entry][N][n] planes in, [entry][n] sums out).
+__global__ void __launch_bounds__(NF_MAXRED_THREADS) k_sum_planes_max(const float* __restrict__ in0, float* __restrict__ out0, int N,
+                                                                       long long n, double* __restrict__ mapMax0) {
+    const float* __restrict__ in = in0 + (long long)blockIdx.y * N * n;
+    float* __restrict__ out = out0 + (long long)blockIdx.y * n;
+    double* __restrict__ pv = mapMax0 + (long long)blockIdx.y * NF_MAP_MAX_DOUBLES + 4;
+    long long* __restrict__ pi = (long long*)(pv + NF_MAXRED_BLOCKS);
     double best = -INFINITY;
     long long arg = 0x7FFFFFFFFFFFFFFFLL;
     for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < n; p += (long long)gridDim.x * blockDim.x) {
@@ -702,12 +716,18 @@ __global__ void __launch_bounds__(NF_MAXRED_THREADS) k_sum_planes_max(const floa
 }
 
 // the second half of nf_map_max, the relative-weight gather (nemo/filters.py:661-667: the N planes at the position of the
-// maximum, then the maximum) and signalNorm = y0 / peak (:659) as one finishing kernel
-__global__ void __launch_bounds__(NF_MAXRED_THREADS) k_map_max_finish_weights(const double* __restrict__ pv, const long long* __restrict__ pi,
-                                                                               int nPart, double* __restrict__ out,
-                                                                               const float* __restrict__ planes, int N, long long npix,
-                                                                               double* __restrict__ relOut, const double* __restrict__ peak,
-                                                                               double y0, double* __restrict__ normOut) {
+// maximum, then the maximum) and signalNorm = y0 / peak (:659) as one finishing kernel.  blockIdx.x: batch entry.
+__global__ void __launch_bounds__(NF_MAXRED_THREADS) k_map_max_finish_weights(double* __restrict__ mapMax0, int nPart,
+                                                                               const float* __restrict__ planes0, int N, long long npix,
+                                                                               nf::BatchPtrs relOutP, const double* __restrict__ peak0,
+                                                                               double y0, nf::BatchPtrs normOutP,
+                                                                               double* __restrict__ normWs) {
+    double* __restrict__ out = mapMax0 + (long long)blockIdx.x * NF_MAP_MAX_DOUBLES;
+    const double* __restrict__ pv = out + 4;
+    const long long* __restrict__ pi = (const long long*)(pv + NF_MAXRED_BLOCKS);
+    const float* __restrict__ planes = planes0 + (long long)blockIdx.x * N * npix;
+    double* __restrict__ relOut = (double*)relOutP.p[blockIdx.x];
+    double* __restrict__ normOut = (double*)normOutP.p[blockIdx.x];
     double best = -INFINITY;
     long long arg = 0x7FFFFFFFFFFFFFFFLL;
     for (int k = threadIdx.x; k < nPart; k += blockDim.x) max_first(best, arg, pv[k], pi[k]);
@@ -718,7 +738,9 @@ __global__ void __launch_bounds__(NF_MAXRED_THREADS) k_map_max_finish_weights(co
         out[1] = (double)arg;
         at = arg;
         relOut[N] = best;
-        normOut[0] = __ddiv_rn(y0, peak[0]);
+        const double norm = __ddiv_rn(y0, peak0[blockIdx.x]);
+        normOut[0] = norm;
+        if (normWs != nullptr) normWs[blockIdx.x] = norm;      // (the batch's norms side by side, for the next launch)
     }
     __syncthreads();
     if ((int)threadIdx.x < N) relOut[threadIdx.x] = (double)planes[(long long)threadIdx.x * npix + at];
@@ -729,37 +751,41 @@ static int map_max_parts(long long n) {
     return (int)(want < 1 ? 1 : (want > NF_MAXRED_BLOCKS ? NF_MAXRED_BLOCKS : want));
 }
 
-int sum_planes_max(const float* in, float* out, int N, long long n, double* mapMax, hipStream_t s) {
-    double* pv = mapMax + 4;
-    long long* pi = (long long*)(pv + NF_MAXRED_BLOCKS);
-    hipLaunchKernelGGL(k_sum_planes_max, dim3(map_max_parts(n)), dim3(NF_MAXRED_THREADS), 0, s, in, out, N, n, pv, pi);
+// (batched forms: nb maps / plane stacks one after the other, mapMax = nb blocks of NF_MAP_MAX_DOUBLES, peak = nb doubles)
+int sum_planes_max(const float* in, float* out, int N, long long n, double* mapMax, hipStream_t s, int nb) {
+    hipLaunchKernelGGL(k_sum_planes_max, dim3(map_max_parts(n), nb), dim3(NF_MAXRED_THREADS), 0, s, in, out, N, n, mapMax);
     NF_CHECK_LAUNCH("k_sum_planes_max");
+    return NF_OK;
+}
+
+int map_max_finish_weights_batch(double* mapMax, long long n, const float* planes, int N, const BatchPtrs& relOut, const double* peak,
+                                 double y0, const BatchPtrs& normOut, double* normWs, int nb, hipStream_t s) {
+    hipLaunchKernelGGL(k_map_max_finish_weights, dim3(nb), dim3(NF_MAXRED_THREADS), 0, s, mapMax, map_max_parts(n), planes, N, n, relOut,
+                       peak, y0, normOut, normWs);
+    NF_CHECK_LAUNCH("k_map_max_finish_weights");
     return NF_OK;
 }
 
 int map_max_finish_weights(double* mapMax, long long n, const float* planes, int N, double* relOut, const double* peak, double y0,
                            double* normOut, hipStream_t s) {
-    double* pv = mapMax + 4;
-    long long* pi = (long long*)(pv + NF_MAXRED_BLOCKS);
-    hipLaunchKernelGGL(k_map_max_finish_weights, dim3(1), dim3(NF_MAXRED_THREADS), 0, s, pv, pi, map_max_parts(n), mapMax, planes, N, n,
-                       relOut, peak, y0, normOut);
-    NF_CHECK_LAUNCH("k_map_max_finish_weights");
-    return NF_OK;
+    BatchPtrs r, o;
+    memset(&r, 0, sizeof(r));
+    memset(&o, 0, sizeof(o));
+    r.p[0] = relOut;
+    o.p[0] = normOut;
+    return map_max_finish_weights_batch(mapMax, n, planes, N, r, peak, y0, o, nullptr, 1, s);
 }
 
 // out: NF_MAP_MAX_DOUBLES (= 4 + 2 * 2048) doubles on the device, owned by the caller: [0] max value, [1] first index of
-// the max, [4..] per-workgroup partials (values, then indices)
-int map_max(int vtype, const void* m, long long n, double* out, hipStream_t s) {
-    double* pv = out + 4;
-    long long* pi = (long long*)(pv + NF_MAXRED_BLOCKS);
-    long long want = (n + NF_MAXRED_THREADS * 8LL - 1) / (NF_MAXRED_THREADS * 8LL);
-    const int nPart = (int)(want < 1 ? 1 : (want > NF_MAXRED_BLOCKS ? NF_MAXRED_BLOCKS : want));
-    dim3 g(nPart), b(NF_MAXRED_THREADS);
+// the max, [4..] per-workgroup partials (values, then indices); nb maps (mapStride elements apart): nb such blocks
+int map_max(int vtype, const void* m, long long n, double* out, hipStream_t s, int nb, long long mapStride) {
+    const int nPart = map_max_parts(n);
+    dim3 g(nPart, nb), b(NF_MAXRED_THREADS);
     if (vtype == NF_F64)
-        hipLaunchKernelGGL(k_map_max<double>, g, b, 0, s, (const double*)m, n, pv, pi);
+        hipLaunchKernelGGL(k_map_max<double>, g, b, 0, s, (const double*)m, n, mapStride, out);
     else
-        hipLaunchKernelGGL(k_map_max<float>, g, b, 0, s, (const float*)m, n, pv, pi);
-    hipLaunchKernelGGL(k_map_max_finish, dim3(1), b, 0, s, pv, pi, nPart, out);
+        hipLaunchKernelGGL(k_map_max<float>, g, b, 0, s, (const float*)m, n, mapStride, out);
+    hipLaunchKernelGGL(k_map_max_finish, dim3(nb), b, 0, s, out, nPart);
     NF_CHECK_LAUNCH("map_max");
     return NF_OK;
 }

@@ -70,8 +70,9 @@ struct LineArgs {
                              //   conjugate of the stored one; only its filter value and window factor are fetched)
     int realH, realW;        // shape of the real map (H rows, W columns)
     int packNyq;             // columns kernel: lane 0 of tile 0 carries columns 0 and W/2 as one complex column (nLines = W/2)
-    // rows kernel, pairMode 2 (real output): optional epilogues on the value being stored (batch 1 only)
+    // rows kernel, pairMode 2 (real output): optional epilogues on the value being stored
     const double* epiScale;          // device scalar: out = (float)value * scale (* epiMask), formed in the output type
+    long long epiScaleStride;        //   batch entry b takes epiScale[b * epiScaleStride]
     const unsigned char* epiMask;    //   mask multiplied in after the scale
     const void* epiZeroRef;          // map of the output type: where it is zero the output is zero
     const int* epiZeroRows;          // line filter, rows: per map row, 0 = that row of epiZeroRef holds no zero (it is not read)
@@ -101,7 +102,8 @@ struct Plan2D {
     int inverse_half(const void* in, void* work, void* out, int outType, int batch, int scaleDiv, double scale,
                      hipStream_t stream, const double* filtSym, int nSum, long long filtBatchStride, const double* winY,
                      const double* winX, const double* epiScale = nullptr, const unsigned char* epiMask = nullptr,
-                     const void* epiZeroRef = nullptr, const double* planeScale = nullptr, int rowLo = 0, int rowHi = 0);
+                     const void* epiZeroRef = nullptr, const double* planeScale = nullptr, int rowLo = 0, int rowHi = 0,
+                     long long inBatchStride = -1, long long epiScaleStride = 0);
 };
 
 }  // namespace nf

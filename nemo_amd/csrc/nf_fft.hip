@@ -876,7 +876,7 @@ __device__ __forceinline__ void store_pairs_inv(const cpx<T>* __restrict__ buf, 
     const int n = p.n;
     const T r = (T)a.scale, rb = r * (T)a.conjOutSign;
     const bool doScale = a.epiScale != nullptr;
-    const double es = doScale ? *a.epiScale : 1.0;
+    const double es = doScale ? a.epiScale[(size_t)blockIdx.y * (size_t)a.epiScaleStride] : 1.0;
     const bool useMask = doScale && a.epiMask != nullptr, useRef = a.epiZeroRef != nullptr;
     constexpr int NB = 4;
     for (int line = G.tl; line < G.nl; line += G.TL) {
@@ -1129,14 +1129,14 @@ __device__ __forceinline__ T lf_load(const void* p, int type, size_t off) {
 }
 
 template <typename T>
-__device__ __forceinline__ void lf_store(const nf::LineArgs<T>& a, void* outP, size_t off, T v, bool useRef) {
+__device__ __forceinline__ void lf_store(const nf::LineArgs<T>& a, void* outP, const void* refP, size_t off, T v, bool useRef) {
     if (a.outType == 1) {
         double w = (double)v;
-        if (useRef && ((const double*)a.epiZeroRef)[off] == 0.0) w = 0.0;
+        if (useRef && ((const double*)refP)[off] == 0.0) w = 0.0;
         ((double*)outP)[off] = w;
     } else {
         float w = (float)v;
-        if (useRef && ((const float*)a.epiZeroRef)[off] == 0.0f) w = 0.0f;
+        if (useRef && ((const float*)refP)[off] == 0.0f) w = 0.0f;
         ((float*)outP)[off] = w;
     }
 }
@@ -1172,6 +1172,9 @@ __global__ void __launch_bounds__(COLS ? NF_FFT_MAXTHREADS : 512) k_line_filter(
     const size_t inEs = a.inType == 1 ? 8 : 4, outEs = a.outType == 1 ? 8 : 4;
     G.inP = (const char*)a.in + (size_t)blockIdx.y * plane * inEs;
     G.outP = (char*)a.out + (size_t)blockIdx.y * plane * outEs;
+    // (every map of a batch has its own zero reference and its own row flags, laid out like the maps)
+    const void* refP = a.epiZeroRef != nullptr ? (const void*)((const char*)a.epiZeroRef + (size_t)blockIdx.y * plane * outEs) : nullptr;
+    const int* __restrict__ zeroRows = a.epiZeroRows != nullptr ? a.epiZeroRows + (size_t)blockIdx.y * (size_t)a.realH : nullptr;
     constexpr int NB = 4;
     const size_t W = (size_t)a.realW;
 
@@ -1267,8 +1270,8 @@ __global__ void __launch_bounds__(COLS ? NF_FFT_MAXTHREADS : 512) k_line_filter(
                     o.y = (float)-v.y;
                     *(float2*)((float*)G.outP + (size_t)e * W + c0) = o;
                 } else {
-                    lf_store<T>(a, G.outP, (size_t)e * W + c0, v.x, useRef);
-                    if (haveB) lf_store<T>(a, G.outP, (size_t)e * W + c0 + 1, -v.y, useRef);
+                    lf_store<T>(a, G.outP, refP, (size_t)e * W + c0, v.x, useRef);
+                    if (haveB) lf_store<T>(a, G.outP, refP, (size_t)e * W + c0 + 1, -v.y, useRef);
                 }
             }
         }
@@ -1278,12 +1281,12 @@ __global__ void __launch_bounds__(COLS ? NF_FFT_MAXTHREADS : 512) k_line_filter(
             const bool haveB = rowA + 1 < (size_t)a.realH;
             const cpx<T>* __restrict__ lb = buf + line * p.mPad;
             // (a row the caller knows to hold no zero is not looked up in the zero reference)
-            const bool refA = a.epiZeroRef != nullptr && (a.epiZeroRows == nullptr || a.epiZeroRows[rowA] != 0);
-            const bool refB = haveB && a.epiZeroRef != nullptr && (a.epiZeroRows == nullptr || a.epiZeroRows[rowA + 1] != 0);
+            const bool refA = refP != nullptr && (zeroRows == nullptr || zeroRows[rowA] != 0);
+            const bool refB = haveB && refP != nullptr && (zeroRows == nullptr || zeroRows[rowA + 1] != 0);
             for (int e = G.tb; e < n; e += G.TB) {
                 const cpx<T> v = lb[swz(e)];
-                lf_store<T>(a, G.outP, rowA * W + (size_t)e, v.x, refA);
-                if (haveB) lf_store<T>(a, G.outP, (rowA + 1) * W + (size_t)e, -v.y, refB);
+                lf_store<T>(a, G.outP, refP, rowA * W + (size_t)e, v.x, refA);
+                if (haveB) lf_store<T>(a, G.outP, refP, (rowA + 1) * W + (size_t)e, -v.y, refB);
             }
         }
     }
@@ -1788,12 +1791,13 @@ template <typename T>
 int Plan2D<T>::inverse_half(const void* in, void* work, void* out, int outType, int batch, int scaleDiv, double scale,
                             hipStream_t stream, const double* filtSym, int nSum, long long filtBatchStride, const double* winY,
                             const double* winX, const double* epiScale, const unsigned char* epiMask, const void* epiZeroRef,
-                            const double* planeScale, int rowLo, int rowHi) {
+                            const double* planeScale, int rowLo, int rowHi, long long inBatchStride, long long epiScaleStride) {
     if (outType == 0) {
         nf_set_error("a half-stored spectrum has a real inverse transform: ask for real output");
         return NF_ERR_ARG;
     }
     LineArgs<T> c = col_args<T>(*this, in, work);
+    if (inBatchStride >= 0) c.inBatchStride = inBatchStride;      // (0: every batch entry transforms the same planes, each with its filter)
     c.conjInSign = -1.0;
     c.mulSym = filtSym;
     c.mulBatchStride = filtBatchStride;
@@ -1821,6 +1825,7 @@ int Plan2D<T>::inverse_half(const void* in, void* work, void* out, int outType, 
     a.nLines = (H + 1) / 2;
     a.conjOutSign = 1.0;
     a.epiScale = epiScale;
+    a.epiScaleStride = epiScaleStride;
     a.epiMask = epiMask;
     a.epiZeroRef = epiZeroRef;
     if (packOk()) {
@@ -1866,7 +1871,7 @@ int Plan2D<T>::axis_filter(int axis, const void* in, int inType, void* out, int 
     a.realW = W;
     a.winElem = wperm;
     a.epiZeroRef = zeroRef;
-    a.epiZeroRows = (axis == 0 && batch == 1 && zeroRef != nullptr) ? zeroRows : nullptr;
+    a.epiZeroRows = (axis == 0 && zeroRef != nullptr) ? zeroRows : nullptr;          // [batch][H]
     a.conjInSign = a.conjOutSign = a.scale = 1.0;
     int mode = 0;
     for (int s = 0; s < lp.nst; ++s)

@@ -8,6 +8,22 @@ struct WeightVec {
     double v[8];
 };
 
+// the scales of a tile as the batch dimension of one launch (nf_scale.hip): per-entry operands, by value
+#define NF_SB_MAX 8
+struct BatchPtrs {
+    void* p[NF_SB_MAX];
+};
+struct FinalizeBatch {
+    void* filtered[NF_SB_MAX];
+    const float* rms[NF_SB_MAX];
+    const unsigned char* edgeCheck[NF_SB_MAX];
+    void* snOut[NF_SB_MAX];
+    float* rmsOut[NF_SB_MAX];
+    unsigned char* maskOut[NF_SB_MAX];
+    unsigned long long* chunkRange[NF_SB_MAX];
+    int* zeroRows[NF_SB_MAX];
+};
+
 // nf_pointwise.hip
 template <typename T>
 int cross_power(const void* F, void* NP, int N, long long npix, hipStream_t s, int halfH = 0, int halfW = 0);
@@ -23,6 +39,10 @@ int build_filter(int covType, int sigType, const void* cov, const void* S, const
                  long long npix, hipStream_t s, int halfH = 0, int halfW = 0);
 int build_filter_sym(int covType, int sigType, const void* cov, const void* S, const WeightVec& w, float* filt, double* sym, int N,
                      int H, int W, hipStream_t s);
+int build_filter_sym_batch(int covType, int sigType, const void* cov, const void* S, const WeightVec& w, const BatchPtrs& filt, int nb,
+                           double* sym, int N, int H, int W, hipStream_t s);
+int finalize_batch(int vtype, const FinalizeBatch& fb, int nb, const unsigned char* surveyMask, const unsigned char* psMask, int H, int W,
+                   int apodPix, int mulSurvey, hipStream_t s);
 template <typename T>
 int apply_filter(const void* F, const float* filt, void* G, int N, int sum, long long npix, hipStream_t s);
 template <typename T>
@@ -88,6 +108,10 @@ struct NoiseGrid {
 };
 int noise_map(int vtype, const void* filtered, const void* weights, int wtype, float* rms, int H, int W, const NoiseGrid& g,
               void* cellStats, size_t cellStatsBytes, bool tablesValid, hipStream_t s);
+bool noise_batchable(const NoiseGrid& g);
+int noise_map_batch(int vtype, const void* filtered, long long vStrideBytes, const void* weights, int wtype, float* const* rmsList, int nb,
+                    int nbTables, int H, int W, const NoiseGrid& g, void* cellStats, size_t cellStatsBytes, long long wsStrideBytes,
+                    bool tablesValid, hipStream_t s);
 size_t noise_workspace_bytes(const NoiseGrid& g, int H, int W);
 size_t noise_smart_workspace_bytes();
 int noise_map_smart(int vtype, const void* filtered, const void* weights, int wtype, float* rms, long long n, int numBins,
@@ -109,8 +133,10 @@ int resample_bilinear(const float* in, float* out, int N, int H, int W, int H2, 
 int rms_table(const float* rms, const unsigned char* areaMask, const int* flagMask, int maxFlags, const unsigned char* intersect,
               const unsigned long long* rowAreaFix, int H, int W, unsigned* keys, unsigned long long* cnt, unsigned long long* area,
               int tableSize, int* overflow, hipStream_t s);
-int map_max(int vtype, const void* m, long long n, double* out, hipStream_t s);
-int sum_planes_max(const float* in, float* out, int N, long long n, double* mapMax, hipStream_t s);
+int map_max(int vtype, const void* m, long long n, double* out, hipStream_t s, int nb = 1, long long mapStride = 0);
+int sum_planes_max(const float* in, float* out, int N, long long n, double* mapMax, hipStream_t s, int nb = 1);
+int map_max_finish_weights_batch(double* mapMax, long long n, const float* planes, int N, const BatchPtrs& relOut, const double* peak,
+                                 double y0, const BatchPtrs& normOut, double* normWs, int nb, hipStream_t s);
 int map_max_finish_weights(double* mapMax, long long n, const float* planes, int N, double* relOut, const double* peak, double y0,
                            double* normOut, hipStream_t s);
 int ring_flags(const int* ringLabels, const double* ringStats, int numRing, int minRingPix, int H, int W, unsigned char* isRing,

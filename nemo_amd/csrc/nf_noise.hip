@@ -636,6 +636,33 @@ struct BlockWs {
     int maxBy, maxBx;
 };
 
+// Several maps of one grid and one weight map in one launch (the scales of a tile, nf_scale.hip): blockIdx.z is the map.  The maps
+// lie vBytes apart, each has its own workspace (cell records and block tables) wsBytes after the one before, and its own output.
+struct NoiseBatch {
+    long long vBytes, wsBytes;
+    float* rms[NF_SB_MAX];
+};
+__device__ __forceinline__ void ws_shift(BlockWs& ws, long long off) {
+    if (off == 0) return;
+#define NF_SH(f) ws.f = (decltype(ws.f))((char*)ws.f + off)
+    NF_SH(hdr);
+    NF_SH(breakY);
+    NF_SH(breakX);
+    NF_SH(wY0);
+    NF_SH(wY1);
+    NF_SH(wX0);
+    NF_SH(wX1);
+    NF_SH(rec);
+    NF_SH(tails);
+    NF_SH(tails2);
+    NF_SH(cls);
+    NF_SH(heavyIds);
+#undef NF_SH
+}
+#define NF_NB_WS ws_shift(ws, (long long)blockIdx.z * nb.wsBytes)
+#define NF_NB_V v = (decltype(v))((const char*)v + (long long)blockIdx.z * nb.vBytes)
+#define NF_NB_STATS stats = (decltype(stats))((const char*)stats + (long long)blockIdx.z * nb.wsBytes)
+
 #define NF_HEAVY 256
 #define NF_NCLS 16
 // lower bound of magnitude class c of a block with core threshold T: [T m_c, T m_(c+1)), the last class open above.  The
@@ -770,7 +797,8 @@ __device__ void axis_walk_lds(const int* __restrict__ ext, int m, int* __restric
     if (threadIdx.x == 0) *nOutLds = min(total, maxOut);
 }
 
-__global__ void __launch_bounds__(256) k_noise_breaks(NoiseGrid g, int H, int W, BlockWs ws) {
+__global__ void __launch_bounds__(256) k_noise_breaks(NoiseGrid g, int H, int W, BlockWs ws, NoiseBatch nb) {
+    NF_NB_WS;
     __shared__ int E[2][NF_BRK_MAXCELLS + 1];
     __shared__ int merged[2][2 * NF_BRK_MAXCELLS + 2];   // 0, the merged boundaries, the axis length
     __shared__ int outL[2][NF_BRK_MAXOUT];
@@ -854,7 +882,9 @@ __device__ __forceinline__ void cell_range(const int* __restrict__ e, int ncell,
 // First sweep (k_noise_block_stats): valid count, sum v, sum v^2, weight ranges.
 template <typename VT, typename WT>
 __global__ void __launch_bounds__(64) k_noise_block_stats(const VT* __restrict__ v, const WT* __restrict__ wts, int W, BlockWs ws,
-                                                         int reuse) {
+                                                         int reuse, NoiseBatch nb) {
+    NF_NB_WS;
+    NF_NB_V;
     // reuse: the workspace still holds the block tables of an earlier call with the same grid and weights (k_noise_breaks did
     // not run: the call's counters are cleared here) and every block's weight range over all of its pixels (rec[10], rec[11]).
     // The weights are then read only for a block that is valid in part.
@@ -969,7 +999,9 @@ __global__ void __launch_bounds__(64) k_noise_block_stats(const VT* __restrict__
 // median of the blocks' unclipped standard deviations, weighted by their valid pixels - bright objects sit in a few blocks
 // and leave it alone.  Left in the cell record's rms slot until k_noise_windows overwrites it; -1 for a window without
 // valid pixels.  Windows of more than 64 blocks (a cell over a whole map) take the plain standard deviation of the window.
-__global__ void __launch_bounds__(64) k_noise_window_rms0(NoiseGrid g, BlockWs ws, double* __restrict__ stats) {
+__global__ void __launch_bounds__(64) k_noise_window_rms0(NoiseGrid g, BlockWs ws, double* __restrict__ stats, NoiseBatch nb) {
+    NF_NB_WS;
+    NF_NB_STATS;
     const int cell = blockIdx.x, lane = threadIdx.x;
     const int i = cell / g.nx, k = cell - i * g.nx;
     const int BY0 = ws.wY0[i], BX0 = ws.wX0[k], nbx = ws.wX1[k] - BX0, nblk = (ws.wY1[i] - BY0) * nbx;
@@ -1031,7 +1063,10 @@ __global__ void __launch_bounds__(64) k_noise_window_rms0(NoiseGrid g, BlockWs w
 // Core sums about the block mean, tail list in pixel order.  The block is found in the L2 / infinity cache.
 template <typename VT>
 __global__ void __launch_bounds__(64) k_noise_block_core(const VT* __restrict__ v, int W, NoiseGrid g, BlockWs ws,
-                                                        const double* __restrict__ stats) {
+                                                        const double* __restrict__ stats, NoiseBatch nb) {
+    NF_NB_WS;
+    NF_NB_V;
+    NF_NB_STATS;
     int by, bx;
     if (!block_of_workgroup(ws, &by, &bx)) return;
     const int y0 = ws.breakY[by], y1 = ws.breakY[by + 1], x0 = ws.breakX[bx], x1 = ws.breakX[bx + 1];
@@ -1140,7 +1175,8 @@ __device__ __forceinline__ int tail_class(bool in, double a, const double (&boun
     return k;
 }
 
-__global__ void __launch_bounds__(64 * NF_CLS_WAVES) k_noise_block_classes(BlockWs ws) {
+__global__ void __launch_bounds__(64 * NF_CLS_WAVES) k_noise_block_classes(BlockWs ws, NoiseBatch nb) {
+    NF_NB_WS;
     __shared__ int cntW[NF_CLS_WAVES][NF_NCLS];      // per wavefront and class: count, then first position
     __shared__ int clsStart[NF_NCLS + 1];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -1625,7 +1661,11 @@ __device__ __forceinline__ double window_clip(const VT* __restrict__ v, int W, c
 }
 
 template <typename VT>
-__global__ void __launch_bounds__(64) k_noise_windows(const VT* __restrict__ v, int W, NoiseGrid g, BlockWs ws, double* __restrict__ stats) {
+__global__ void __launch_bounds__(64) k_noise_windows(const VT* __restrict__ v, int W, NoiseGrid g, BlockWs ws, double* __restrict__ stats,
+                                                      NoiseBatch nb) {
+    NF_NB_WS;
+    NF_NB_V;
+    NF_NB_STATS;
     __shared__ WinLds L;
     const int cell = blockIdx.x, i = cell / g.nx, k = cell - i * g.nx;
     const int BY0 = ws.wY0[i], BX0 = ws.wX0[k], nbx = ws.wX1[k] - BX0, nblk = (ws.wY1[i] - BY0) * nbx;
@@ -1766,7 +1806,10 @@ __global__ void __launch_bounds__(64) k_noise_windows(const VT* __restrict__ v, 
 template <typename WT>
 __global__ void __launch_bounds__(NF_BLK_THREADS)
 k_noise_paint_blocks(const WT* __restrict__ wts, float* __restrict__ rmsMap, int W, NoiseGrid g, BlockWs ws,
-                     const double* __restrict__ stats) {
+                     const double* __restrict__ stats, NoiseBatch nb) {
+    NF_NB_WS;
+    NF_NB_STATS;
+    rmsMap = nb.rms[blockIdx.z];
     __shared__ double cLo[NF_PAINT_MAXCAND], cHi[NF_PAINT_MAXCAND];
     __shared__ float cR[NF_PAINT_MAXCAND];
     __shared__ int nCand, range[4];
@@ -1906,7 +1949,10 @@ __device__ float paint_pixel(const WT* __restrict__ wts, long long q, const Nois
 template <typename WT>
 __global__ void __launch_bounds__(256)
 k_noise_paint_rows(const WT* __restrict__ wts, float* __restrict__ rmsMap, int W, NoiseGrid g, BlockWs ws,
-                   const double* __restrict__ stats) {
+                   const double* __restrict__ stats, NoiseBatch nb) {
+    NF_NB_WS;
+    NF_NB_STATS;
+    rmsMap = nb.rms[blockIdx.z];
     __shared__ int bX[NF_PR_MAXBX + 1];
     __shared__ float val[NF_PR_MAXBX];
     __shared__ unsigned char uni[NF_PR_MAXBX];
@@ -2089,6 +2135,31 @@ size_t noise_workspace_bytes(const NoiseGrid& g, int H, int W) {
 
 int noise_map(int vtype, const void* filtered, const void* weights, int wtype, float* rms, int H, int W, const NoiseGrid& g,
               void* cellStats, size_t cellStatsBytes, bool tablesValid, hipStream_t s) {
+    float* one[1] = {rms};
+    return noise_map_batch(vtype, filtered, 0, weights, wtype, one, 1, 1, H, W, g, cellStats, cellStatsBytes, 0, tablesValid, s);
+}
+
+bool noise_batchable(const NoiseGrid& g) {
+    static const bool blockPath = env_flag_default_on("NF_NOISE_BLOCKS");
+    return g.estimator == 0 && g.numBins == 1 && blockPath;
+}
+
+// nb maps (vStrideBytes apart) of one grid and one weight map; map b uses the workspace cellStats + b * wsStrideBytes (each of
+// cellStatsBytes) and writes rms[b].  When the block tables are not valid they are made for nbTables >= nb workspaces, so that
+// "valid" afterwards holds for all of them.  nb > 1 needs noise_batchable(g).
+int noise_map_batch(int vtype, const void* filtered, long long vStrideBytes, const void* weights, int wtype, float* const* rmsList, int nb,
+                    int nbTables, int H, int W, const NoiseGrid& g, void* cellStats, size_t cellStatsBytes, long long wsStrideBytes,
+                    bool tablesValid, hipStream_t s) {
+    if (nb < 1 || nb > NF_SB_MAX || nbTables < nb || (nb > 1 && (!noise_batchable(g) || (wsStrideBytes & 7) != 0))) {
+        nf_set_error("noise_map_batch: 1..8 maps per launch (one-bin clipped-RMS grid mode for more than one)");
+        return NF_ERR_ARG;
+    }
+    float* rms = rmsList[0];
+    NoiseBatch nbArgs;
+    memset(&nbArgs, 0, sizeof(nbArgs));
+    nbArgs.vBytes = vStrideBytes;
+    nbArgs.wsBytes = nb > 1 || nbTables > 1 ? wsStrideBytes : 0;
+    for (int b = 0; b < nb; ++b) nbArgs.rms[b] = rmsList[b];
     if (g.numBins < 1 || g.numBins > NF_MAXBINS) {
         nf_set_error("noise_map: numNoiseBins must be in 1..16");
         return NF_ERR_ARG;
@@ -2129,17 +2200,17 @@ int noise_map(int vtype, const void* filtered, const void* weights, int wtype, f
         }
         const int reuse = tablesValid ? 1 : 0;
         if (!reuse) {
-            hipLaunchKernelGGL(k_noise_breaks, dim3(1), dim3(256), 0, s, g, H, W, ws);
+            hipLaunchKernelGGL(k_noise_breaks, dim3(1, 1, nbTables), dim3(256), 0, s, g, H, W, ws, nbArgs);
             NF_CHECK_LAUNCH("k_noise_breaks");
         }
-        dim3 gb(blocks_grid(ws)), gw(g.ny * g.nx);
+        dim3 gb(blocks_grid(ws), 1, nb), gw(g.ny * g.nx, 1, nb);
 #define NF_NB(VT, WT)                                                                                                      \
     do {                                                                                                                   \
-        hipLaunchKernelGGL((k_noise_block_stats<VT, WT>), gb, dim3(64), 0, s, (const VT*)filtered, (const WT*)weights, W, ws, reuse); \
-        hipLaunchKernelGGL(k_noise_window_rms0, gw, dim3(64), 0, s, g, ws, stats);                                         \
-        hipLaunchKernelGGL((k_noise_block_core<VT>), gb, dim3(64), 0, s, (const VT*)filtered, W, g, ws, stats);            \
-        hipLaunchKernelGGL(k_noise_block_classes, dim3(512), dim3(64 * NF_CLS_WAVES), 0, s, ws);                                    \
-        hipLaunchKernelGGL((k_noise_windows<VT>), gw, dim3(64), 0, s, (const VT*)filtered, W, g, ws, stats);               \
+        hipLaunchKernelGGL((k_noise_block_stats<VT, WT>), gb, dim3(64), 0, s, (const VT*)filtered, (const WT*)weights, W, ws, reuse, nbArgs); \
+        hipLaunchKernelGGL(k_noise_window_rms0, gw, dim3(64), 0, s, g, ws, stats, nbArgs);                                 \
+        hipLaunchKernelGGL((k_noise_block_core<VT>), gb, dim3(64), 0, s, (const VT*)filtered, W, g, ws, stats, nbArgs);    \
+        hipLaunchKernelGGL(k_noise_block_classes, dim3(512, 1, nb), dim3(64 * NF_CLS_WAVES), 0, s, ws, nbArgs);            \
+        hipLaunchKernelGGL((k_noise_windows<VT>), gw, dim3(64), 0, s, (const VT*)filtered, W, g, ws, stats, nbArgs);       \
     } while (0)
         if (vtype == NF_F64 && wtype == NF_F64) NF_NB(double, double);
         else if (vtype == NF_F64 && wtype == NF_F32) NF_NB(double, float);
@@ -2149,15 +2220,15 @@ int noise_map(int vtype, const void* filtered, const void* weights, int wtype, f
         NF_CHECK_LAUNCH("k_noise_blocks / k_noise_windows");
         static const bool paintRows = env_flag_default_on("NF_NOISE_PAINT_ROWS");
         if (paintRows && ws.maxBx <= NF_PR_MAXBX) {
-            dim3 gr((NF_BLK + NF_PR_ROWS - 1) / NF_PR_ROWS, ws.maxBy - 1);
+            dim3 gr((NF_BLK + NF_PR_ROWS - 1) / NF_PR_ROWS, ws.maxBy - 1, nb);
             if (wtype == NF_F64)
-                hipLaunchKernelGGL(k_noise_paint_rows<double>, gr, dim3(256), 0, s, (const double*)weights, rms, W, g, ws, stats);
+                hipLaunchKernelGGL(k_noise_paint_rows<double>, gr, dim3(256), 0, s, (const double*)weights, rms, W, g, ws, stats, nbArgs);
             else
-                hipLaunchKernelGGL(k_noise_paint_rows<float>, gr, dim3(256), 0, s, (const float*)weights, rms, W, g, ws, stats);
+                hipLaunchKernelGGL(k_noise_paint_rows<float>, gr, dim3(256), 0, s, (const float*)weights, rms, W, g, ws, stats, nbArgs);
         } else if (wtype == NF_F64)
-            hipLaunchKernelGGL(k_noise_paint_blocks<double>, gb, dim3(NF_BLK_THREADS), 0, s, (const double*)weights, rms, W, g, ws, stats);
+            hipLaunchKernelGGL(k_noise_paint_blocks<double>, gb, dim3(NF_BLK_THREADS), 0, s, (const double*)weights, rms, W, g, ws, stats, nbArgs);
         else
-            hipLaunchKernelGGL(k_noise_paint_blocks<float>, gb, dim3(NF_BLK_THREADS), 0, s, (const float*)weights, rms, W, g, ws, stats);
+            hipLaunchKernelGGL(k_noise_paint_blocks<float>, gb, dim3(NF_BLK_THREADS), 0, s, (const float*)weights, rms, W, g, ws, stats, nbArgs);
         NF_CHECK_LAUNCH("k_noise_paint_blocks / k_noise_paint_rows");
         return NF_OK;
     }

@@ -193,11 +193,16 @@ __global__ void k_build_filter(const T* __restrict__ cov, const cpx<TS>* __restr
 // (-y, -x), computes both filter values exactly as k_build_filter does, stores them, and stores 0.5 (a + b) as
 // k_symmetrise_filter would - the filter cube is not read back.  In the self-mirrored columns (x = 0, and x = W/2 for even W)
 // the mirror mode belongs to another thread of the same column: its value is computed here too, but stored there.
+// blockIdx.z: one filter per entry of a batch (the scales of a tile: same covariance and weights, another signal spectrum) -
+// signal spectra and symmetrised filters lie batch entry after batch entry, the float32 cubes are the callers' (fp.p[z], or null).
 template <typename T, typename TS, int N>
-__global__ void k_build_filter_sym(const T* __restrict__ cov, const cpx<TS>* __restrict__ S, nf::WeightVec w,
-                                   float* __restrict__ filt, double* __restrict__ sym, int H, int W) {
+__global__ void k_build_filter_sym(const T* __restrict__ cov, const cpx<TS>* __restrict__ S0, nf::WeightVec w,
+                                   nf::BatchPtrs fp, double* __restrict__ sym0, int H, int W) {
     const int hw = W / 2 + 1;
     const long long npix = (long long)H * W;
+    const cpx<TS>* __restrict__ S = S0 + (long long)blockIdx.z * N * npix;
+    double* __restrict__ sym = sym0 + (long long)blockIdx.z * N * npix;
+    float* __restrict__ filt = (float*)fp.p[blockIdx.z];
     for (int y = blockIdx.y; y < H; y += gridDim.y) {
         const int ym = y == 0 ? 0 : H - y;
         for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < hw; x += gridDim.x * blockDim.x) {
@@ -254,12 +259,12 @@ static int build_filter_n(const void* cov, const void* S, const WeightVec& w, fl
 }
 
 template <typename T, typename TS>
-static int build_filter_sym_n(const void* cov, const void* S, const WeightVec& w, float* filt, double* sym, int N, int H, int W,
-                              hipStream_t s) {
-    dim3 g(nf_div_up(W / 2 + 1, 256), H < 4096 ? H : 4096), b(256);
+static int build_filter_sym_n(const void* cov, const void* S, const WeightVec& w, const BatchPtrs& fp, int nb, double* sym, int N, int H,
+                              int W, hipStream_t s) {
+    dim3 g(nf_div_up(W / 2 + 1, 256), H < 4096 ? H : 4096, nb), b(256);
 #define NF_BFS(NN)                                                                                                             \
     case NN:                                                                                                                   \
-        hipLaunchKernelGGL((k_build_filter_sym<T, TS, NN>), g, b, 0, s, (const T*)cov, (const cpx<TS>*)S, w, filt, sym, H, W); \
+        hipLaunchKernelGGL((k_build_filter_sym<T, TS, NN>), g, b, 0, s, (const T*)cov, (const cpx<TS>*)S, w, fp, sym, H, W);   \
         break;
     switch (N) {
         NF_BFS(1)
@@ -277,14 +282,26 @@ static int build_filter_sym_n(const void* cov, const void* S, const WeightVec& w
     return NF_OK;
 }
 
-int build_filter_sym(int covType, int sigType, const void* cov, const void* S, const WeightVec& w, float* filt, double* sym, int N,
-                     int H, int W, hipStream_t s) {
-    if (covType == NF_F64 && sigType == NF_F32) return build_filter_sym_n<double, float>(cov, S, w, filt, sym, N, H, W, s);
-    if (covType == NF_F64 && sigType == NF_F64) return build_filter_sym_n<double, double>(cov, S, w, filt, sym, N, H, W, s);
-    if (covType == NF_F32 && sigType == NF_F32) return build_filter_sym_n<float, float>(cov, S, w, filt, sym, N, H, W, s);
-    if (covType == NF_F32 && sigType == NF_F64) return build_filter_sym_n<float, double>(cov, S, w, filt, sym, N, H, W, s);
+int build_filter_sym_batch(int covType, int sigType, const void* cov, const void* S, const WeightVec& w, const BatchPtrs& filt, int nb,
+                           double* sym, int N, int H, int W, hipStream_t s) {
+    if (nb < 1 || nb > NF_SB_MAX) {
+        nf_set_error("build_filter_sym_batch: 1..8 filters per launch");
+        return NF_ERR_ARG;
+    }
+    if (covType == NF_F64 && sigType == NF_F32) return build_filter_sym_n<double, float>(cov, S, w, filt, nb, sym, N, H, W, s);
+    if (covType == NF_F64 && sigType == NF_F64) return build_filter_sym_n<double, double>(cov, S, w, filt, nb, sym, N, H, W, s);
+    if (covType == NF_F32 && sigType == NF_F32) return build_filter_sym_n<float, float>(cov, S, w, filt, nb, sym, N, H, W, s);
+    if (covType == NF_F32 && sigType == NF_F64) return build_filter_sym_n<float, double>(cov, S, w, filt, nb, sym, N, H, W, s);
     nf_set_error("build_filter: bad dtype");
     return NF_ERR_ARG;
+}
+
+int build_filter_sym(int covType, int sigType, const void* cov, const void* S, const WeightVec& w, float* filt, double* sym, int N,
+                     int H, int W, hipStream_t s) {
+    BatchPtrs fp;
+    memset(&fp, 0, sizeof(fp));
+    fp.p[0] = filt;
+    return build_filter_sym_batch(covType, sigType, cov, S, w, fp, 1, sym, N, H, W, s);
 }
 
 int build_filter(int covType, int sigType, const void* cov, const void* S, const WeightVec& w, float* filt, int N,
@@ -573,11 +590,18 @@ int sn_cached(int vtype, const void* data, const float* rms, double* sn, long lo
 //   SN = filtered / RMS where RMS > 0 (else filtered);  edge = edgeCheck (or 1)
 //   filtered' = filtered*edge [*surveyMask' if fourier variant];  surveyMask' = edge*surveyMask*psMask
 //   surveyMask'' = surveyMask' * apodMask;  SN' = SN*surveyMask'' (NaN -> 0);  RMS' = RMS*surveyMask''
+// blockIdx.y: one map per entry of a batch (the scales of a tile share the masks; every other operand is per map, fb.*[y]).
 template <typename VT>
-__global__ void __launch_bounds__(256) k_finalize(VT* __restrict__ filtered, const float* rms, const unsigned char* __restrict__ surveyMask,
-                           const unsigned char* __restrict__ psMask, const unsigned char* __restrict__ edgeCheck, VT* __restrict__ snOut,
-                           float* rmsOut, unsigned char* __restrict__ maskOut, int H, int W, int apodPix,
-                           int mulSurvey, unsigned long long* __restrict__ chunkRange, int nchunks, int* __restrict__ zeroRows) {
+__global__ void __launch_bounds__(256) k_finalize(nf::FinalizeBatch fb, const unsigned char* __restrict__ surveyMask,
+                           const unsigned char* __restrict__ psMask, int H, int W, int apodPix, int mulSurvey, int nchunks) {
+    VT* __restrict__ filtered = (VT*)fb.filtered[blockIdx.y];
+    const float* rms = fb.rms[blockIdx.y];
+    const unsigned char* __restrict__ edgeCheck = fb.edgeCheck[blockIdx.y];
+    VT* __restrict__ snOut = (VT*)fb.snOut[blockIdx.y];
+    float* rmsOut = fb.rmsOut[blockIdx.y];
+    unsigned char* __restrict__ maskOut = fb.maskOut[blockIdx.y];
+    unsigned long long* __restrict__ chunkRange = fb.chunkRange[blockIdx.y];
+    int* __restrict__ zeroRows = fb.zeroRows[blockIdx.y];
     const long long n = (long long)H * W;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wavesPerWG = blockDim.x >> 6;
     // a wavefront takes one 1024-pixel chunk after another, 64 consecutive pixels at a time: the chunk's largest and smallest
@@ -637,24 +661,42 @@ __global__ void __launch_bounds__(256) k_finalize(VT* __restrict__ filtered, con
     }
 }
 
-int finalize(int vtype, void* filtered, const float* rms, const unsigned char* surveyMask, const unsigned char* psMask,
-             const unsigned char* edgeCheck, void* snOut, float* rmsOut, unsigned char* maskOut, int H, int W, int apodPix,
-             int mulSurvey, unsigned long long* chunkRange, int* zeroRows, hipStream_t s) {
+// (the zeroRows arrays of a batch are cleared by the caller)
+int finalize_batch(int vtype, const FinalizeBatch& fb, int nb, const unsigned char* surveyMask, const unsigned char* psMask, int H, int W,
+                   int apodPix, int mulSurvey, hipStream_t s) {
     if ((long long)H * W >= 2147483647LL) {
         nf_set_error("finalize: map too large for 32-bit pixel indices");
         return NF_ERR_SIZE;
     }
+    if (nb < 1 || nb > NF_SB_MAX) {
+        nf_set_error("finalize_batch: 1..8 maps per launch");
+        return NF_ERR_ARG;
+    }
     const int nchunks = nf_div_up((long long)H * W, NF_SN_CHUNK);
-    if (zeroRows != nullptr) NF_HIP(hipMemsetAsync(zeroRows, 0, (size_t)H * sizeof(int), s));
-    dim3 g(grid_for((long long)nchunks * 64, 256)), b(256);        // one wavefront per chunk, as many at a time as the grid holds
+    dim3 g(grid_for((long long)nchunks * 64, 256), nb), b(256);        // one wavefront per chunk, as many at a time as the grid holds
     if (vtype == NF_F64)
-        hipLaunchKernelGGL(k_finalize<double>, g, b, 0, s, (double*)filtered, rms, surveyMask, psMask, edgeCheck, (double*)snOut,
-                           rmsOut, maskOut, H, W, apodPix, mulSurvey, chunkRange, nchunks, zeroRows);
+        hipLaunchKernelGGL(k_finalize<double>, g, b, 0, s, fb, surveyMask, psMask, H, W, apodPix, mulSurvey, nchunks);
     else
-        hipLaunchKernelGGL(k_finalize<float>, g, b, 0, s, (float*)filtered, rms, surveyMask, psMask, edgeCheck, (float*)snOut,
-                           rmsOut, maskOut, H, W, apodPix, mulSurvey, chunkRange, nchunks, zeroRows);
+        hipLaunchKernelGGL(k_finalize<float>, g, b, 0, s, fb, surveyMask, psMask, H, W, apodPix, mulSurvey, nchunks);
     NF_CHECK_LAUNCH("k_finalize");
     return NF_OK;
+}
+
+int finalize(int vtype, void* filtered, const float* rms, const unsigned char* surveyMask, const unsigned char* psMask,
+             const unsigned char* edgeCheck, void* snOut, float* rmsOut, unsigned char* maskOut, int H, int W, int apodPix,
+             int mulSurvey, unsigned long long* chunkRange, int* zeroRows, hipStream_t s) {
+    if (zeroRows != nullptr) NF_HIP(hipMemsetAsync(zeroRows, 0, (size_t)H * sizeof(int), s));
+    FinalizeBatch fb;
+    memset(&fb, 0, sizeof(fb));
+    fb.filtered[0] = filtered;
+    fb.rms[0] = rms;
+    fb.edgeCheck[0] = edgeCheck;
+    fb.snOut[0] = snOut;
+    fb.rmsOut[0] = rmsOut;
+    fb.maskOut[0] = maskOut;
+    fb.chunkRange[0] = chunkRange;
+    fb.zeroRows[0] = zeroRows;
+    return finalize_batch(vtype, fb, 1, surveyMask, psMask, H, W, apodPix, mulSurvey, s);
 }
 
 // ---------------------------------------------------------------------------------------------------

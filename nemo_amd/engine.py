@@ -108,6 +108,7 @@ def ptr(t):
 
 
 _PINNED_COPY_MAX = 4 << 20
+SCALE_BATCH = None            # scales per group of nf_matched_filter_scales (None: by tile size, Engine.scale_batch)
 _AXIS_WINDOW = os.environ.get('NEMO_AMD_AXIS_WINDOW', '1') != '0'    # 0: apply_window through the 2-D transforms always
 
 
@@ -533,6 +534,16 @@ class TileEngine(object):
         check(self.lib.nf_signal_norm(0 if outputUnits == 'yc' else 1, ptr(src), float(y0), ptr(out), stream_ptr()), "nf_signal_norm")
         return DeviceScalar(out, wide=outputUnits == 'yc')
 
+    def scale_batch(self):
+        """Scales of a tile that walk nf_matched_filter_scales' sequence together (nf_mf_tile.scaleBatch): 8 on 1-2 Mpix tiles -
+        one map's kernels leave most of the 256 CUs idle there - falling to 1 where a single map fills the chip and the
+        scale-after-scale order keeps a scale's intermediates in the Infinity Cache.  SCALE_BATCH (module attribute) or
+        NEMO_AMD_SCALE_BATCH override."""
+        v = SCALE_BATCH if SCALE_BATCH is not None else os.environ.get('NEMO_AMD_SCALE_BATCH', None)
+        if v is not None and int(v) > 0:
+            return min(int(v), 8)
+        return 8 if self.npix <= 2.5e6 else (4 if self.npix <= 5e6 else (2 if self.npix <= 9e6 else 1))
+
     def matched_filter_scales(self, tile, scales, lanes, noiseKey=None):
         """nf_matched_filter_scales: ``tile`` an _lib.MfTile, ``scales`` a ctypes array of _lib.MfScale.  The lanes' workspaces
         are kept by the engine (one set per size) and reused call after call: calls are ordered by the stream they are made
@@ -541,6 +552,7 @@ class TileEngine(object):
         t = self.t
         n = len(scales)
         lanes = max(1, min(int(lanes), n, int(self.lib.nf_matched_filter_max_lanes())))
+        tile.scaleBatch = self.scale_batch()
         nbytes = int(self.lib.nf_matched_filter_workspace_bytes(ctypes.byref(tile)))
         if nbytes == 0:
             check(-1, "nf_matched_filter_workspace_bytes")

@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 import helpers  # noqa: E402
-from nemo_amd import filters  # noqa: E402
+from nemo_amd import engine, filters  # noqa: E402
 
 CASES = [
     # shape, freqs, fwhm, noise, kind, class, outputUnits, dtype, extra params, undoPixelWindow
@@ -23,12 +23,19 @@ CASES = [
     ((211, 256), (150.0,), (1.4,), (20.0,), 'beam', 'BeamMatchedFilter', 'uK', np.float64, {'edgeTrimArcmin': 2.0}, True),
     ((211, 256), (150.0, 98.0), (1.4, 2.1), (15.0, 20.0), 'arnaud', 'ArnaudModelMatchedFilter', 'yc', np.float32, {}, False),
     ((160, 200), (150.0,), (1.4,), (20.0,), 'beam', 'BeamMatchedFilter', 'uK', np.float32, {}, True),
+    # one noise bin: the block form of the noise map, which takes the scales of a group as its batch dimension too
+    ((211, 256), (150.0, 98.0), (1.4, 2.1), (15.0, 20.0), 'arnaud', 'ArnaudModelMatchedFilter', 'yc', np.float32,
+     {'noiseParams': {'method': 'dataMap', 'noiseGridArcmin': 20., 'numNoiseBins': 1}}, True),
+    ((160, 200), (150.0,), (1.4,), (20.0,), 'arnaud', 'ArnaudModelMatchedFilter', 'yc', np.float64,
+     {'noiseParams': {'method': 'dataMap', 'noiseGridArcmin': 15., 'numNoiseBins': 1}, 'edgeTrimArcmin': 2.0}, True),
+    ((200, 240), (150.0, 98.0), (1.4, 2.1), (15.0, 20.0), 'beam', 'BeamMatchedFilter', 'uK', np.float32,
+     {'noiseParams': {'method': 'dataMap', 'noiseGridArcmin': 20., 'numNoiseBins': 1}}, True),
 ]
 
 
-def _run(mapsL, filtersList, undo, lanes, entry):
-    keepEntry, keepDev = filters._SCALE_ENTRY, filters.RETURN_DEVICE_ARRAYS
-    filters._SCALE_ENTRY, filters.RETURN_DEVICE_ARRAYS = entry, True
+def _run(mapsL, filtersList, undo, lanes, entry, batch=None):
+    keepEntry, keepDev, keepBatch = filters._SCALE_ENTRY, filters.RETURN_DEVICE_ARRAYS, engine.SCALE_BATCH
+    filters._SCALE_ENTRY, filters.RETURN_DEVICE_ARRAYS, engine.SCALE_BATCH = entry, True, batch
     try:
         res = filters.filterMapsGroup(helpers.product_maps(mapsL), filtersList, 'PRIMARY', diagnosticsDir=None, selFnDir=None,
                                       verbose=False, undoPixelWindow=undo, tileCache={}, lanes=lanes)
@@ -40,7 +47,7 @@ def _run(mapsL, filtersList, undo, lanes, entry):
         torch.cuda.synchronize()
         return out
     finally:
-        filters._SCALE_ENTRY, filters.RETURN_DEVICE_ARRAYS = keepEntry, keepDev
+        filters._SCALE_ENTRY, filters.RETURN_DEVICE_ARRAYS, engine.SCALE_BATCH = keepEntry, keepDev, keepBatch
 
 
 @pytest.mark.parametrize("case", CASES, ids=[str(i) for i in range(len(CASES))])
@@ -61,9 +68,10 @@ def test_scale_entry_equals_statement_path(case):
     before = dict(filters._scaleEntryStats)
     ref = _run(mapsL, filtersList, undo, 1, False)
     assert filters._scaleEntryStats == before          # the statement-by-statement path
-    for lanes in (1, 3):
+    # (lanes, scales per group): scale after scale; groups of 8 (all five scales in one launch per stage), of 2 and of 3
+    for lanes, batch in ((1, 1), (3, 1), (1, 8), (2, 2), (1, 3)):
         before = dict(filters._scaleEntryStats)
-        got = _run(mapsL, filtersList, undo, lanes, True)
+        got = _run(mapsL, filtersList, undo, lanes, True, batch)
         # all scales of the bank went out in ONE library call
         assert filters._scaleEntryStats['calls'] == before['calls'] + 1
         assert filters._scaleEntryStats['scales'] == before['scales'] + len(filtersList)
@@ -76,7 +84,7 @@ def test_scale_entry_equals_statement_path(case):
                 assert type(g['fRelWeights'][f]) == type(r['fRelWeights'][f]) and g['fRelWeights'][f] == r['fRelWeights'][f]
             for key in ('filt', 'data', 'SNMap', 'RMSMap', 'surveyMask'):
                 assert g[key].dtype == r[key].dtype and g[key].shape == r[key].shape, key
-                assert np.array_equal(g[key], r[key]), (key, lanes)
+                assert np.array_equal(g[key], r[key]), (key, lanes, batch)
     # the scales differ from each other (the comparison above is not between copies of one map)
     if kind == 'arnaud':
         assert not np.array_equal(ref[0]['data'], ref[1]['data'])

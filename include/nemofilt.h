@@ -408,7 +408,7 @@ int nf_spline_eval(int vtype, const void* map_d, int negate, int H, int W, const
 /* nf_spline_eval for several (map, point list) jobs at once - what one detection pass reads off its maps at the object
  * positions (nemo/photometry.py:128 on the S/N map; :276-281 and :354-361 on the filtered map and on the reference scale's two
  * maps, called from nemo/pipelines.py:299-311): one launch per kernel instead of one per map.  All maps have dtype `vtype`
- * and shape [H, W].  Host arrays of nJobs (<= 8) entries: maps_d, negate, yx_d (nPts[j] pairs each), out_d (nPts[j] doubles
+ * and shape [H, W].  Host arrays of nJobs (<= 32) entries: maps_d, negate, yx_d (nPts[j] pairs each), out_d (nPts[j] doubles
  * each), edgeSel_d / nEdge (indices of job j's points whose window meets the map border; edgeSel_d[j] NULL: unknown, every
  * point is offered to both kernels). */
 int nf_spline_eval_batch(int vtype, int nJobs, const void* const* maps_d, const int* negate, const double* const* yx_d,

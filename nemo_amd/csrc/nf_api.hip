@@ -820,7 +820,7 @@ int nf_spline_eval_batch(int vtype, int nJobs, const void* const* maps, const in
                          const int* const* edgeSel, const int* nEdge, double* const* out, int H, int W, int halfWin, void* stream) {
     if (nJobs < 0 || nJobs > NF_SPL_MAXJOBS || !maps || !negate || !yx || !nPts || !edgeSel || !nEdge || !out || H < 4 || W < 4 ||
         (vtype != NF_F32 && vtype != NF_F64)) {
-        nf_set_error("nf_spline_eval_batch: bad arguments (at most 8 jobs)");
+        nf_set_error("nf_spline_eval_batch: bad arguments (at most 32 jobs)");
         return NF_ERR_ARG;
     }
     nf::SplineBatch b;

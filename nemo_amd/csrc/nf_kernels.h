@@ -145,7 +145,7 @@ int spline_eval(int vtype, const void* map, int negate, int H, int W, const doub
                 double* out, hipStream_t s);
 
 // jobs of one batched spline evaluation (kernel argument, by value)
-#define NF_SPL_MAXJOBS 8
+#define NF_SPL_MAXJOBS 32
 struct SplineBatch {
     const void* map[NF_SPL_MAXJOBS];      // the maps, all of one dtype
     const double* yx[NF_SPL_MAXJOBS];     // (y, x) pairs

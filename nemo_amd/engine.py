@@ -1035,9 +1035,10 @@ class TileEngine(object):
             out.append(_SplinePoints(dev[off:off + 2 * n], n, pointsClass, halfWin, edge, len(edgeIdx)))
         return out
 
-    def spline_eval_batch(self, jobs):
-        """[(map tensor, _SplinePoints, negate)] -> list of float64 device tensors, one launch per kernel for all jobs of a
-        dtype (nf_spline_eval_batch)."""
+    def spline_eval_batch(self, jobs, returnFlat=False):
+        """[(map tensor, _SplinePoints, negate)] -> list of float64 device tensors, one launch per kernel for up to 32 jobs of a
+        dtype (nf_spline_eval_batch).  The results are views of one buffer, job after job (``returnFlat``: that buffer too).
+        A point set with nEdge < 0 does not know which of its points lie near the border: every point is offered to both kernels."""
         t = self.t
         outs = [None] * len(jobs)
         total = sum(pts.n for _, pts, _ in jobs)
@@ -1050,23 +1051,25 @@ class TileEngine(object):
             if pts.n > 0:
                 groups.setdefault((prec_of(m), pts.halfWin), []).append(k)
         VP, CI = ctypes.c_void_p, ctypes.c_int
+        base = flat.data_ptr()
         for (prec, halfWin), ks in groups.items():
-            for c0 in range(0, len(ks), 8):
-                part = ks[c0:c0 + 8]
+            for c0 in range(0, len(ks), 32):
+                part = ks[c0:c0 + 32]
                 nj = len(part)
                 maps = (VP * nj)(*[jobs[k][0].data_ptr() for k in part])
                 negs = (CI * nj)(*[1 if jobs[k][2] else 0 for k in part])
-                yxs = (VP * nj)(*[jobs[k][1].dev.data_ptr() for k in part])
+                yxp = [jobs[k][1].dev.data_ptr() for k in part]
+                yxs = (VP * nj)(*yxp)
                 ns = (CI * nj)(*[jobs[k][1].n for k in part])
-                edges = (VP * nj)(*[(jobs[k][1].edge.data_ptr() if jobs[k][1].edge is not None else None) for k in part])
                 # (no border points: an empty list, not "unknown" - the pointer must still be non-null to say so)
-                for i, k in enumerate(part):
-                    if jobs[k][1].edge is None:
-                        edges[i] = jobs[k][1].dev.data_ptr()
-                nes = (CI * nj)(*[jobs[k][1].nEdge for k in part])
-                os_ = (VP * nj)(*[outs[k].data_ptr() for k in part])
+                edges = (VP * nj)(*[(None if jobs[k][1].nEdge < 0 else (jobs[k][1].edge.data_ptr() if jobs[k][1].edge is not None else yxp[i]))
+                                    for i, k in enumerate(part)])
+                nes = (CI * nj)(*[max(jobs[k][1].nEdge, 0) for k in part])
+                os_ = (VP * nj)(*[base + 8 * outs[k].storage_offset() for k in part])
                 check(self.lib.nf_spline_eval_batch(prec, nj, maps, negs, yxs, ns, edges, nes, os_, self.H, self.W, halfWin, stream_ptr()),
                       "nf_spline_eval_batch")
+        if returnFlat:
+            return outs, flat[:total]
         return outs
 
     def spline_eval(self, m, yx, negate=False, halfWin=32, to_host=True):

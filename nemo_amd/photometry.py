@@ -144,6 +144,10 @@ def findObjectsGroup(filteredMapDictList, _prefetch=None, **kwargs):
     by map.  ``_prefetch``: one list per map (see findObjects)."""
     if _prefetch is None:
         _prefetch = [None] * len(filteredMapDictList)
+    if _VECTOR_GROUP and len(filteredMapDictList) > 1:
+        res = _findObjectsVector(filteredMapDictList, _prefetch, **kwargs)
+        if res is not None:
+            return res
     gens = [_findObjectsSteps(d, _prefetch=pf, _slot=k, **kwargs) for k, (d, pf) in enumerate(zip(filteredMapDictList, _prefetch))]
     results = [None] * len(gens)
     waiting = {}
@@ -161,6 +165,155 @@ def findObjectsGroup(filteredMapDictList, _prefetch=None, **kwargs):
             except StopIteration as e:
                 results[i] = e.value
         waiting = nxt
+    return results
+
+
+_VECTOR_GROUP = os.environ.get('NEMO_AMD_VECTOR_DETECT', '1') != '0'      # 0: every map of a group through _findObjectsSteps
+
+
+def _findObjectsVector(dicts, prefetch, threshold=3.0, minObjPix=3, rejectBorder=10, findCenterOfMass=True, flagRings=True,
+                       ringThresholdSigma=0, ringFlagDistArcmin=12.0, ringFlagMinRingerSNR=20, invertMap=False,
+                       objIdent='ACT-CL', longNames=False, verbose=True, useInterpolator=True, measureShapes=False,
+                       DS9RegionsPath=None):
+    """findObjects for the maps of a group that share their tile (shape, WCS, flag mask) - the scales of a tile - with the
+    host side written once for all of them: one numpy statement per step over the concatenated object lists instead of one
+    per map, one upload of all positions, one spline batch per 32 reads, one transfer of all values.  The same arithmetic per
+    object as _findObjectsSteps (same catalogues, row for row); returns None when the group is not of that kind (the
+    caller then walks the maps one by one)."""
+    if threshold < 0 or flagRings == True or measureShapes == True or useInterpolator != True:
+        return None
+    first = dicts[0]
+    wcs, flagMask = first['wcs'], first['flagMask']
+    shape = tuple(first['SNMap'].shape)
+    for d in dicts:
+        if d['wcs'] is not wcs or d['flagMask'] is not flagMask or tuple(d['SNMap'].shape) != shape or not hasattr(d['SNMap'], 'is_cuda'):
+            return None
+    import time
+    tm = time.perf_counter() if _TIMING else 0.0
+    t = engine.torch()
+    M = len(dicts)
+    H, W = shape
+    eng = engine.TileEngine.get(shape)
+    cap = eng.statsCap
+    dSNs, recs = [], []
+    for d in dicts:
+        dSN = d['SNMap']
+        hint = d.get('_snChunks', None) if hasattr(d, 'get') else None
+        snChunks = hint[1] if (hint is not None and hint[0] is dSN and hint[0].data_ptr() == dSN.data_ptr()) else None
+        labels, rec = eng.label_and_stats(dSN, threshold, negate=invertMap, slot='objects', cap=cap, snChunks=snChunks)
+        dSNs.append(dSN)
+        recs.append(rec)
+    tm = _mark('label+stats enqueue', tm)
+    flagAny = first.get('_flagAny', None) if hasattr(first, 'get') else None
+    if flagAny is not None and flagAny[0] is not flagMask:
+        flagAny = None
+    parts = [r.reshape(-1) for r in recs] + ([flagAny[1].reshape(-1).to(t.float64)] if flagAny is not None else [])
+    flat = t.cat(parts).cpu().numpy()
+    tm = _mark('stats fetch', tm)
+    recLen = (cap + 1) * 6
+    S = flat[:M * recLen].reshape(M, cap + 1, 6)
+    noFlags = flagAny is not None and flat[M * recLen] == 0.0
+    numObjects = S[:, 0, 0].astype(np.int64)
+    if (numObjects > cap).any():
+        eng.statsCap = 2 * int(numObjects.max())     # more labels than the record table held: the one-by-one path runs again with room
+        return None
+    results = [[] for _ in range(M)]
+    # objects passing the size cut, map after map, in label order
+    valid = (np.arange(1, cap + 1)[None, :] <= numObjects[:, None]) & (S[:, 1:, 0] >= minObjPix)
+    mi, li = np.nonzero(valid)
+    if len(mi) == 0:
+        return results
+    rows = S[mi, li + 1]
+    if findCenterOfMass:
+        ys = rows[:, 2] / rows[:, 1]
+        xs = rows[:, 3] / rows[:, 1]
+    else:
+        idx = rows[:, 5].astype(np.int64)
+        ys = (idx // W).astype(np.float64)
+        xs = (idx % W).astype(np.float64)
+    iyr, ixr = np.round(ys).astype(np.int64), np.round(xs).astype(np.int64)
+    counts = np.bincount(mi, minlength=M)
+    offs = np.concatenate([[0], np.cumsum(counts)])
+    RADeg, decDeg = wcs.pix2wcs(xs, ys)                                           # :115-117
+    RADeg = np.where(RADeg < 0, 360.0 + RADeg, RADeg)
+    havePre = any(bool(pf) for pf in prefetch)
+    # every position in one upload: the detections' own (S/N read) and - for the prefetch reads - the positions measureFluxes /
+    # getSNRValues will compute from the catalogue's coordinates, clamped to the map as FITPACK clamps them
+    if havePre:
+        x2, y2 = wcs.wcs2pix(np.asarray(RADeg, dtype=np.float64), np.asarray(decDeg, dtype=np.float64))
+        x2, y2 = np.atleast_1d(x2), np.atleast_1d(y2)
+        inside = (x2.astype(np.int64) > 0) & (x2.astype(np.int64) < W) & (y2.astype(np.int64) > 0) & (y2.astype(np.int64) < H)
+        yx = np.concatenate([np.stack([ys, xs], axis=1), np.stack([np.clip(y2, 0.0, H - 1.0), np.clip(x2, 0.0, W - 1.0)], axis=1)])
+    else:
+        yx = np.stack([ys, xs], axis=1)
+    n = len(ys)
+    yxDev = engine.to_dev(np.ascontiguousarray(yx).reshape(-1))
+    jobs, keys = [], []           # (map, points of the map's own objects, negate)
+    for k in range(M):
+        a, b = int(offs[k]), int(offs[k + 1])
+        if b == a:
+            continue
+        ptsSN = engine._SplinePoints(yxDev[2 * a:2 * b], b - a, 0, 32, None, -1)
+        jobs.append((dSNs[k], ptsSN, invertMap))
+        keys.append((k, 'SNR'))
+        if prefetch[k]:
+            pts = engine._SplinePoints(yxDev[2 * (n + a):2 * (n + b)], b - a, 0, 32, None, -1)
+            for j, (mapLike, neg) in enumerate(prefetch[k]):
+                jobs.append((engine.to_dev(mapLike), pts, neg))
+                keys.append((k, j))
+    outs, flatOut = eng.spline_eval_batch(jobs, returnFlat=True)
+    queued = flatOut
+    if not noFlags and hasattr(flagMask, 'is_cuda'):
+        queued = t.cat([flatOut, _lookupDev(flagMask, iyr, ixr)])
+    tm = _mark('positions + enqueue reads', tm)
+    vals = queued.cpu().numpy()
+    tm = _mark('fetch reads', tm)
+    flagsOnDevice = hasattr(flagMask, 'is_cuda')
+    if flagsOnDevice and noFlags:
+        flagsAll = np.zeros(n, dtype=_numpyDtype(flagMask))
+    elif flagsOnDevice:
+        flagsAll = vals[len(vals) - n:].astype(_numpyDtype(flagMask))
+    else:
+        flagsAll = np.asarray(flagMask)[iyr, ixr]
+    got, pos = {}, 0
+    for key, (m_, pts_, neg_) in zip(keys, jobs):
+        got[key] = vals[pos:pos + pts_.n]
+        pos += pts_.n
+    SNRs = np.concatenate([got[(k, 'SNR')] for k in range(M) if counts[k] > 0])
+    keep = SNRs > threshold                                                       # :186
+    gal = galacticLatDeg(RADeg, decDeg)
+    numSigPix = rows[:, 0]
+    for k in range(M):
+        a, b = int(offs[k]), int(offs[k + 1])
+        if b == a:
+            continue
+        kp = keep[a:b]
+        nk = int(kp.sum())
+        if nk == 0:
+            continue
+        d = dicts[k]
+        tab = catalogs.Table()
+        tab.setLazyNames(objIdent, longNames)                                      # :120-123 (built on first access)
+        c = tab._cols
+        c['RADeg'] = RADeg[a:b][kp]
+        c['decDeg'] = decDeg[a:b][kp]
+        c['SNR'] = SNRs[a:b][kp]
+        c['numSigPix'] = numSigPix[a:b][kp]
+        c['template'] = np.full(nk, d['label'], dtype='U%d' % max(30, len(d['label'])))
+        c['tileName'] = np.full(nk, d['tileName'], dtype='U%d' % max(30, len(d['tileName'])))
+        ringFlag = np.zeros(nk, dtype=bool)
+        c['flags'] = flagsAll[a:b][kp] + ringFlag                                  # :208 (flags += ringFlag: no rings here)
+        c['ringFlag'] = ringFlag
+        c['galacticLatDeg'] = gal[a:b][kp]
+        c['x'] = xs[a:b][kp]
+        c['y'] = ys[a:b][kp]
+        # column order as findObjects leaves it: flags is set again last there, which keeps its place
+        if prefetch[k]:
+            tab._prefetched = {}
+            for j, (mapLike, neg) in enumerate(prefetch[k]):
+                tab._prefetched[(id(mapLike), bool(neg))] = (got[(k, j)][kp], inside[a:b][kp], nk)
+        results[k] = tab
+    tm = _mark('table', tm)
     return results
 
 

@@ -82,6 +82,46 @@ def test_pipeline_async_equals_sync_and_matches_oracle():
     assert np.abs(np.array(strongRef) / np.array(strongGot) - 1).max() < 2e-5
 
 
+@pytest.mark.parametrize("threshold,measure", [(4.0, True), (2.5, True), (3.0, False)])
+def test_group_detection_written_once_equals_map_by_map(threshold, measure):
+    """photometry._findObjectsVector (the detections of a tile's scales with the host side written once for all of them) against
+    the map-by-map generators: the optimal catalogue and every per-scale catalogue, column for column, bit for bit."""
+    from nemo_amd import photometry
+    mapsL, wcs, truth = helpers.make_tile(SHAPE, freqs=(150.0, 98.0), fwhm=(1.4, 2.1), noise=(12.0, 16.0), seed=21,
+                                          numSources=8, kind='clusters', holes=True)
+    keep = photometry._VECTOR_GROUP
+    seen = {}
+    orig = pipelines._detectAndMeasure
+
+    def spy(config, jobs, *a, **kw):
+        cats = orig(config, jobs, *a, **kw)
+        for job, c in zip(jobs, cats):
+            seen.setdefault(photometry._VECTOR_GROUP, {})[job[0]] = c
+        return cats
+    pipelines._detectAndMeasure = spy
+    try:
+        out = {}
+        for mode in (True, False):
+            photometry._VECTOR_GROUP = mode
+            out[mode] = pipelines.filterMapsAndMakeCatalogs(_config(helpers.product_maps(mapsL), thresholdSigma=threshold,
+                                                                    asyncDetection=False), measureFluxes=measure, verbose=False)
+    finally:
+        photometry._VECTOR_GROUP = keep
+        pipelines._detectAndMeasure = orig
+    assert len(out[True]) >= 3 and list(out[True].keys()) == list(out[False].keys())
+    for k in out[True].keys():
+        assert np.asarray(out[True][k]).dtype == np.asarray(out[False][k]).dtype, k
+        assert np.array_equal(np.asarray(out[True][k]), np.asarray(out[False][k])), k
+    assert set(seen[True].keys()) == set(seen[False].keys()) and len(seen[True]) == len(SCALES)
+    for lab in seen[True]:
+        a, b = seen[True][lab], seen[False][lab]
+        assert len(a) == len(b) and len(a) > 0
+        assert list(a.keys()) == list(b.keys()), lab
+        for k in a.keys():
+            assert np.asarray(a[k]).dtype == np.asarray(b[k]).dtype, (lab, k)
+            assert np.array_equal(np.asarray(a[k]), np.asarray(b[k])), (lab, k)
+
+
 def test_cached_filter_and_rms_refilter_mode():
     """The mode maps.sourceInjectionTest drives (nemo/maps.py:2047-2049, nemo/pipelines.py:234-250): only the reference
     filter, cached filter cube + cached RMS map, pixel window undone after the new S/N map."""

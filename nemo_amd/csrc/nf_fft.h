@@ -80,6 +80,17 @@ struct LineArgs {
     const double* apodElem;  // optional per-element apodisation factors (length n)
 };
 
+// The template path of one matched-filter scale with ONE frequency map as a single column pass (k_template_cols): what the
+// column kernel needs beside the two transforms' own arguments
+#define NF_TF_MAXE 16          // elements of a tile a thread carries through the pointwise step (n * tile width / threads)
+#define NF_TF_MAXBATCH 8
+struct TemplateFuse {
+    const void* cov;           // [H][W] smoothed noise power of the one map (all scales of the batch)
+    double w0;                 // its frequency weight
+    float* filt[NF_TF_MAXBATCH];   // per batch entry: the float32 filter plane [H][W], or NULL (not wanted)
+    double* sym;               // [batch][H][W] symmetrised filter, half-stored (written)
+};
+
 template <typename T>
 struct Plan2D {
     int H, W;
@@ -94,7 +105,16 @@ struct Plan2D {
     int init(int H, int W);
     void destroy();
     int forward(const void* in, int inType, void* out, int batch, const double* apodY, const double* apodX,
-                int scaleDiv, double scale, hipStream_t stream, int half = 0);
+                int scaleDiv, double scale, hipStream_t stream, int half = 0, int rowsOnly = 0);
+    // can template_filter run for this plan (float32 plain-radix columns, a thread's share of a tile within NF_TF_MAXE)?
+    bool template_filter_ok(int batch) const;
+    // rowsOut: what forward(..., half = 1, rowsOnly = 1) left in the spectrum buffer.  Column transform, filter build
+    // (k_build_filter_sym, N = 1), symmetrised filter x planeScale x window, inverse column transform into `work`, then the inverse
+    // row pass into `out` - the values of forward() + build_filter_sym() + inverse_half() bit for bit; the spectrum itself is
+    // never stored.
+    int template_filter(const void* rowsOut, int batch, const TemplateFuse& tf, int covType, const double* planeScale, const double* winY,
+                        const double* winX, void* work, void* out, int outType, int rowLo, int rowHi, int scaleDiv, double scale,
+                        hipStream_t stream);
     int inverse(const void* in, void* work, void* out, int outType, int batch, int scaleDiv, double scale,
                 hipStream_t stream, const float* filt = nullptr, int nSum = 1, long long filtBatchStride = 0,
                 const double* winY = nullptr, const double* winX = nullptr);

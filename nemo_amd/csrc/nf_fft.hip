@@ -1113,6 +1113,198 @@ __global__ void __launch_bounds__((MODE == 0 && SPEC == 3 && sizeof(T) == 8) ? 5
 
 
 // ------------------------------------------------------------------------------------------------------
+// The template path of a matched-filter scale with one frequency map, as ONE pass over the column tiles (float32 templates):
+//   forward column transform of the template's row spectra (k_fft_cols, SPEC 0)      - result stays in LDS
+//   filter build for the tile's modes and their mirror modes (k_build_filter_sym, N = 1) - filter cube (optional) and
+//                                                                                       symmetrised filter go to HBM
+//   spectrum x symmetrised filter x planeScale x pixel window, conjugated (the load of k_fft_cols, SPEC 3)
+//   inverse column transform, stored for the rows that are read (k_fft_cols, SPEC 3)
+// Per element the arithmetic of those three kernels in their order, so the results are theirs bit for bit; what is saved is the
+// traffic between them: the template's spectrum (written once, read twice) and the symmetrised filter's read-back.
+// After the forward DIT stages the tile lies in natural order; the inverse DIT stages want element k at the digit-reversed
+// position rev[k]: every thread carries its elements' products over a barrier in registers (NF_TF_MAXE).
+template <typename CT>
+__device__ __forceinline__ float tf_filter_value(CT c, double rhs) {
+    if (c == (CT)0) return 0.0f;
+    const CT inv = (CT)1 / c;
+    return (float)((double)inv * rhs);
+}
+
+template <typename CT, int MODE>
+__global__ void __launch_bounds__(NF_FFT_MAXTHREADS) k_template_cols(nf::LineArgs<float> af, nf::LineArgs<float> ai, nf::TemplateFuse tf) {
+    extern __shared__ __align__(16) unsigned char nf_smem[];
+    cpx<float>* buf = (cpx<float>*)nf_smem;
+    const nf::LinePlan<float>& p = af.plan;
+    const int per = (af.nTiles + 7) >> 3;
+    const int tile = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (tile >= af.nTiles) return;
+    Geo G;
+    G.TL = af.linesPerWG;
+    G.line0 = tile * G.TL;
+    const int nvalid = min(G.TL, af.nLines - G.line0);
+    G.tl = threadIdx.x & (G.TL - 1);
+    G.tb = threadIdx.x / G.TL;
+    G.TB = blockDim.x / G.TL;
+    G.nl = G.tl < nvalid ? G.tl + 1 : 0;
+    G.inP = (const char*)af.in + (size_t)blockIdx.y * (size_t)af.inBatchStride * sizeof(cpx<float>);
+    G.outP = (char*)ai.out + (size_t)blockIdx.y * (size_t)ai.outBatchStride * sizeof(cpx<float>);
+    const bool packed0 = af.packNyq && tile == 0;
+    bool pairF = false, pairI = false;
+    if constexpr (MODE == 0) {
+        const bool whole = G.TL >= 2 && nvalid == G.TL && !packed0 && p.nst >= 2 && (blockDim.x % (G.TL >> 1)) == 0;
+        pairF = af.colPair && whole && ((size_t)G.inP & 15) == 0;
+        pairI = ai.colPair && whole && ((size_t)G.outP & 15) == 0;
+    }
+    // ---- forward transform: every stage leaves its result in LDS ----
+    for (int s = 0; s < p.nst; ++s) {
+        bool done = false;
+        if constexpr (MODE == 0) {
+            if (pairF && s == 0) done = fft_stage_colpair_dispatch<0>(buf, af, s, true, G);
+        }
+        if (!done) fft_stage_dispatch<float, true, MODE, 0>(buf, af, s, false, s == 0, false, G);
+    }
+    // ---- the tile's modes: filter, symmetrised filter, product ----
+    const unsigned n = (unsigned)p.n, TL = (unsigned)G.TL, W = (unsigned)af.realW, colN = W / 2;
+    const float r = (float)af.scale, ri = r * (float)af.conjOutSign, h = 0.5f;
+    const float cj = (float)ai.conjInSign;
+    const CT* __restrict__ cov = (const CT*)tf.cov;
+    const size_t npix = (size_t)af.realH * (size_t)W;
+    double* __restrict__ sym = tf.sym + (size_t)blockIdx.y * npix;
+    float* __restrict__ filt = tf.filt[blockIdx.y & (NF_TF_MAXBATCH - 1)];
+    const double ps = ai.usePlaneScale ? ai.planeScale[blockIdx.y & 7] : 1.0;
+    const bool win = ai.winElem != nullptr;
+    cpx<float> hold[NF_TF_MAXE];
+    // (a thread's elements in groups of NF_TF_GRP: the noise power at the group's modes and mirror modes is fetched in one
+    //  batch of independent loads - one memory round trip per group instead of one per element)
+#define NF_TF_GRP 8
+#pragma unroll
+    for (int j0 = 0; j0 < NF_TF_MAXE; j0 += NF_TF_GRP) {
+        CT c1[NF_TF_GRP], c2[NF_TF_GRP];
+#pragma unroll
+        for (int u = 0; u < NF_TF_GRP; ++u) {
+            const unsigned i = threadIdx.x + (unsigned)(j0 + u) * blockDim.x;
+            const unsigned line = i & (TL - 1), e = i / TL;
+            const bool live = i < n * TL && (int)line < nvalid && !(packed0 && line == 0);
+            const unsigned em = e == 0u ? 0u : n - e;
+            const unsigned col = (unsigned)G.line0 + line;
+            const unsigned xm = col == 0u ? 0u : W - col;
+            c1[u] = live ? cov[(size_t)e * W + col] : (CT)0;
+            c2[u] = live ? cov[(size_t)em * W + xm] : (CT)0;
+        }
+#pragma unroll
+        for (int u = 0; u < NF_TF_GRP; ++u) {
+            const int j = j0 + u;
+            const unsigned i = threadIdx.x + (unsigned)j * blockDim.x;
+            hold[j].x = 0.0f;
+            hold[j].y = 0.0f;
+            if (i >= n * TL) continue;
+            const unsigned line = i & (TL - 1), e = i / TL;
+            if ((int)line >= nvalid) continue;
+            const unsigned em = e == 0u ? 0u : n - e;
+            const cpx<float> z = buf[(unsigned)swz((int)e) * TL + line];
+            if (packed0 && line == 0) {
+                // columns 0 and W/2 as they leave the forward pass (k_fft_cols' unpacking), each with its mirror row in its own column
+                const cpx<float> zm = buf[(unsigned)swz((int)em) * TL];
+                cpx<float> g0, gN, g0m, gNm;
+                g0.x = h * (z.x + zm.x) * r;
+                g0.y = h * (z.y - zm.y) * ri;
+                gN.x = h * (z.y + zm.y) * r;
+                gN.y = -h * (z.x - zm.x) * ri;
+                g0m.x = h * (zm.x + z.x) * r;
+                g0m.y = h * (zm.y - z.y) * ri;
+                gNm.x = h * (zm.y + z.y) * r;
+                gNm.y = -h * (zm.x - z.x) * ri;
+                const size_t p0 = (size_t)e * W, p0m = (size_t)em * W, pN = p0 + colN, pNm = p0m + colN;
+                const float a1 = tf_filter_value<CT>(cov[p0], tf.w0 * (double)hypotf(g0.x, g0.y));
+                const float a2 = p0m == p0 ? a1 : tf_filter_value<CT>(cov[p0m], tf.w0 * (double)hypotf(g0m.x, g0m.y));
+                const float b1 = tf_filter_value<CT>(cov[pN], tf.w0 * (double)hypotf(gN.x, gN.y));
+                const float b2 = pNm == pN ? b1 : tf_filter_value<CT>(cov[pNm], tf.w0 * (double)hypotf(gNm.x, gNm.y));
+                const double s0 = 0.5 * ((double)a1 + (double)a2), sN = 0.5 * ((double)b1 + (double)b2);
+                if (filt != nullptr) {
+                    filt[p0] = a1;
+                    filt[pN] = b1;
+                }
+                sym[p0] = s0;
+                sym[pN] = sN;
+                // the inverse pass's load of the packed column (fused_ops_herm on each column, then z0 + i zN)
+                double f0 = s0, fN = sN;
+                if (ai.usePlaneScale) {
+                    f0 *= ps;
+                    fN *= ps;
+                }
+                double re0 = 0.0, im0 = 0.0, reN = 0.0, imN = 0.0;
+                re0 += (double)g0.x * f0;
+                im0 += (double)(g0.y * cj) * f0;
+                reN += (double)gN.x * fN;
+                imN += (double)(gN.y * cj) * fN;
+                if (win) {
+                    const double w0_ = ai.winElem[e] * ai.winLine[0], wN_ = ai.winElem[e] * ai.winLine[colN];
+                    re0 *= w0_;
+                    im0 *= w0_;
+                    reN *= wN_;
+                    imN *= wN_;
+                }
+                const float x0 = (float)re0, y0 = (float)im0, xN = (float)reN, yN = (float)imN;
+                hold[j].x = x0 - yN;
+                hold[j].y = y0 + xN;
+            } else {
+                cpx<float> v = z;
+                v.x *= r;
+                v.y *= ri;                                        // the spectrum value as the forward pass would store it
+                const unsigned col = (unsigned)G.line0 + line;
+                const unsigned xm = col == 0u ? 0u : W - col;
+                const bool selfColumn = xm == col;
+                const size_t pp = (size_t)e * W + col, pm = (size_t)em * W + xm;
+                const float o1 = tf_filter_value<CT>(c1[u], tf.w0 * (double)hypotf(v.x, v.y));
+                float o2 = o1;
+                if (pm != pp) {
+                    double rhs2 = tf.w0 * (double)hypotf(v.x, v.y);
+                    if (selfColumn) {                             // the mirror mode is stored in this column: its own spectrum value
+                        cpx<float> vm = buf[(unsigned)swz((int)em) * TL + line];
+                        vm.x *= r;
+                        vm.y *= ri;
+                        rhs2 = tf.w0 * (double)hypotf(vm.x, vm.y);
+                    }
+                    o2 = tf_filter_value<CT>(c2[u], rhs2);
+                }
+                const double sv = 0.5 * ((double)o1 + (double)o2);
+                if (filt != nullptr) {
+                    filt[pp] = o1;
+                    if (!selfColumn) filt[pm] = o2;
+                }
+                sym[pp] = sv;
+                // the inverse pass's load (SPEC 3): one real factor, formed in its order
+                double f = sv;
+                if (ai.usePlaneScale) f *= ps;
+                if (win) f *= ai.winElem[e] * ai.winLine[col];
+                hold[j].x = (float)((double)v.x * f);
+                hold[j].y = (float)((double)(v.y * cj) * f);
+            }
+        }
+    }
+#undef NF_TF_GRP
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NF_TF_MAXE; ++j) {
+        const unsigned i = threadIdx.x + (unsigned)j * blockDim.x;
+        if (i >= n * TL) continue;
+        const unsigned line = i & (TL - 1), e = i / TL;
+        if ((int)line >= nvalid) continue;
+        buf[(unsigned)swz((int)p.rev[e]) * TL + line] = hold[j];
+    }
+    __syncthreads();
+    // ---- inverse transform from LDS; the last stage stores the rows that are wanted ----
+    for (int s = 0; s < p.nst; ++s) {
+        const bool dstG = s == p.nst - 1;
+        bool done = false;
+        if constexpr (MODE == 0) {
+            if (pairI && dstG) done = fft_stage_colpair_dispatch<3>(buf, ai, s, false, G);
+        }
+        if (!done) fft_stage_dispatch<float, true, MODE, 3>(buf, ai, s, false, false, dstG, G);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
 // Circular filtering of REAL lines by a real, even transfer function: y = IFFT(FFT(x) * w), one kernel, one pass over the map.
 // enmap.apply_window (nemo/filters.py:98-101, nemo/maps.py:1849) multiplies the 2-D spectrum by wy[ky] * wx[kx]: the two 1-D
 // operators along x and along y commute, each is this kernel once - the map is read and written twice instead of four times,
@@ -1723,7 +1915,7 @@ static LineArgs<T> col_args(const Plan2D<T>& P, const void* in, void* out) {
 // result divided by `scale` if scaleDiv (enmap.fft: sqrt(H*W)).
 template <typename T>
 int Plan2D<T>::forward(const void* in, int inType, void* out, int batch, const double* apodY, const double* apodX,
-                       int scaleDiv, double scale, hipStream_t stream, int half) {
+                       int scaleDiv, double scale, hipStream_t stream, int half, int rowsOnly) {
     LineArgs<T> a = row_args<T>(*this, in, out, inType, 0);
     a.apodLine = apodY;
     a.apodElem = apodX;
@@ -1748,7 +1940,7 @@ int Plan2D<T>::forward(const void* in, int inType, void* out, int batch, const d
         c.nTiles = nf_div_up(c.nLines, colsPerWG);
     }
     int rc = launch_lines<T>(a, false, batch, threadsRow, stream);
-    if (rc) return rc;
+    if (rc || rowsOnly) return rc;
     return launch_lines<T>(c, true, batch, threadsCol, stream);
 }
 
@@ -1847,6 +2039,123 @@ int Plan2D<T>::inverse_half(const void* in, void* work, void* out, int outType, 
     int rc = launch_lines<T>(c, true, batch, threadsCol, stream);
     if (rc) return rc;
     return launch_lines<T>(a, false, batch, threadsRow, stream);
+}
+
+template <typename T>
+bool Plan2D<T>::template_filter_ok(int batch) const {
+    static const int on = env_int("NF_TEMPLATE_FUSED", 1);
+    if (!on || sizeof(T) != 4 || col.bluestein || row.bluestein || batch < 1 || batch > NF_TF_MAXBATCH) return false;
+    LineArgs<T> c;
+    memset(&c, 0, sizeof(c));
+    c.linesPerWG = colsPerWG;
+    c.nLines = packOk() ? W / 2 : W / 2 + 1;
+    c.nTiles = nf_div_up(c.nLines, colsPerWG);
+    fit_col_tiles<T>(c, batch);
+    const long long share = ((long long)col.n * c.linesPerWG + threadsCol - 1) / threadsCol;
+    return share <= NF_TF_MAXE && threadsCol <= NF_FFT_MAXTHREADS && (threadsCol % c.linesPerWG) == 0;
+}
+
+template <typename T>
+int Plan2D<T>::template_filter(const void* rowsOut, int batch, const TemplateFuse& tf, int covType, const double* planeScale,
+                               const double* winY, const double* winX, void* work, void* out, int outType, int rowLo, int rowHi,
+                               int scaleDiv, double scale, hipStream_t stream) {
+    if constexpr (sizeof(T) != 4) {
+        nf_set_error("template_filter: float32 templates only");
+        return NF_ERR_ARG;
+    } else {
+        if (!template_filter_ok(batch) || outType == 0 || (planeScale != nullptr && batch > 8)) {
+            nf_set_error("template_filter: not available for this plan");
+            return NF_ERR_ARG;
+        }
+        // the forward column pass as forward(half = 1) sets it up
+        LineArgs<float> cf = col_args<float>(*this, rowsOut, const_cast<void*>(rowsOut));
+        if (scaleDiv) cf.scale = 1.0 / scale;
+        cf.nLines = W / 2 + 1;
+        if (packOk()) {
+            cf.packNyq = 1;
+            cf.nLines = W / 2;
+        }
+        cf.nTiles = nf_div_up(cf.nLines, colsPerWG);
+        // the inverse column pass and the row pass as inverse_half(batch entries with one plane each) sets them up
+        LineArgs<float> ci = col_args<float>(*this, rowsOut, work);
+        ci.conjInSign = -1.0;
+        ci.mulSym = tf.sym;
+        ci.mulBatchStride = (long long)H * W;
+        ci.nSum = 1;
+        ci.sumStride = (long long)H * W;
+        ci.winLine = winX;
+        ci.winElem = winY;
+        ci.herm = 1;
+        ci.halfIn = 1;
+        ci.fused = 1;
+        if (planeScale != nullptr) {
+            ci.usePlaneScale = 1;
+            for (int i = 0; i < batch; ++i) ci.planeScale[i] = planeScale[i];
+        }
+        ci.nLines = cf.nLines;
+        ci.nTiles = cf.nTiles;
+        ci.packNyq = cf.packNyq;
+        LineArgs<float> a = row_args<float>(*this, work, out, 0, outType);
+        a.pairMode = 2;
+        a.nLines = (H + 1) / 2;
+        a.conjOutSign = 1.0;
+        if (rowHi > rowLo) {
+            const int lo = (rowLo < 0 ? 0 : rowLo) & ~1, hi = rowHi >= H ? H : ((rowHi + 1) & ~1);
+            if (lo < hi && (lo > 0 || hi < H)) {
+                ci.storeLo = lo;
+                ci.storeHi = hi;
+                a.lineBase = lo / 2;
+                a.nLines = (hi + 1) / 2;
+            }
+        }
+        fit_col_tiles<float>(cf, batch);
+        ci.linesPerWG = cf.linesPerWG;
+        ci.nTiles = cf.nTiles;
+        const size_t lds = (size_t)cf.plan.mPad * cf.linesPerWG * sizeof(cpx<float>);
+        if (lds > (size_t)kMaxLds || (double)(W / 2 + 1) * cf.plan.n >= 2147483648.0) {
+            nf_set_error("template_filter: column tile does not fit");
+            return NF_ERR_SIZE;
+        }
+        static const int pairOn = env_int("NF_FFT_COL_PAIR", 1);
+        const bool pairBase = pairOn && lds > 80 * 1024 && (cf.linesPerWG & 1) == 0 && (W & 1) == 0 && (((long long)H * W) & 1) == 0;
+        cf.colPair = pairBase ? 1 : 0;
+        ci.colPair = pairBase ? 1 : 0;
+        int mode = 0;
+        for (int s = 0; s < cf.plan.nst; ++s)
+            if (cf.plan.st[s].R > 8) mode = 1;
+        static bool attrSet = false;
+        if (!attrSet) {
+#define NF_ATTR(K) NF_HIP(hipFuncSetAttribute((const void*)K, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds))
+            NF_ATTR((k_template_cols<double, 0>));
+            NF_ATTR((k_template_cols<double, 1>));
+            NF_ATTR((k_template_cols<float, 0>));
+            NF_ATTR((k_template_cols<float, 1>));
+#undef NF_ATTR
+            attrSet = true;
+        }
+        int nCubes = 0;
+        for (int b = 0; b < batch; ++b) nCubes += tf.filt[b] != nullptr;
+        const double covB = covType == NF_F32 ? 4.0 : 8.0;
+        {
+            // algorithmic bytes: the row spectra and the noise power in; the symmetrised filter, the wanted cubes and the stored rows out
+            ProfScope ps(PT_FFT_COLS_F32, stream,
+                         (double)H * W * (batch * (4.0 + covB + 4.0) + nCubes * 4.0) + (double)(ci.storeHi > 0 ? ci.storeHi - ci.storeLo : H) * (W / 2 + 1) * 8.0 * batch);
+            dim3 grid(((cf.nTiles + 7) / 8) * 8, batch);
+            if (covType == NF_F64) {
+                if (mode == 0)
+                    hipLaunchKernelGGL((k_template_cols<double, 0>), grid, dim3(threadsCol), lds, stream, cf, ci, tf);
+                else
+                    hipLaunchKernelGGL((k_template_cols<double, 1>), grid, dim3(threadsCol), lds, stream, cf, ci, tf);
+            } else {
+                if (mode == 0)
+                    hipLaunchKernelGGL((k_template_cols<float, 0>), grid, dim3(threadsCol), lds, stream, cf, ci, tf);
+                else
+                    hipLaunchKernelGGL((k_template_cols<float, 1>), grid, dim3(threadsCol), lds, stream, cf, ci, tf);
+            }
+            NF_CHECK_LAUNCH("k_template_cols");
+        }
+        return launch_lines<float>(a, false, batch, threadsRow, stream);
+    }
 }
 
 // y = IFFT(FFT(x) * w) along one axis of a real map (k_line_filter): axis 0 = along the rows (x), 1 = along the columns (y).

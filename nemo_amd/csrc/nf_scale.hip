@@ -179,7 +179,7 @@ int run_group(nf_plan* plan, const nf_mf_tile& t, const nf_mf_scale* sc, int nb,
         }
     }
     char* pre = undo ? ws + L.pre : (char*)sc[0].data_d;  // filtered maps [nb] before the window undo
-    const double unit = std::sqrt((double)H * (double)W);  // (the transforms here are not unitary: never applied)
+    const double unit = std::sqrt((double)H * (double)W);  // enmap.fft's divisor (the forward transforms are unitary, the inverse ones are not)
     NF_TRY(nf_plan_ensure_prec(plan, NF_F32));
     NF_TRY(nf_plan_ensure_prec(plan, t.prec));
     NF_TRY(nf_plan_ensure_prec(plan, outPrec));
@@ -210,9 +210,17 @@ int run_group(nf_plan* plan, const nf_mf_tile& t, const nf_mf_scale* sc, int nb,
         nf::ProfScope ps(nf::PT_PAINT, st, (double)npix * 4.0 * P.n);
         NF_TRY(nf::paint_radial_planes(T + (size_t)p0 * npix, H, W, t.A_d, t.B_d, t.C_d, P, st));
     }
-    NF_TRY(nf_fft2_forward_half(plan, NF_F32, T, NF_IN_REAL32, F, nPlanes, nullptr, nullptr, 1, S));
+    // One frequency map: the column transform of the template's spectrum, the filter build and the filtered template's column
+    // transform walk the same column tiles - one kernel does all three and the spectrum never reaches HBM (k_template_cols;
+    // per element the arithmetic of the three, bit for bit).  Otherwise: transform, then build, then transform back.
+    const bool fuse = N == 1 && plan->pf.template_filter_ok(nb);
+    if (fuse) {
+        NF_TRY(plan->pf.forward(T, NF_IN_REAL32, F, nPlanes, nullptr, nullptr, 1, unit, st, 1, 1));      // row pass only
+    } else {
+        NF_TRY(nf_fft2_forward_half(plan, NF_F32, T, NF_IN_REAL32, F, nPlanes, nullptr, nullptr, 1, S));
+    }
     // the filters (:621-627) and their symmetrised forms for the half-spectrum inverse
-    {
+    if (!fuse) {
         nf::WeightVec wv;
         memset(&wv, 0, sizeof(wv));
         for (int i = 0; i < N; ++i) wv.v[i] = t.w[i];
@@ -234,12 +242,26 @@ int run_group(nf_plan* plan, const nf_mf_tile& t, const nf_mf_scale* sc, int nb,
         normOut.p[b] = sc[b].signalNorm_d;
         relOut.p[b] = sc[b].relWeights_d;
     }
+    nf::TemplateFuse tf;
+    memset(&tf, 0, sizeof(tf));
+    if (fuse) {
+        tf.cov = t.noiseCov_d;
+        tf.w0 = t.w[0];
+        tf.sym = filtSym;
+        for (int b = 0; b < nb; ++b) tf.filt[b] = sc[b].filt_d;
+    }
     // normalisation
     if (yc) {
         // the y0-scaled templates (:639-646) are the unit templates times templateScale: the factor rides on the load.  Up to 8
         // planes (the room in the factor table) per transform.
         const int per = N == 1 ? 8 : 8 / N;               // scales per transform
-        for (int b0 = 0; b0 < nb; b0 += per) {
+        if (fuse) {
+            double planeScale[8];
+            for (int j = 0; j < nb; ++j) planeScale[j] = sc[j].templateScale[0];
+            NF_TRY(plan->pf.template_filter(F, nb, tf, t.covType, planeScale, t.winY_d, t.winX_d, work, sig, NF_IN_REAL32, t.centreRowLo,
+                                            t.centreRowHi, 1, unit, st));
+        }
+        for (int b0 = 0; b0 < nb && !fuse; b0 += per) {
             const int cnt = nb - b0 < per ? nb - b0 : per;
             double planeScale[8];
             for (int j = 0; j < cnt; ++j)
@@ -287,8 +309,11 @@ int run_group(nf_plan* plan, const nf_mf_tile& t, const nf_mf_scale* sc, int nb,
             NF_CHECK_LAUNCH("k_signal_norm_group");
         }
     } else {
-        NF_TRY(plan->pf.inverse_half(F, work, sig, NF_IN_REAL32, nb, 0, unit, st, filtSym, N, (long long)N * npix, nullptr, nullptr, nullptr,
-                                     nullptr, nullptr, nullptr, 0, 0, (long long)N * npix));
+        if (fuse)
+            NF_TRY(plan->pf.template_filter(F, nb, tf, t.covType, nullptr, nullptr, nullptr, work, sig, NF_IN_REAL32, 0, 0, 1, unit, st));
+        else
+            NF_TRY(plan->pf.inverse_half(F, work, sig, NF_IN_REAL32, nb, 0, unit, st, filtSym, N, (long long)N * npix, nullptr, nullptr,
+                                         nullptr, nullptr, nullptr, nullptr, 0, 0, (long long)N * npix));
         {
             nf::ProfScope ps(nf::PT_MAP_MAX, st, (double)npix * 4.0 * nb);
             NF_TRY(nf::map_max(NF_F32, sig, npix, mapMax, st, nb, npix));

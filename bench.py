@@ -213,10 +213,10 @@ def cpu_baseline(procs, size):
 
 def pmc_traffic(tag, shape, numScales, dtype):
     """HBM bytes per launch (GB) of the kernel behind `tag` from the committed rocprofv3 PMC passes over this same command
-    (profiles/r02_pmc_traffic.json: FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE).
+    (profiles/r03_pmc_traffic.json: FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE).
     Counters cannot be read from inside a run, so this is the profiled figure for the headline workload only - None for
     any other size / scale count / dtype, or when the file is absent."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
     if tuple(shape) != (4096, 4096) or numScales != 15 or dtype != "f64" or not os.path.exists(path):
         return None
     with open(path) as f:
@@ -425,7 +425,7 @@ def main():
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": d['GBps'], "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": round(d['GBps'] / HBM_PEAK_GBS, 4),
                                "traffic": pmc_traffic(dom, shape, S, args.dtype),
-                               "traffic_unit": "GB per launch (rocprofv3 PMC, profiles/r02_pmc_traffic.json)",
+                               "traffic_unit": "GB per launch (rocprofv3 PMC, profiles/r03_pmc_traffic.json)",
                                "avg_us": d['avg_us'], "launches_timed": d['calls'], "alg_GB_per_launch": d['alg_GB_per_call'],
                                "share_of_device_time": round(kernels[dom]['ms_total'] / devMs, 3),
                                "lanes": lanes,

@@ -6,7 +6,7 @@ used as reported.  Counters report KiB."""
 import csv, glob, json, re, sys, collections
 
 TAGS = [('fft_cols_f64', ['k_fft_cols<double'], None), ('fft_rows_f64', ['k_fft_rows<double'], None),
-        ('fft_cols_f32', ['k_fft_cols<float'], None), ('fft_rows_f32', ['k_fft_rows<float'], None),
+        ('fft_cols_f32', ['k_fft_cols<float', 'k_template_cols'], None), ('fft_rows_f32', ['k_fft_rows<float'], None),
         # the pixel-window undo as two 1-D circular filters (nf_axis_filter): one kernel per axis
         ('axis_filter_cols', [r'k_line_filter<\w+, ?(true|1)'], None), ('axis_filter_rows', [r'k_line_filter<\w+, ?(false|0)'], None),
         # one nf_noise_map call = (breaks, first scale of a tile and lane only) + block_stats + window_rms0 + block_core + block_classes + windows + paint_blocks

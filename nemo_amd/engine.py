@@ -661,7 +661,7 @@ class TileEngine(object):
         check(self.lib.nf_noise_map(prec_of(filtered), ptr(filtered), ptr(medWeights), prec_of(medWeights), ptr(rms),
                                     self.H, self.W, ncy, ncx, ptr(yE), ptr(xE), overlap, nb, quant, est, ptr(work),
                                     work.numel() * 8, 1 if tablesValid else 0, stream_ptr()), "nf_noise_map")
-        self._lastNoiseWork = (work, ncy, ncx, nb)       # diagnostics (tools/noisedbg.py)
+        self._lastNoiseWork = (work, ncy, ncx, nb)       # diagnostics (tools/noisebench.py, the heavy-tail tests)
         return rms
 
     def edge_check(self, filtered, psMask, size):

@@ -6,8 +6,10 @@ Follows ``maps.MapDict.preprocess`` (nemo/maps.py:325-465), ``maps.makeDegreesDi
 Catalogues are lists of dicts here.  The WCS object is duck-typed (``wcs2pix``, ``pix2wcs``, ``getPixelSizeDeg``,
 ``getXPixelSizeDeg``).  Radial tables and haversine geometry are handed in by the caller (they are host-side numpy in
 the product too); the painter is ``painter.paint_radial`` - PARITY UNPINNED against pixell.pointsrcs.sim_objects, which
-is absent offline.  Pinned pieces: the median background (scipy itself, as in the reference), the distance map and the
-mask/fill statements (plain numpy, the reference's own statements in the same order).
+is absent offline.  Everything else is PINNED by the reference's own code: ``MapDict.preprocess``'s catalogue statements and
+``makeModelImage`` were run unmodified under the stub importer (tests/golden/make_golden_r3.py, painter and WCS served from
+outside) and this module is held to their outputs bit for bit (tests/golden/preprocess.npz, 12 + 6 cases;
+tests/test_cpu_reference_r3.py).
 """
 import numpy as np
 from scipy import ndimage

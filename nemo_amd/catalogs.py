@@ -662,15 +662,27 @@ def _drawTilePositions(ys, xs, wcs, numSourcesPerTile, avoidanceRadiusArcmin, re
                 pick = np.random.randint(0, n, size)
                 yield wcs.pix2wcs(xs[pick] + np.random.uniform(0, 1, size), ys[pick] + np.random.uniform(0, 1, size))
                 tried += size
+    # The reference tests one candidate at a time against the objects kept so far (:913-921): "kept unless
+    # not calcAngSepDeg(...).min() * 60 > radius".  Same decisions here, with the separations of 64 candidates at a time formed
+    # in one call each (candidate first, kept object second, as there): against the objects kept before the chunk, and among
+    # the chunk's own candidates.
     for ra, dec in batches():
         ra, dec = np.atleast_1d(ra), np.atleast_1d(dec)
-        for rai, deci in zip(ra.tolist(), dec.tolist()):
-            if len(tileRAs) > 0 and not calcAngSepDeg(rai, deci, np.array(tileRAs), np.array(tileDecs)).min() * 60 > avoidanceRadiusArcmin:
-                continue
-            tileRAs.append(rai)
-            tileDecs.append(deci)
-            if len(tileRAs) == numSourcesPerTile:
-                return tileRAs, tileDecs
+        for c0 in range(0, len(ra), 64):
+            cra, cdec = ra[c0:c0 + 64], dec[c0:c0 + 64]
+            blocked = np.zeros(len(cra), dtype=bool)
+            if len(tileRAs) > 0:
+                d1 = calcAngSepDeg(cra[:, None], cdec[:, None], np.array(tileRAs)[None, :], np.array(tileDecs)[None, :])
+                blocked = (~(d1 * 60 > avoidanceRadiusArcmin)).any(axis=1)
+            close = ~(calcAngSepDeg(cra[:, None], cdec[:, None], cra[None, :], cdec[None, :]) * 60 > avoidanceRadiusArcmin)
+            for i in range(len(cra)):
+                if blocked[i]:
+                    continue
+                tileRAs.append(float(cra[i]))
+                tileDecs.append(float(cdec[i]))
+                if len(tileRAs) == numSourcesPerTile:
+                    return tileRAs, tileDecs
+                blocked[i + 1:] |= close[i + 1:, i]
     return tileRAs, tileDecs
 
 

@@ -387,6 +387,40 @@ def modelWindow(shape, wcs, RADeg, decDeg, maxSizeDeg):
     return x0, x1, y0, y1
 
 
+def _modelGeometryMany(shape, wcs, RADeg, decDeg, maxSizeDeg):
+    """modelWindow and signals.paintGeometry(window=...) for many objects at once: (windows [n, 4] = x0, x1, y0, y1; the
+    objects' tables A[rows], B[rows], C[columns] one after the other; where each object's A and C start).  Every value is
+    what the per-object functions give (the same elementwise statements on concatenated arrays)."""
+    H, W = shape
+    n = len(RADeg)
+    cosDec = np.cos(np.radians(decDeg))
+    xa, ya = wcs.wcs2pix(RADeg + maxSizeDeg / cosDec, decDeg - maxSizeDeg)
+    xb, yb = wcs.wcs2pix(RADeg - maxSizeDeg / cosDec, decDeg + maxSizeDeg)
+    xa, ya, xb, yb = (np.rint(np.atleast_1d(v)).astype(np.int64) for v in (xa, ya, xb, yb))      # int(round()): half to even
+    x0, x1 = np.minimum(xa, xb), np.maximum(xa, xb)
+    y0, y1 = np.minimum(ya, yb), np.maximum(ya, yb)
+    x0, y0 = np.minimum(np.maximum(x0, 0), W), np.minimum(np.maximum(y0, 0), H)
+    x1, y1 = np.minimum(np.maximum(x1, x0), W), np.minimum(np.maximum(y1, y0), H)
+    nrow, ncol = y1 - y0, x1 - x0
+    size = 2 * nrow + ncol
+    offA = np.concatenate([[0], np.cumsum(size)[:-1]]) if n > 0 else np.zeros(0, dtype=np.int64)
+    offC = offA + 2 * nrow
+    geom = np.empty(int(size.sum()), dtype=np.float64)
+    dec0, ra0 = np.radians(decDeg), np.radians(RADeg)
+    # rows: element j of object k is row y0[k] + j
+    rowObj = np.repeat(np.arange(n), nrow)
+    rowIn = np.arange(len(rowObj)) - np.repeat(np.cumsum(nrow) - nrow, nrow)
+    dec = wcs.rowDecRad()[y0[rowObj] + rowIn]
+    geom[offA[rowObj] + rowIn] = np.sin((dec - dec0[rowObj]) / 2.0) ** 2
+    geom[offA[rowObj] + nrow[rowObj] + rowIn] = np.cos(dec) * np.cos(dec0)[rowObj]
+    colObj = np.repeat(np.arange(n), ncol)
+    colIn = np.arange(len(colObj)) - np.repeat(np.cumsum(ncol) - ncol, ncol)
+    ra = wcs.colRARad()[x0[colObj] + colIn]
+    dra = (ra - ra0[colObj] + np.pi) % (2 * np.pi) - np.pi
+    geom[offC[colObj] + colIn] = np.sin(dra / 2.0) ** 2
+    return np.stack([x0, x1, y0, y1], axis=1), geom, offA, offC
+
+
 def makeModelImage(shape, wcs, catalog, beamFileName, obsFreqGHz=None, GNFWParams='default', profile='A10', cosmoModel=None,
                    applyPixelWindow=True, override=None, validAreaSection=None, minSNR=-99, TCMBAlpha=0, reportTimingInfo=False,
                    maxSizeDegMultiplier=5, useInferredSZProperties=False, _geomCache=None):
@@ -412,19 +446,27 @@ def makeModelImage(shape, wcs, catalog, beamFileName, obsFreqGHz=None, GNFWParam
     beam = signals._asBeam(beamFileName)
     objects = _modelObjects(catalog, beam, obsFreqGHz, GNFWParams, profile, override, TCMBAlpha, maxSizeDegMultiplier, cosmoModel)
     perObjectFactors = override is None          # the override branch converts the summed map instead (:1786-1788)
-    objs, wins, geomParts, profTabs, profIndex, off = [], [], [], [], {}, 0
-    tileKey = (tuple(shape), wcs._crval1, wcs._crpix1, wcs._crpix2, wcs._cdelt1, wcs._cdelt2)
-    for RADeg, decDeg, table, maxSizeDeg, factors in objects:
-        gkey = (tileKey, float(RADeg), float(decDeg), float(maxSizeDeg))
-        held = _geomCache.get(gkey) if _geomCache is not None else None
-        if held is None:
-            win = modelWindow(shape, wcs, RADeg, decDeg, maxSizeDeg)
-            held = (win, signals.paintGeometry(shape, wcs, RADeg, decDeg, window=win))
-            if _geomCache is not None:
-                _geomCache[gkey] = held
-        (wx0, wx1, wy0, wy1), (A, B, C) = held
-        nrow, ncol = wy1 - wy0, wx1 - wx0
-        geomParts += [A, B, C]
+    # windows and haversine tables of ALL objects in a few numpy statements (modelWindow / signals.paintGeometry element for
+    # element); the same catalogue on the same tile - the frequency maps of a tile, pass after pass of a mask catalogue - is
+    # served from the cache
+    nObj = len(objects)
+    RAs = np.array([o[0] for o in objects], dtype=np.float64)
+    decs = np.array([o[1] for o in objects], dtype=np.float64)
+    sizes = np.array([o[3] for o in objects], dtype=np.float64)
+    gkey = ('many', tuple(shape), wcs._crval1, wcs._crpix1, wcs._crpix2, wcs._cdelt1, wcs._cdelt2, RAs.tobytes(), decs.tobytes(),
+            sizes.tobytes())
+    held = _geomCache.get(gkey) if _geomCache is not None else None
+    if held is None:
+        held = _modelGeometryMany(shape, wcs, RAs, decs, sizes)
+        if _geomCache is not None:
+            _geomCache[gkey] = held
+    winArr, geom, offA, offC = held
+    objs, profTabs, profIndex = [], [], {}
+    wins = np.zeros((nObj, 8), dtype=np.int64)
+    wins[:, 0:4] = winArr
+    wins[:, 4] = offA
+    wins[:, 5] = offC
+    for k, (RADeg, decDeg, table, maxSizeDeg, factors) in enumerate(objects):
         pid = profIndex.get(id(table.prof))
         if pid is None:
             pid = profIndex[id(table.prof)] = len(profTabs)
@@ -434,11 +476,10 @@ def makeModelImage(shape, wcs, catalog, beamFileName, obsFreqGHz=None, GNFWParam
         useF = 1.0 if (factors is not None and perObjectFactors) else 0.0
         f1, f2 = factors if factors is not None else (1.0, 1.0)
         objs.append([table.amp, table.sign, f1, f2, float(pid), useF, 0.0, 0.0])
-        wins.append([wx0, wx1, wy0, wy1, off, off + 2 * nrow, pid, 0])
-        off += 2 * nrow + ncol
+        wins[k, 6] = pid
     eng = engine.TileEngine.get(shape)
     ntab = profTabs[0].shape[1]
-    modelMap = eng.paint_catalog(objs, wins, np.concatenate(geomParts) if off > 0 else np.zeros(1), np.array(profTabs), ntab)
+    modelMap = eng.paint_catalog(objs, wins, geom if len(geom) > 0 else np.zeros(1), np.array(profTabs), ntab)
     if override is not None and obsFreqGHz is not None:
         # convertToDeltaT of the whole map (:1786-1788): float32 * float64 scalar -> a float64 map from here on (numpy >= 2)
         fx = float(signals.fSZ(obsFreqGHz, TCMBAlpha=TCMBAlpha, z=override['redshift']))

@@ -184,6 +184,22 @@ class MapFilter(object):
         if tileCache is not None and not isinstance(self, RealSpaceMatchedFilter):
             shared = tileCache.setdefault(('tile', tileName, self.params.get('mapToUse', None)), {})
         self._shared = shared
+        # the second and later filters of a tile (the scales of a bank) are the first one's state with another label and
+        # parameter set: everything below depends on the tile and the maps only
+        snap = shared.get(('initSnapshot', type(self))) if shared is not None else None
+        if snap is not None:
+            self.__dict__.update(snap)
+            self.label, self.params, self._tileCache = label, paramsDict, tileCache
+            self.diagnosticsDir, self.selFnDir, self.tileName = diagnosticsDir, selFnDir, tileName
+            if self.diagnosticsDir is not None:
+                self.filterFileName = self.diagnosticsDir + os.path.sep + self.tileName + os.path.sep + \
+                    "filter_%s#%s.fits" % (self.label, self.tileName)
+            else:
+                self.filterFileName = None
+            self._shared = shared
+            self.signalNorm = 1.0
+            self.fRelWeights = {}
+            return
         if shared is not None and 'maps' in shared:
             self.unfilteredMapsDictList = shared['maps']
         else:
@@ -269,6 +285,8 @@ class MapFilter(object):
                 shared['dev'] = (self._dData, self._dWeights, self._dSurveyMask, self._dPSMask)
         self._geom = None
         self._dFilt = None
+        if shared is not None:
+            shared[('initSnapshot', type(self))] = dict(self.__dict__)
 
     # -- geometry ---------------------------------------------------------------------------------------------
     def makeRadiansMap(self):

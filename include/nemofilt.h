@@ -340,6 +340,14 @@ int nf_object_stats_chunks(int vtype, const void* sn_d, int negate, const int* l
 int nf_label_and_stats(int vtype, const void* sn_d, double threshold, int negate, int* labels_d, int H, int W, int* work_d,
                        int* dirty_d, int maxObjects, double* stats_d, const unsigned long long* snChunkRange_d, void* stream);
 
+/* nf_label_and_stats for numMaps maps of one shape (the scales of a tile, nemo/pipelines.py:267-289) with every pass ONE launch
+ * for all of them (groups of 8 maps): sn_d, labels_d, work_d, stats_d - and dirty_d, snChunkRange_d, each NULL or an array whose
+ * entries may be NULL - are HOST arrays of numMaps device pointers, each as in nf_label_and_stats; no two maps may share a
+ * labels, work, dirty or record buffer.  Same labels and records per map as numMaps single calls. */
+int nf_label_and_stats_batch(int vtype, int numMaps, const void* const* sn_d, double threshold, int negate, int* const* labels_d,
+                             int H, int W, int* const* work_d, int* const* dirty_d, int maxObjects, double* const* stats_d,
+                             const unsigned long long* const* snChunkRange_d, void* stream);
+
 /* The segment moments behind measureShapes (photometry.findObjects, nemo/photometry.py:136-150): per label id 0..numObjects
  * a record of 10 doubles {xMin, yMin, xMax, yMax, S, Sx, Sy, Sxx, Syy, Sxy} with S = sum v, Sx = sum v*(x - xMin),
  * Sxx = sum v*(x - xMin)^2 ... over the segment's pixels (v as in nf_object_stats: exact integer sums of v * 2^40).

@@ -741,6 +741,23 @@ int nf_label_and_stats(int vtype, const void* sn, double threshold, int negate, 
     return nf::label_and_stats(vtype, sn, threshold, negate, labels, H, W, work, dirty, maxObjects, stats, snChunkRange, S(stream));
 }
 
+int nf_label_and_stats_batch(int vtype, int numMaps, const void* const* sn, double threshold, int negate, int* const* labels, int H,
+                             int W, int* const* work, int* const* dirty, int maxObjects, double* const* stats,
+                             const unsigned long long* const* snChunkRange, void* stream) {
+    if (!sn || !labels || !work || !stats || numMaps < 1 || H < 1 || W < 1 || maxObjects < 0 || (vtype != NF_F32 && vtype != NF_F64)) {
+        nf_set_error("nf_label_and_stats_batch: bad arguments");
+        return NF_ERR_ARG;
+    }
+    for (int m = 0; m < numMaps; ++m)
+        if (!sn[m] || !labels[m] || !work[m] || !stats[m]) {
+            nf_set_error("nf_label_and_stats_batch: a map, label, work or record pointer is NULL");
+            return NF_ERR_ARG;
+        }
+    nf::ProfScope ps(nf::PT_LABEL, S(stream), (double)numMaps * H * W * (vtype == NF_F32 ? 4.0 : 8.0));
+    return nf::label_and_stats_batch(vtype, numMaps, sn, threshold, negate, labels, H, W, work, dirty, maxObjects, stats, snChunkRange,
+                                     S(stream));
+}
+
 int nf_object_shapes(int vtype, const void* sn, int negate, const int* labels, int H, int W, int numObjects, double* shapes,
                      void* stream) {
     if (!sn || !labels || !shapes || H < 1 || W < 1 || numObjects < 0 || (vtype != NF_F32 && vtype != NF_F64)) {

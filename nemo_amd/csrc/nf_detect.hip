@@ -43,11 +43,28 @@ __device__ __forceinline__ bool is_fg(const VT* sn, long long p, VT thr, int neg
 // pass records that per chunk (chunkFG), and every later pass leaves such a chunk after reading one flag: the union-find
 // passes then cost what the foreground costs, and only the first pass (read the map, write parent) and the last (write
 // the labels) touch the whole map.
+// The maps of one launch (blockIdx.y = map): the scales of a tile are labelled together (nf_label_and_stats_batch), every pass
+// ONE launch for all of them.  work[m] = parent[n], blockCounts[nblocks + 1], chunkFG[nblocks].
+struct DetBatch {
+    const void* sn[NF_SB_MAX];
+    int* labels[NF_SB_MAX];
+    int* work[NF_SB_MAX];
+    int* dirty[NF_SB_MAX];                             // kept labels (k_relabel), or NULL
+    double* stats[NF_SB_MAX];                          // the record table (cleared by the first labelling pass when asked)
+    const unsigned long long* snRange[NF_SB_MAX];      // nf_finalize's S/N range per chunk, or NULL
+    const int* chunkFG[NF_SB_MAX];                     // the sums: foreground flags of the labelling call that made the labels, or NULL
+    const int* count[NF_SB_MAX];                       // the sums: where the number of labels found lies on the device, or NULL
+};
+
 template <typename VT>
-__global__ void __launch_bounds__(256) k_ccl_init(const VT* __restrict__ sn, VT thr, int negate, int* __restrict__ parent,
-                                                  long long n, int* __restrict__ chunkFG, const unsigned long long* __restrict__ snRange,
-                                                  unsigned long long* __restrict__ clear, long long clearWords) {
+__global__ void __launch_bounds__(256) k_ccl_init(DetBatch b, VT thr, int negate, long long n, long long clearWords) {
+    const int m = blockIdx.y, nblocks = gridDim.x;
+    const VT* __restrict__ sn = (const VT*)b.sn[m];
+    int* __restrict__ parent = b.work[m];
+    int* __restrict__ chunkFG = parent + n + nblocks + 1;
+    const unsigned long long* __restrict__ snRange = b.snRange[m];
     // (label_and_stats: the record table of the sums that follow is cleared here rather than by a fill of its own)
+    unsigned long long* __restrict__ clear = (unsigned long long*)b.stats[m];
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < clearWords; i += (long long)gridDim.x * 256) clear[i] = 0ULL;
     if (snRange != nullptr) {
         // the chunk's largest / smallest S/N is known (nf_finalize wrote it): a chunk that cannot hold foreground is not read
@@ -101,9 +118,11 @@ __device__ __forceinline__ void uf_union(int* parent, int a, int b) {
     }
 }
 
-__global__ void __launch_bounds__(256) k_ccl_merge(int* __restrict__ parent, int H, int W, const int* __restrict__ chunkFG) {
-    if (!chunkFG[blockIdx.x]) return;
+__global__ void __launch_bounds__(256) k_ccl_merge(DetBatch b, int H, int W) {
     const long long n = (long long)H * W, base = (long long)blockIdx.x * NF_SCAN_CHUNK;
+    int* __restrict__ parent = b.work[blockIdx.y];
+    const int* __restrict__ chunkFG = parent + n + gridDim.x + 1;
+    if (!chunkFG[blockIdx.x]) return;
     for (int j = 0; j < 4; ++j) {
         const long long p = base + j * 256 + threadIdx.x;
         if (p >= n || parent[p] < 0) continue;
@@ -115,9 +134,11 @@ __global__ void __launch_bounds__(256) k_ccl_merge(int* __restrict__ parent, int
 }
 
 // every foreground pixel points at its root; the roots of the chunk are counted on the way
-__global__ void __launch_bounds__(256) k_ccl_flatten_count(int* __restrict__ parent, long long n, const int* __restrict__ chunkFG,
-                                                           int* __restrict__ blockCounts) {
+__global__ void __launch_bounds__(256) k_ccl_flatten_count(DetBatch b, long long n) {
     __shared__ int red[4];
+    int* __restrict__ parent = b.work[blockIdx.y];
+    int* __restrict__ blockCounts = parent + n;
+    const int* __restrict__ chunkFG = blockCounts + gridDim.x + 1;
     if (!chunkFG[blockIdx.x]) {
         if (threadIdx.x == 0) blockCounts[blockIdx.x] = 0;
         return;
@@ -141,9 +162,13 @@ __global__ void __launch_bounds__(256) k_ccl_flatten_count(int* __restrict__ par
 // The roots of chunk b are numbered from 1 + (roots in the chunks before b), raster order.  Every chunk with foreground sums the
 // counts before it by itself (at most 64 KB of coalesced reads from the L2 - cheaper than a scan kernel between two launches);
 // the last workgroup also leaves the total in blockCounts[nblocks].
-__global__ void __launch_bounds__(256) k_number_roots(const int* __restrict__ parent, long long n, int* __restrict__ blockCounts,
-                                                      int nblocks, const int* __restrict__ chunkFG, int* __restrict__ labels) {
+__global__ void __launch_bounds__(256) k_number_roots(DetBatch b, long long n) {
     __shared__ int waveTot[4], redTot[4];
+    const int nblocks = gridDim.x;
+    const int* __restrict__ parent = b.work[blockIdx.y];
+    int* __restrict__ blockCounts = b.work[blockIdx.y] + n;
+    const int* __restrict__ chunkFG = blockCounts + nblocks + 1;
+    int* __restrict__ labels = b.labels[blockIdx.y];
     const bool fg = chunkFG[blockIdx.x] != 0, last = (int)blockIdx.x == nblocks - 1;
     if (!fg && !last) return;
     int before = 0;
@@ -192,8 +217,11 @@ __global__ void __launch_bounds__(256) k_number_roots(const int* __restrict__ pa
 // `dirty` (optional): the caller keeps `labels` between calls - zero everywhere except in chunks whose dirty flag is set (they
 // held foreground in the previous call).  A chunk without foreground is then cleared only if it is dirty, and the flags are
 // brought up to date: the pass writes what the foreground touches, not the whole map.
-__global__ void __launch_bounds__(256) k_relabel(const int* __restrict__ parent, int* __restrict__ labels, long long n,
-                                                 const int* __restrict__ chunkFG, int* __restrict__ dirty) {
+__global__ void __launch_bounds__(256) k_relabel(DetBatch b, long long n) {
+    const int* __restrict__ parent = b.work[blockIdx.y];
+    const int* __restrict__ chunkFG = parent + n + gridDim.x + 1;
+    int* __restrict__ labels = b.labels[blockIdx.y];
+    int* __restrict__ dirty = b.dirty[blockIdx.y];
     const long long base = (long long)blockIdx.x * NF_SCAN_CHUNK;
     if (!chunkFG[blockIdx.x]) {
         if (dirty == nullptr || dirty[blockIdx.x]) {
@@ -223,31 +251,39 @@ long long label_chunk_flags_offset(int H, int W) {
     return n + nf_div_up(n, NF_SCAN_CHUNK) + 1;
 }
 
-int label_components(int vtype, const void* sn, double threshold, int negate, int* labels, int H, int W, int* work,
-                     int* numObjects, int* dirty, hipStream_t s, const unsigned long long* snRange, unsigned long long* clear,
-                     long long clearWords) {
+// the five labelling passes for the nb maps of `b` (one launch each); clearWords > 0: b.stats[m] is cleared on the way
+static int label_batch(int vtype, const DetBatch& b, int nb, double threshold, int negate, int H, int W, long long clearWords,
+                       hipStream_t s) {
     const long long n = (long long)H * W;
     if (n >= 2147483647LL) {
         nf_set_error("label_components: map too large for 32-bit pixel indices");
         return NF_ERR_SIZE;
     }
-    int* parent = work;
-    const int nblocks = nf_div_up(n, NF_SCAN_CHUNK);
-    int* blockCounts = work + n;                 // nblocks + 1
-    int* chunkFG = blockCounts + nblocks + 1;    // nblocks
-    dim3 g(nblocks), b(256);
+    dim3 g(nf_div_up(n, NF_SCAN_CHUNK), nb), t(256);
     if (vtype == NF_F64)
-        hipLaunchKernelGGL(k_ccl_init<double>, g, b, 0, s, (const double*)sn, threshold, negate, parent, n, chunkFG, snRange, clear, clearWords);
+        hipLaunchKernelGGL(k_ccl_init<double>, g, t, 0, s, b, threshold, negate, n, clearWords);
     else  // a Python-float threshold compared against a float32 map is cast to float32 by numpy
-        hipLaunchKernelGGL(k_ccl_init<float>, g, b, 0, s, (const float*)sn, (float)threshold, negate, parent, n, chunkFG, snRange, clear,
-                           clearWords);
-    hipLaunchKernelGGL(k_ccl_merge, g, b, 0, s, parent, H, W, chunkFG);
-    hipLaunchKernelGGL(k_ccl_flatten_count, g, b, 0, s, parent, n, chunkFG, blockCounts);
-    hipLaunchKernelGGL(k_number_roots, g, b, 0, s, parent, n, blockCounts, nblocks, chunkFG, labels);
-    hipLaunchKernelGGL(k_relabel, g, b, 0, s, parent, labels, n, chunkFG, dirty);
+        hipLaunchKernelGGL(k_ccl_init<float>, g, t, 0, s, b, (float)threshold, negate, n, clearWords);
+    hipLaunchKernelGGL(k_ccl_merge, g, t, 0, s, b, H, W);
+    hipLaunchKernelGGL(k_ccl_flatten_count, g, t, 0, s, b, n);
+    hipLaunchKernelGGL(k_number_roots, g, t, 0, s, b, n);
+    hipLaunchKernelGGL(k_relabel, g, t, 0, s, b, n);
     NF_CHECK_LAUNCH("label_components");
-    if (numObjects != nullptr) {        // (NULL: the count stays on the device, work[n + nblocks] - label_and_stats)
-        NF_HIP(hipMemcpyAsync(numObjects, blockCounts + nblocks, sizeof(int), hipMemcpyDeviceToHost, s));
+    return NF_OK;
+}
+
+int label_components(int vtype, const void* sn, double threshold, int negate, int* labels, int H, int W, int* work,
+                     int* numObjects, int* dirty, hipStream_t s) {
+    DetBatch b = {};
+    b.sn[0] = sn;
+    b.labels[0] = labels;
+    b.work[0] = work;
+    b.dirty[0] = dirty;
+    int rc = label_batch(vtype, b, 1, threshold, negate, H, W, 0, s);
+    if (rc != NF_OK) return rc;
+    if (numObjects != nullptr) {
+        const long long n = (long long)H * W;
+        NF_HIP(hipMemcpyAsync(numObjects, work + n + nf_div_up(n, NF_SCAN_CHUNK), sizeof(int), hipMemcpyDeviceToHost, s));
         NF_HIP(hipStreamSynchronize(s));
     }
     return NF_OK;
@@ -291,14 +327,18 @@ __device__ __forceinline__ unsigned long long ordered_key(double v) {
 
 // One workgroup per 1024-pixel chunk (chunkFG, from the labelling pass, when the caller has it: a chunk without foreground
 // costs one flag); a thread takes 4 consecutive pixels and flushes one entry per run of equal labels within a row.
+// The record table of a map: 6 doubles per label, then the 9 integer limbs, the maximum key and the argmax of every label.
 template <typename VT>
-__global__ void __launch_bounds__(256) k_object_sums(const VT* __restrict__ sn, int negate, const int* __restrict__ labels, int H, int W,
-                                                     double* __restrict__ stats, unsigned long long* __restrict__ limbs,
-                                                     unsigned long long* __restrict__ maxKey, const int* __restrict__ chunkFG,
-                                                     int maxId) {
+__global__ void __launch_bounds__(256) k_object_sums(DetBatch b, int negate, int H, int W, int maxId) {
+    const int* __restrict__ chunkFG = b.chunkFG[blockIdx.y];
     if (chunkFG != nullptr && !chunkFG[blockIdx.x]) return;
     const long long n = (long long)H * W, p0 = (long long)blockIdx.x * NF_SCAN_CHUNK + threadIdx.x * 4;
     if (p0 >= n) return;
+    const VT* __restrict__ sn = (const VT*)b.sn[blockIdx.y];
+    const int* __restrict__ labels = b.labels[blockIdx.y];
+    double* __restrict__ stats = b.stats[blockIdx.y];
+    unsigned long long* __restrict__ limbs = (unsigned long long*)(stats + ((size_t)maxId + 1) * NF_STAT_STRIDE);
+    unsigned long long* __restrict__ maxKey = limbs + ((size_t)maxId + 1) * NF_LIMB_WORDS;
     int y = (int)(p0 / W), x = (int)(p0 - (long long)y * W);
     int cur = 0;
     double cnt = 0, mx = 0;
@@ -338,10 +378,14 @@ __global__ void __launch_bounds__(256) k_object_sums(const VT* __restrict__ sn, 
 }
 
 template <typename VT>
-__global__ void __launch_bounds__(256) k_object_argmax(const VT* __restrict__ sn, int negate, const int* __restrict__ labels, long long n,
-                                                       const unsigned long long* __restrict__ maxKey, unsigned long long* __restrict__ argmax,
-                                                       const int* __restrict__ chunkFG, int maxId) {
+__global__ void __launch_bounds__(256) k_object_argmax(DetBatch b, int negate, long long n, int maxId) {
+    const int* __restrict__ chunkFG = b.chunkFG[blockIdx.y];
     if (chunkFG != nullptr && !chunkFG[blockIdx.x]) return;
+    const VT* __restrict__ sn = (const VT*)b.sn[blockIdx.y];
+    const int* __restrict__ labels = b.labels[blockIdx.y];
+    const unsigned long long* __restrict__ maxKey =
+        (const unsigned long long*)(b.stats[blockIdx.y] + ((size_t)maxId + 1) * NF_STAT_STRIDE) + ((size_t)maxId + 1) * NF_LIMB_WORDS;
+    unsigned long long* __restrict__ argmax = (unsigned long long*)maxKey + ((size_t)maxId + 1);
     const long long base = (long long)blockIdx.x * NF_SCAN_CHUNK;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -361,9 +405,12 @@ __device__ __forceinline__ double limbs_to_double(const unsigned long long* w) {
     return (hi * 18446744073709551616.0 + lo) * (1.0 / (double)(1ULL << NF_FIX_SHIFT));
 }
 
-__global__ void k_stats_finish(double* __restrict__ stats, const unsigned long long* __restrict__ limbs,
-                               const unsigned long long* __restrict__ maxKey, const unsigned long long* __restrict__ argmax,
-                               int numObjects, const int* __restrict__ count) {
+__global__ void k_stats_finish(DetBatch b, int numObjects) {
+    double* __restrict__ stats = b.stats[blockIdx.y];
+    const unsigned long long* __restrict__ limbs = (const unsigned long long*)(stats + ((size_t)numObjects + 1) * NF_STAT_STRIDE);
+    const unsigned long long* __restrict__ maxKey = limbs + ((size_t)numObjects + 1) * NF_LIMB_WORDS;
+    const unsigned long long* __restrict__ argmax = maxKey + ((size_t)numObjects + 1);
+    const int* __restrict__ count = b.count[blockIdx.y];
     for (int id = blockIdx.x * blockDim.x + threadIdx.x; id <= numObjects; id += gridDim.x * blockDim.x) {
         const unsigned long long* w = limbs + (long long)id * NF_LIMB_WORDS;
         double* r = stats + (long long)id * NF_STAT_STRIDE;
@@ -371,51 +418,78 @@ __global__ void k_stats_finish(double* __restrict__ stats, const unsigned long l
         r[2] = limbs_to_double(w + 3);
         r[3] = limbs_to_double(w + 6);
         unsigned long long k = maxKey[id];
-        unsigned long long b = (k & 0x8000000000000000ULL) ? (k & 0x7FFFFFFFFFFFFFFFULL) : ~k;
-        r[4] = __longlong_as_double((long long)b);
+        unsigned long long kb = (k & 0x8000000000000000ULL) ? (k & 0x7FFFFFFFFFFFFFFFULL) : ~k;
+        r[4] = __longlong_as_double((long long)kb);
         r[5] = (double)~argmax[id];
         // label_and_stats: the number of labels found travels in the (otherwise empty) background record
         if (id == 0 && count != nullptr) r[0] = (double)count[0];
     }
 }
 
-// `stats` must hold (numObjects+1) * 17 doubles: 6 per record, then scratch - the 9 integer limbs, the maximum key and the
-// argmax of every label
-int object_stats(int vtype, const void* sn, int negate, const int* labels, int H, int W, int numObjects, double* stats,
-                 const int* chunkFG, hipStream_t s, const int* count, bool cleared) {
+// the sums of the nb maps of `b` (one launch per pass); b.stats[m] holds (numObjects+1) * 17 doubles
+static int stats_batch(int vtype, const DetBatch& b, int nb, int negate, int H, int W, int numObjects, hipStream_t s) {
     const long long n = (long long)H * W;
-    const size_t nrec = (size_t)numObjects + 1;
-    unsigned long long* limbs = (unsigned long long*)(stats + nrec * NF_STAT_STRIDE);
-    unsigned long long* maxKey = limbs + nrec * NF_LIMB_WORDS;
-    unsigned long long* argmax = maxKey + nrec;
-    // records, limbs, maximum keys and (inverted) argmax all start at zero
-    if (!cleared) NF_HIP(hipMemsetAsync(stats, 0, nrec * (NF_STAT_STRIDE + NF_LIMB_WORDS + 2) * sizeof(double), s));
-    dim3 g(nf_div_up(n, NF_SCAN_CHUNK)), b(256);
+    dim3 g(nf_div_up(n, NF_SCAN_CHUNK), nb), t(256);
     if (vtype == NF_F64) {
-        hipLaunchKernelGGL(k_object_sums<double>, g, b, 0, s, (const double*)sn, negate, labels, H, W, stats, limbs, maxKey, chunkFG, numObjects);
-        hipLaunchKernelGGL(k_object_argmax<double>, g, b, 0, s, (const double*)sn, negate, labels, n, maxKey, argmax, chunkFG, numObjects);
+        hipLaunchKernelGGL(k_object_sums<double>, g, t, 0, s, b, negate, H, W, numObjects);
+        hipLaunchKernelGGL(k_object_argmax<double>, g, t, 0, s, b, negate, n, numObjects);
     } else {
-        hipLaunchKernelGGL(k_object_sums<float>, g, b, 0, s, (const float*)sn, negate, labels, H, W, stats, limbs, maxKey, chunkFG, numObjects);
-        hipLaunchKernelGGL(k_object_argmax<float>, g, b, 0, s, (const float*)sn, negate, labels, n, maxKey, argmax, chunkFG, numObjects);
+        hipLaunchKernelGGL(k_object_sums<float>, g, t, 0, s, b, negate, H, W, numObjects);
+        hipLaunchKernelGGL(k_object_argmax<float>, g, t, 0, s, b, negate, n, numObjects);
     }
-    hipLaunchKernelGGL(k_stats_finish, dim3(grid_for(nrec, 256)), dim3(256), 0, s, stats, limbs, maxKey, argmax, numObjects, count);
+    hipLaunchKernelGGL(k_stats_finish, dim3(grid_for((long long)numObjects + 1, 256), nb), dim3(256), 0, s, b, numObjects);
     NF_CHECK_LAUNCH("object_stats");
     return NF_OK;
 }
 
-// Labelling and the per-label sums without a host round trip in between: the record table has room for maxObjects labels,
-// the number found stays on the device and comes back in stats[0] (the background record's count, otherwise unused).
-int label_and_stats(int vtype, const void* sn, double threshold, int negate, int* labels, int H, int W, int* work, int* dirty,
-                    int maxObjects, double* stats, const unsigned long long* snRange, hipStream_t s) {
+// `stats` must hold (numObjects+1) * 17 doubles: 6 per record, then scratch - the 9 integer limbs, the maximum key and the
+// argmax of every label
+int object_stats(int vtype, const void* sn, int negate, const int* labels, int H, int W, int numObjects, double* stats,
+                 const int* chunkFG, hipStream_t s) {
+    const size_t nrec = (size_t)numObjects + 1;
+    // records, limbs, maximum keys and (inverted) argmax all start at zero
+    NF_HIP(hipMemsetAsync(stats, 0, nrec * (NF_STAT_STRIDE + NF_LIMB_WORDS + 2) * sizeof(double), s));
+    DetBatch b = {};
+    b.sn[0] = sn;
+    b.labels[0] = (int*)labels;
+    b.stats[0] = stats;
+    b.chunkFG[0] = chunkFG;
+    return stats_batch(vtype, b, 1, negate, H, W, numObjects, s);
+}
+
+// Labelling and the per-label sums without a host round trip in between, for up to NF_SB_MAX maps of one shape per launch:
+// every record table has room for maxObjects labels, the number found stays on the device and comes back in stats[m][0] (the
+// background record's count, otherwise unused).
+int label_and_stats_batch(int vtype, int nb, const void* const* sn, double threshold, int negate, int* const* labels, int H, int W,
+                          int* const* work, int* const* dirty, int maxObjects, double* const* stats,
+                          const unsigned long long* const* snRange, hipStream_t s) {
     const long long clearWords = ((long long)maxObjects + 1) * (NF_STAT_STRIDE + NF_LIMB_WORDS + 2);
-    int rc = label_components(vtype, sn, threshold, negate, labels, H, W, work, nullptr, dirty, s, snRange, (unsigned long long*)stats,
-                              clearWords);
-    if (rc != NF_OK) return rc;
     const long long n = (long long)H * W;
     const int nblocks = nf_div_up(n, NF_SCAN_CHUNK);
-    const int* count = work + n + nblocks;
-    const int* chunkFG = work + n + nblocks + 1;
-    return object_stats(vtype, sn, negate, labels, H, W, maxObjects, stats, chunkFG, s, count, true);
+    for (int m0 = 0; m0 < nb; m0 += NF_SB_MAX) {
+        const int c = nb - m0 < NF_SB_MAX ? nb - m0 : NF_SB_MAX;
+        DetBatch b = {};
+        for (int i = 0; i < c; ++i) {
+            b.sn[i] = sn[m0 + i];
+            b.labels[i] = labels[m0 + i];
+            b.work[i] = work[m0 + i];
+            b.dirty[i] = dirty != nullptr ? dirty[m0 + i] : nullptr;
+            b.stats[i] = stats[m0 + i];
+            b.snRange[i] = snRange != nullptr ? snRange[m0 + i] : nullptr;
+            b.count[i] = work[m0 + i] + n + nblocks;
+            b.chunkFG[i] = work[m0 + i] + n + nblocks + 1;
+        }
+        int rc = label_batch(vtype, b, c, threshold, negate, H, W, clearWords, s);
+        if (rc != NF_OK) return rc;
+        rc = stats_batch(vtype, b, c, negate, H, W, maxObjects, s);
+        if (rc != NF_OK) return rc;
+    }
+    return NF_OK;
+}
+
+int label_and_stats(int vtype, const void* sn, double threshold, int negate, int* labels, int H, int W, int* work, int* dirty,
+                    int maxObjects, double* stats, const unsigned long long* snRange, hipStream_t s) {
+    return label_and_stats_batch(vtype, 1, &sn, threshold, negate, &labels, H, W, &work, &dirty, maxObjects, &stats, &snRange, s);
 }
 
 // ---------------------------------------------------------------------------------------------------

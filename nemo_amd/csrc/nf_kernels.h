@@ -121,12 +121,14 @@ int median_stack(int rtype, const void* in, void* out, int N, long long n, hipSt
 // nf_detect.hip
 long long label_chunk_flags_offset(int H, int W);
 int label_components(int vtype, const void* sn, double threshold, int negate, int* labels, int H, int W, int* work,
-                     int* numObjects, int* dirty, hipStream_t s, const unsigned long long* snRange = nullptr,
-                     unsigned long long* clear = nullptr, long long clearWords = 0);
+                     int* numObjects, int* dirty, hipStream_t s);
 int object_stats(int vtype, const void* sn, int negate, const int* labels, int H, int W, int numObjects, double* stats,
-                 const int* chunkFG, hipStream_t s, const int* count = nullptr, bool cleared = false);
+                 const int* chunkFG, hipStream_t s);
 int label_and_stats(int vtype, const void* sn, double threshold, int negate, int* labels, int H, int W, int* work, int* dirty,
                     int maxObjects, double* stats, const unsigned long long* snRange, hipStream_t s);
+int label_and_stats_batch(int vtype, int nb, const void* const* sn, double threshold, int negate, int* const* labels, int H, int W,
+                          int* const* work, int* const* dirty, int maxObjects, double* const* stats,
+                          const unsigned long long* const* snRange, hipStream_t s);
 int object_shapes(int vtype, const void* sn, int negate, const int* labels, int H, int W, int numObjects, double* shapes, hipStream_t s);
 int resample_bilinear(const float* in, float* out, int N, int H, int W, int H2, int W2, const double* yIdx, const double* xIdx,
                       hipStream_t s);

@@ -925,6 +925,39 @@ class TileEngine(object):
                                           ptr(work), ptr(dirty), int(cap), ptr(stats), ptr(snChunks), stream_ptr()), "nf_label_and_stats")
         return labels, stats[:(cap + 1) * 6].reshape(cap + 1, 6)
 
+    def label_and_stats_batch(self, sns, threshold, negate=False, slot=None, cap=4096, snChunks=None):
+        """label_and_stats() of several maps of this shape with every pass one launch for all of them
+        (nf_label_and_stats_batch): (list of labels, records [len(sns), cap + 1, 6] - one device tensor, one transfer).  The
+        labels of map k live in the buffer kept for (thread, (slot, k))."""
+        t = self.t
+        M = len(sns)
+        nchunks = (self.npix + 1023) // 1024
+        wlen = (self.npix + 2 * nchunks + 16 + 3) // 4 * 4
+        work = t.empty((M, wlen), dtype=t.int32, device=self.dev)
+        stats = t.empty((M, (cap + 1) * 17), dtype=t.float64, device=self.dev)        # NF_OBJECT_STATS_DOUBLES
+        labels, dirty = [], []
+        for k in range(M):
+            if slot is None:
+                labels.append(t.empty((self.H, self.W), dtype=t.int32, device=self.dev))
+                dirty.append(None)
+            else:
+                key = (threading.get_ident(), (slot, k))
+                if key not in self._keptLabels:
+                    self._keptLabels[key] = (t.zeros((self.H, self.W), dtype=t.int32, device=self.dev),
+                                             t.zeros(nchunks, dtype=t.int32, device=self.dev))
+                lab, dr = self._keptLabels[key]
+                labels.append(lab)
+                dirty.append(dr)
+        arr = ctypes.c_void_p * M
+        pv = lambda xs: arr(*[ptr(x) for x in xs])          # noqa: E731
+        wp, sp = work.data_ptr(), stats.data_ptr()
+        check(self.lib.nf_label_and_stats_batch(prec_of(sns[0]), M, pv(sns), float(threshold), 1 if negate else 0, pv(labels), self.H,
+                                                self.W, arr(*[wp + 4 * wlen * k for k in range(M)]), pv(dirty), int(cap),
+                                                arr(*[sp + 8 * (cap + 1) * 17 * k for k in range(M)]),
+                                                pv(snChunks if snChunks is not None else [None] * M), stream_ptr()),
+              "nf_label_and_stats_batch")
+        return labels, stats[:, :(cap + 1) * 6].reshape(M, cap + 1, 6)
+
     def object_stats(self, sn, labels, numObjects, negate=False):
         t = self.t
         stats = t.empty((numObjects + 1) * 17, dtype=t.float64, device=self.dev)      # NF_OBJECT_STATS_DOUBLES

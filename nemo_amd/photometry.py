@@ -169,6 +169,7 @@ def findObjectsGroup(filteredMapDictList, _prefetch=None, **kwargs):
 
 
 _VECTOR_GROUP = os.environ.get('NEMO_AMD_VECTOR_DETECT', '1') != '0'      # 0: every map of a group through _findObjectsSteps
+_LABEL_BATCH = os.environ.get('NEMO_AMD_LABEL_BATCH', '1') != '0'         # 0: the maps of a group labelled one launch sequence each
 
 
 def _findObjectsVector(dicts, prefetch, threshold=3.0, minObjPix=3, rejectBorder=10, findCenterOfMass=True, flagRings=True,
@@ -195,20 +196,28 @@ def _findObjectsVector(dicts, prefetch, threshold=3.0, minObjPix=3, rejectBorder
     H, W = shape
     eng = engine.TileEngine.get(shape)
     cap = eng.statsCap
-    dSNs, recs = [], []
+    dSNs, chunks = [], []
     for d in dicts:
         dSN = d['SNMap']
         hint = d.get('_snChunks', None) if hasattr(d, 'get') else None
-        snChunks = hint[1] if (hint is not None and hint[0] is dSN and hint[0].data_ptr() == dSN.data_ptr()) else None
-        labels, rec = eng.label_and_stats(dSN, threshold, negate=invertMap, slot='objects', cap=cap, snChunks=snChunks)
+        chunks.append(hint[1] if (hint is not None and hint[0] is dSN and hint[0].data_ptr() == dSN.data_ptr()) else None)
         dSNs.append(dSN)
-        recs.append(rec)
+    if len({m.dtype for m in dSNs}) != 1:
+        return None
+    # labelling and per-label sums of all the maps: every pass one launch (:59)
+    if _LABEL_BATCH:
+        labels, recs = eng.label_and_stats_batch(dSNs, threshold, negate=invertMap, slot='objects', cap=cap, snChunks=chunks)
+    else:
+        recs = t.stack([eng.label_and_stats(m, threshold, negate=invertMap, slot='objects', cap=cap, snChunks=c)[1]
+                        for m, c in zip(dSNs, chunks)])
     tm = _mark('label+stats enqueue', tm)
     flagAny = first.get('_flagAny', None) if hasattr(first, 'get') else None
     if flagAny is not None and flagAny[0] is not flagMask:
         flagAny = None
-    parts = [r.reshape(-1) for r in recs] + ([flagAny[1].reshape(-1).to(t.float64)] if flagAny is not None else [])
-    flat = t.cat(parts).cpu().numpy()
+    flat = recs.reshape(-1)
+    if flagAny is not None:
+        flat = t.cat([flat, flagAny[1].reshape(-1).to(t.float64)])
+    flat = flat.cpu().numpy()
     tm = _mark('stats fetch', tm)
     recLen = (cap + 1) * 6
     S = flat[:M * recLen].reshape(M, cap + 1, 6)

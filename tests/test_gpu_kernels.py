@@ -625,3 +625,42 @@ def test_label_and_stats_with_sn_chunk_ranges(vdtype):
             stC = _np(eng.object_stats(sn, labC, nC, negate=negate))
             assert nC == n and np.array_equal(_np(labC), _np(labA))
             assert np.array_equal(stC[1:], a[1:n + 1])
+
+
+@pytest.mark.parametrize("vdtype", [np.float64, np.float32])
+def test_label_and_stats_batch_equals_map_by_map(vdtype):
+    """nf_label_and_stats_batch (every pass one launch for the maps of a group) leaves the labels and records of single calls:
+    11 maps (two launches' worth) of different foreground, one without any, kept label buffers used twice in a row (the second
+    time with other maps, so that stale chunks must be cleared), with and without the S/N range tables."""
+    shape = (211, 389)
+    eng = _eng(shape)
+    rng = np.random.default_rng(5)
+    ones = np.ones(shape, dtype=np.uint8)
+    rms = np.ones(shape, dtype=np.float32)
+
+    def make(k, seed):
+        r = np.random.default_rng(seed)
+        f = r.standard_normal(shape).astype(vdtype) * (0.2 if k == 3 else 1.0 + 0.1 * k)
+        if k != 3:
+            for _ in range(3 + k):
+                y, x = int(r.integers(5, shape[0] - 8)), int(r.integers(5, shape[1] - 8))
+                f[y:y + 1 + k % 3, x:x + 2 + k % 4] += 7.0 + k
+        d, sn, _, _ = eng.finalize(engine.to_dev(f.copy()), engine.to_dev(rms), engine.to_dev(ones), engine.to_dev(ones), None, True)
+        return sn, eng.lastSNChunks[1]
+    for rnd in range(2):
+        maps = [make(k, 100 * rnd + k) for k in range(11 if rnd == 0 else 5)]
+        sns = [m[0] for m in maps]
+        for negate, thr, useChunks in ((False, 4.0, True), (True, 3.0, False), (False, 2.5, False)):
+            chunks = [m[1] for m in maps] if useChunks else None
+            labs, recs = eng.label_and_stats_batch(sns, thr, negate=negate, slot='batchtest', cap=3000, snChunks=chunks)
+            R = _np(recs)
+            assert R.shape == (len(sns), 3001, 6)
+            for k, sn in enumerate(sns):
+                labA, recA = eng.label_and_stats(sn, thr, negate=negate, cap=3000)
+                a = _np(recA)
+                n = int(a[0, 0])
+                assert n == int(R[k, 0, 0]), (rnd, k)
+                if k == 3 and rnd == 0 and thr >= 3.0:
+                    assert n == 0
+                assert np.array_equal(a[1:n + 1], R[k, 1:n + 1])
+                assert np.array_equal(_np(labA), _np(labs[k]))

@@ -475,26 +475,43 @@ __global__ void __launch_bounds__(256) k_paint_radial_planes(float* __restrict__
         const double h = __dadd_rn(A[y], __dmul_rn(B[y], cx));
         const double th = theta_from_hav(h);
         const float lth = __log2f((float)th);
+        // planes on the same radii (the templates of a bank: one log-uniform grid) share the interval search: cls = where th
+        // lies (0 below the table, 1 beyond it, 2 on its last radius, 3 inside: interval j, offset dr)
+        const double* rSeen = nullptr;
+        int cls = 0, j = 0;
+        double dr = 0.0;
         for (int i = 0; i < P.n; ++i) {
             const double* __restrict__ r = P.r[i];
             const double* __restrict__ prof = P.prof[i];
             const double* __restrict__ slope = P.slope[i];
             const int ntab = P.ntab[i];
-            const double rlast = r[ntab - 1], rfirst = r[0];
+            if (r != rSeen) {
+                rSeen = r;
+                const double rlast = r[ntab - 1], rfirst = r[0];
+                if (th < rfirst) {
+                    cls = 0;
+                } else if (th > rlast) {
+                    cls = 1;
+                } else if (th == rlast) {
+                    cls = 2;
+                } else {
+                    cls = 3;
+                    j = (int)((lth - P.log2r0[i]) * P.invDlog2[i]);
+                    if (j < 0) j = 0;
+                    if (j > ntab - 2) j = ntab - 2;
+                    while (j > 0 && r[j] > th) --j;
+                    while (j < ntab - 2 && r[j + 1] <= th) ++j;
+                    dr = __dsub_rn(th, r[j]);
+                }
+            }
             double val;
-            if (th < rfirst) {
+            if (cls == 0) {
                 val = prof[0];
-            } else if (th > rlast) {
+            } else if (cls == 1) {
                 val = 0.0;
-            } else if (th == rlast) {
+            } else if (cls == 2) {
                 val = prof[ntab - 1];
             } else {
-                int j = (int)((lth - P.log2r0[i]) * P.invDlog2[i]);
-                if (j < 0) j = 0;
-                if (j > ntab - 2) j = ntab - 2;
-                while (j > 0 && r[j] > th) --j;
-                while (j < ntab - 2 && r[j + 1] <= th) ++j;
-                const double dr = __dsub_rn(th, r[j]);
                 const double sl = slope != nullptr ? slope[j] : __ddiv_rn(__dsub_rn(prof[j + 1], prof[j]), __dsub_rn(r[j + 1], r[j]));
                 val = __dadd_rn(__dmul_rn(sl, dr), prof[j]);
             }

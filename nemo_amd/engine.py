@@ -108,6 +108,7 @@ def ptr(t):
 
 
 _PINNED_COPY_MAX = 4 << 20
+_radiiDev = {}                # (length, content hash) -> device copy of a radial table's radii (TileEngine._tableDev)
 SCALE_BATCH = None            # scales per group of nf_matched_filter_scales (None: by tile size, Engine.scale_batch)
 _AXIS_WINDOW = os.environ.get('NEMO_AMD_AXIS_WINDOW', '1') != '0'    # 0: apply_window through the 2-D transforms always
 
@@ -482,8 +483,16 @@ class TileEngine(object):
             # radii, profile and slopes in ONE upload (three views of it): every upload is host time on the enqueueing thread
             r_, p_ = np.asarray(table.r, dtype=np.float64), np.asarray(table.prof, dtype=np.float64)
             n_ = len(r_)
-            packed = to_dev(np.concatenate([r_, p_, (p_[1:] - p_[:-1]) / (r_[1:] - r_[:-1])]))
-            table._dev = (packed[:n_], packed[n_:2 * n_], packed[2 * n_:])
+            # (tables on the same radii - the templates of a bank - share ONE device copy of them: nf_paint_radial_planes then
+            # searches the interval of a pixel once for all such planes)
+            rkey = (n_, hash(r_.tobytes()))
+            r_d = _radiiDev.get(rkey)
+            if r_d is None:
+                if len(_radiiDev) >= 64:
+                    _radiiDev.clear()
+                r_d = _radiiDev[rkey] = to_dev(r_)
+            packed = to_dev(np.concatenate([p_, (p_[1:] - p_[:-1]) / (r_[1:] - r_[:-1])]))
+            table._dev = (r_d, packed[:n_], packed[n_:])
         return table._dev
 
     def _geomDev(self, geom):

@@ -98,7 +98,7 @@ int nf_cross_power(int prec, const void* F_d, void* NP_d, int N, long long npix,
  *   nf_fft2_inverse_half  = nf_fft2_inverse_fused with real output of half-stored input planes and the symmetrised filter
  *                           (NULL = none); the window tables must be even, wy[H-y] == wy[y], as enmap.apply_window's
  *                           sinc(fftfreq) tables are.  planeScale (HOST doubles, or NULL): one more real factor per plane of
- *                           the sum (nSum > 1: nSum entries) or per batch entry (nSum == 1: batch entries), at most 8 -
+ *                           the sum (nSum > 1: nSum entries) or per batch entry (nSum == 1: batch entries), at most 16 -
  *                           the amplitude of a template whose spectrum is given for unit amplitude (nemo/filters.py:639-646).
  *                           rowLo < rowHi: only the output rows rowLo .. rowHi - 1 (widened to whole row pairs) are
  *                           computed, the rest of out_d is left as it was - nemo/filters.py:654-657 reads the filtered

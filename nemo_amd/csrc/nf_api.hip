@@ -280,7 +280,7 @@ int nf_fft2_inverse_half(nf_plan* p, int prec, const void* in, const double* fil
                          const double* wy, const double* wx, const double* planeScale, void* work, void* out, int outType, int batch,
                          int rowLo, int rowHi, int unitary, void* stream) {
     if (!p || !in || !work || !out || batch < 1 || (outType != NF_IN_REAL64 && outType != NF_IN_REAL32) || nSum < 1 ||
-        (nSum > 1 && (!filtSym || batch != 1)) || ((wy == nullptr) != (wx == nullptr)) || (planeScale && (nSum > 1 ? nSum : batch) > 8)) {
+        (nSum > 1 && (!filtSym || batch != 1)) || ((wy == nullptr) != (wx == nullptr)) || (planeScale && (nSum > 1 ? nSum : batch) > NF_PLANE_SCALES)) {
         nf_set_error("nf_fft2_inverse_half: bad arguments (the output must be real)");
         return NF_ERR_ARG;
     }

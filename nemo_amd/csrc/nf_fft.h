@@ -31,6 +31,8 @@ struct LinePlan {
     const cpx<T>* chirpFp;      // [m]  FFT_m(conj chirp, wrapped) / m, digit-reversed positions (Bluestein only)
 };
 
+#define NF_PLANE_SCALES 16      // room of the per-plane factor table of a transform (a power of two)
+
 template <typename T>
 struct LineArgs {
     LinePlan<T> plan;
@@ -56,7 +58,7 @@ struct LineArgs {
     int lineBase;            // rows kernel: first line of this launch (lines lineBase .. nLines - 1)
     int colPair;             // columns kernel, float32: strides, types and table alignment allow two adjacent columns per thread
     int usePlaneScale;       // halfIn: plane pl of the sum (nSum > 1) / batch entry b (nSum <= 1) is also multiplied by planeScale[pl / b]
-    double planeScale[8];
+    double planeScale[NF_PLANE_SCALES];
     const double* winLine;   // pixel-window table along the line index (columns kernel: wx[col]) and
     const double* winElem;   //   along the element index (wy[row]); both NULL = no window
     // real-data transforms (half the work of a complex transform; see "Real input / real output" in nf_fft.hip)

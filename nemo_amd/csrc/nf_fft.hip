@@ -257,7 +257,7 @@ __device__ __forceinline__ cpx<T> fused_ops_herm(const nf::LineArgs<T>& a, const
                 f.y *= (T)a.conjInSign;
             }
             double g = ms ? ms[(size_t)pl * (size_t)a.sumStride + off] : 1.0;
-            if (a.usePlaneScale) g *= a.planeScale[a.nSum > 1 ? pl : (int)(blockIdx.y & 7)];
+            if (a.usePlaneScale) g *= a.planeScale[a.nSum > 1 ? pl : (int)(blockIdx.y & (NF_PLANE_SCALES - 1))];
             re += (double)f.x * g;
             im += (double)f.y * g;
         }
@@ -366,7 +366,7 @@ __device__ __forceinline__ void fft_stage(cpx<T>* __restrict__ buf, const nf::Li
                         for (int k = 0; k < R; ++k) f[k] = 1.0;
                     }
                     if (a.usePlaneScale) {
-                        const double ps = a.planeScale[blockIdx.y & 7];
+                        const double ps = a.planeScale[blockIdx.y & (NF_PLANE_SCALES - 1)];
 #pragma unroll
                         for (int k = 0; k < R; ++k) f[k] *= ps;
                     }
@@ -538,7 +538,7 @@ __device__ __forceinline__ void fft_stage_colpair(cpx<float>* __restrict__ buf, 
                         m2[k].y = 1.0;
                     }
                 }
-                const double ps = a.usePlaneScale ? a.planeScale[blockIdx.y & 7] : 1.0;
+                const double ps = a.usePlaneScale ? a.planeScale[blockIdx.y & (NF_PLANE_SCALES - 1)] : 1.0;
                 const bool win = a.winElem != nullptr;
                 const double wl0 = win ? a.winLine[col] : 1.0, wl1 = win ? a.winLine[col + 1] : 1.0;
 #pragma unroll
@@ -1171,7 +1171,7 @@ __global__ void __launch_bounds__(NF_FFT_MAXTHREADS) k_template_cols(nf::LineArg
     const size_t npix = (size_t)af.realH * (size_t)W;
     double* __restrict__ sym = tf.sym + (size_t)blockIdx.y * npix;
     float* __restrict__ filt = tf.filt[blockIdx.y & (NF_TF_MAXBATCH - 1)];
-    const double ps = ai.usePlaneScale ? ai.planeScale[blockIdx.y & 7] : 1.0;
+    const double ps = ai.usePlaneScale ? ai.planeScale[blockIdx.y & (NF_PLANE_SCALES - 1)] : 1.0;
     const bool win = ai.winElem != nullptr;
     cpx<float> hold[NF_TF_MAXE];
     // (a thread's elements in groups of NF_TF_GRP: the noise power at the group's modes and mirror modes is fetched in one
@@ -2002,8 +2002,8 @@ int Plan2D<T>::inverse_half(const void* in, void* work, void* out, int outType, 
     c.fused = 1;
     if (planeScale != nullptr) {
         const int np_ = nSum > 1 ? nSum : batch;
-        if (np_ > 8) {
-            nf_set_error("inverse_half: at most 8 plane factors");
+        if (np_ > NF_PLANE_SCALES) {
+            nf_set_error("inverse_half: at most 16 plane factors");
             return NF_ERR_ARG;
         }
         c.usePlaneScale = 1;

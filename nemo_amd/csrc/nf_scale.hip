@@ -63,9 +63,9 @@ Layout layout_of(const nf_mf_tile& t) {
     L.T = take(B * N * npix * 4);                    // painted templates, float32
     L.F = take(B * N * npix * 8);                    // their half-stored spectra, complex64
     L.filtSym = take(B * N * npix * 8);              // symmetrised filters, float64
-    // transposed intermediate of the inverse transforms: the group's data maps, or one chunk (<= 8 planes) of filtered templates
+    // transposed intermediate of the inverse transforms: the group's data maps, or one chunk (<= 16 planes) of filtered templates
     size_t work = B * npix * (t.prec == NF_F64 ? 16 : 8);
-    const size_t chunk = (B * N < 8 ? B * N : 8) * npix * 8;
+    const size_t chunk = (B * N < NF_PLANE_SCALES ? B * N : NF_PLANE_SCALES) * npix * 8;
     if (yc && chunk > work) work = chunk;
     L.work = take(work);
     L.sig = take(B * npix * 4);                      // filtered templates
@@ -261,8 +261,8 @@ int run_group(nf_plan* plan, const nf_mf_tile& t, const nf_mf_scale* sc, int nb,
     // normalisation
     if (yc) {
         // the y0-scaled templates (:639-646) are the unit templates times templateScale: the factor rides on the load.  Up to 8
-        // planes (the room in the factor table) per transform.
-        const int per = N == 1 ? 8 : 8 / N;               // scales per transform
+        // planes (the room in the fused kernel's tables) per transform with one map, 16 (the factor table) with several.
+        const int per = N == 1 ? 8 : NF_PLANE_SCALES / N;               // scales per transform
         if (fuse) {
             double planeScale[8];
             for (int j = 0; j < nb; ++j) planeScale[j] = sc[j].templateScale[0];
@@ -271,7 +271,7 @@ int run_group(nf_plan* plan, const nf_mf_tile& t, const nf_mf_scale* sc, int nb,
         }
         for (int b0 = 0; b0 < nb && !fuse; b0 += per) {
             const int cnt = nb - b0 < per ? nb - b0 : per;
-            double planeScale[8];
+            double planeScale[NF_PLANE_SCALES];
             for (int j = 0; j < cnt; ++j)
                 for (int i = 0; i < N; ++i) planeScale[j * N + i] = sc[b0 + j].templateScale[i];
             const char* Fc = F + (size_t)b0 * N * npix * 8;

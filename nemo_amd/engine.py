@@ -330,8 +330,8 @@ class TileEngine(object):
         if half:
             ps = None
             if planeScale is not None:
-                if len(planeScale) != N or N > 8:
-                    raise NemoFiltError("planeScale: one factor per plane, at most 8 planes")
+                if len(planeScale) != N or N > 16:
+                    raise NemoFiltError("planeScale: one factor per plane, at most 16 planes")
                 ps = (ctypes.c_double * N)(*[float(v) for v in planeScale])
             rowLo, rowHi = (0, 0) if rows is None else (int(rows[0]), int(rows[1]))
             check(self.lib.nf_fft2_inverse_half(self.plan, prec, ptr(X3), ptr(f3), nSum, perBatch, ptr(wy), ptr(wx), ps, ptr(work),

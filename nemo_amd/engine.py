@@ -1077,21 +1077,27 @@ class TileEngine(object):
             out.append(_SplinePoints(dev[off:off + 2 * n], n, pointsClass, halfWin, edge, len(edgeIdx)))
         return out
 
-    def spline_eval_batch(self, jobs, returnFlat=False):
+    def spline_eval_batch(self, jobs, returnFlat=False, flatOnly=False):
         """[(map tensor, _SplinePoints, negate)] -> list of float64 device tensors, one launch per kernel for up to 32 jobs of a
-        dtype (nf_spline_eval_batch).  The results are views of one buffer, job after job (``returnFlat``: that buffer too).
-        A point set with nEdge < 0 does not know which of its points lie near the border: every point is offered to both kernels."""
+        dtype (nf_spline_eval_batch).  The results are views of one buffer, job after job (``returnFlat``: that buffer too;
+        ``flatOnly``: only that buffer - no view per job is made).  A point set with nEdge < 0 does not know which of its points
+        lie near the border: every point is offered to both kernels; its ``dev`` may be a raw device address (int) into a
+        tensor the caller keeps alive."""
         t = self.t
         outs = [None] * len(jobs)
-        total = sum(pts.n for _, pts, _ in jobs)
-        flat = t.empty(max(total, 1), dtype=t.float64, device=self.dev)
+        offs = [0] * len(jobs)
         pos = 0
         groups = {}
         for k, (m, pts, neg) in enumerate(jobs):
-            outs[k] = flat[pos:pos + pts.n]
+            offs[k] = pos
             pos += pts.n
             if pts.n > 0:
                 groups.setdefault((prec_of(m), pts.halfWin), []).append(k)
+        total = pos
+        flat = t.empty(max(total, 1), dtype=t.float64, device=self.dev)
+        if not flatOnly:
+            for k, (m, pts, neg) in enumerate(jobs):
+                outs[k] = flat[offs[k]:offs[k] + pts.n]
         VP, CI = ctypes.c_void_p, ctypes.c_int
         base = flat.data_ptr()
         for (prec, halfWin), ks in groups.items():
@@ -1100,16 +1106,18 @@ class TileEngine(object):
                 nj = len(part)
                 maps = (VP * nj)(*[jobs[k][0].data_ptr() for k in part])
                 negs = (CI * nj)(*[1 if jobs[k][2] else 0 for k in part])
-                yxp = [jobs[k][1].dev.data_ptr() for k in part]
+                yxp = [jobs[k][1].dev if isinstance(jobs[k][1].dev, int) else jobs[k][1].dev.data_ptr() for k in part]
                 yxs = (VP * nj)(*yxp)
                 ns = (CI * nj)(*[jobs[k][1].n for k in part])
                 # (no border points: an empty list, not "unknown" - the pointer must still be non-null to say so)
                 edges = (VP * nj)(*[(None if jobs[k][1].nEdge < 0 else (jobs[k][1].edge.data_ptr() if jobs[k][1].edge is not None else yxp[i]))
                                     for i, k in enumerate(part)])
                 nes = (CI * nj)(*[max(jobs[k][1].nEdge, 0) for k in part])
-                os_ = (VP * nj)(*[base + 8 * outs[k].storage_offset() for k in part])
+                os_ = (VP * nj)(*[base + 8 * offs[k] for k in part])
                 check(self.lib.nf_spline_eval_batch(prec, nj, maps, negs, yxs, ns, edges, nes, os_, self.H, self.W, halfWin, stream_ptr()),
                       "nf_spline_eval_batch")
+        if flatOnly:
+            return None, flat[:total]
         if returnFlat:
             return outs, flat[:total]
         return outs

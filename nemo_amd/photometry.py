@@ -228,7 +228,8 @@ def _findObjectsVector(dicts, prefetch, threshold=3.0, minObjPix=3, rejectBorder
         return None
     results = [[] for _ in range(M)]
     # objects passing the size cut, map after map, in label order
-    valid = (np.arange(1, cap + 1)[None, :] <= numObjects[:, None]) & (S[:, 1:, 0] >= minObjPix)
+    top = int(numObjects.max())                       # (records beyond the largest label count of the group hold nothing)
+    valid = (np.arange(1, top + 1)[None, :] <= numObjects[:, None]) & (S[:, 1:top + 1, 0] >= minObjPix)
     mi, li = np.nonzero(valid)
     if len(mi) == 0:
         return results
@@ -243,6 +244,7 @@ def _findObjectsVector(dicts, prefetch, threshold=3.0, minObjPix=3, rejectBorder
     iyr, ixr = np.round(ys).astype(np.int64), np.round(xs).astype(np.int64)
     counts = np.bincount(mi, minlength=M)
     offs = np.concatenate([[0], np.cumsum(counts)])
+    tm = _mark('records', tm)
     RADeg, decDeg = wcs.pix2wcs(xs, ys)                                           # :115-117
     RADeg = np.where(RADeg < 0, 360.0 + RADeg, RADeg)
     havePre = any(bool(pf) for pf in prefetch)
@@ -256,25 +258,29 @@ def _findObjectsVector(dicts, prefetch, threshold=3.0, minObjPix=3, rejectBorder
     else:
         yx = np.stack([ys, xs], axis=1)
     n = len(ys)
-    yxDev = engine.to_dev(np.ascontiguousarray(yx).reshape(-1))
+    tm = _mark('positions', tm)
+    yxDev = engine.to_dev(np.ascontiguousarray(yx).reshape(-1))       # (the jobs below name its parts by address)
+    yxBase = yxDev.data_ptr()
+    tm = _mark('upload', tm)
     jobs, keys = [], []           # (map, points of the map's own objects, negate)
     for k in range(M):
         a, b = int(offs[k]), int(offs[k + 1])
         if b == a:
             continue
-        ptsSN = engine._SplinePoints(yxDev[2 * a:2 * b], b - a, 0, 32, None, -1)
+        ptsSN = engine._SplinePoints(yxBase + 16 * a, b - a, 0, 32, None, -1)
         jobs.append((dSNs[k], ptsSN, invertMap))
         keys.append((k, 'SNR'))
         if prefetch[k]:
-            pts = engine._SplinePoints(yxDev[2 * (n + a):2 * (n + b)], b - a, 0, 32, None, -1)
+            pts = engine._SplinePoints(yxBase + 16 * (n + a), b - a, 0, 32, None, -1)
             for j, (mapLike, neg) in enumerate(prefetch[k]):
                 jobs.append((engine.to_dev(mapLike), pts, neg))
                 keys.append((k, j))
-    outs, flatOut = eng.spline_eval_batch(jobs, returnFlat=True)
+    tm = _mark('jobs', tm)
+    outs, flatOut = eng.spline_eval_batch(jobs, flatOnly=True)
     queued = flatOut
     if not noFlags and hasattr(flagMask, 'is_cuda'):
         queued = t.cat([flatOut, _lookupDev(flagMask, iyr, ixr)])
-    tm = _mark('positions + enqueue reads', tm)
+    tm = _mark('enqueue reads', tm)
     vals = queued.cpu().numpy()
     tm = _mark('fetch reads', tm)
     flagsOnDevice = hasattr(flagMask, 'is_cuda')
@@ -290,37 +296,47 @@ def _findObjectsVector(dicts, prefetch, threshold=3.0, minObjPix=3, rejectBorder
         pos += pts_.n
     SNRs = np.concatenate([got[(k, 'SNR')] for k in range(M) if counts[k] > 0])
     keep = SNRs > threshold                                                       # :186
-    gal = galacticLatDeg(RADeg, decDeg)
-    numSigPix = rows[:, 0]
+    # the rows that stay, compressed once for all maps; a map's table then takes slices
+    keptPerMap = np.bincount(mi[keep], minlength=M)
+    offsK = np.concatenate([[0], np.cumsum(keptPerMap)])
+    RAk, deck, SNRk = RADeg[keep], decDeg[keep], SNRs[keep]
+    numSigPixk = rows[:, 0][keep]
+    flagsk = flagsAll[keep]
+    galk = galacticLatDeg(RAk, deck)
+    xk, yk = xs[keep], ys[keep]
+    insidek = inside[keep] if havePre else None
+    ringAll = np.zeros(len(RAk), dtype=bool)
+    flagsk = flagsk + ringAll                                                      # :208 (flags += ringFlag: no rings here)
+    templatek = np.repeat(np.array([d['label'] for d in dicts], dtype='U%d' % max([30] + [len(d['label']) for d in dicts])), keptPerMap)
+    tileNamek = np.repeat(np.array([d['tileName'] for d in dicts], dtype='U%d' % max([30] + [len(d['tileName']) for d in dicts])),
+                          keptPerMap)
     for k in range(M):
-        a, b = int(offs[k]), int(offs[k + 1])
-        if b == a:
-            continue
-        kp = keep[a:b]
-        nk = int(kp.sum())
+        nk = int(keptPerMap[k])
         if nk == 0:
             continue
+        a, b = int(offs[k]), int(offs[k + 1])
+        a2, b2 = int(offsK[k]), int(offsK[k + 1])
         d = dicts[k]
         tab = catalogs.Table()
         tab.setLazyNames(objIdent, longNames)                                      # :120-123 (built on first access)
         c = tab._cols
-        c['RADeg'] = RADeg[a:b][kp]
-        c['decDeg'] = decDeg[a:b][kp]
-        c['SNR'] = SNRs[a:b][kp]
-        c['numSigPix'] = numSigPix[a:b][kp]
-        c['template'] = np.full(nk, d['label'], dtype='U%d' % max(30, len(d['label'])))
-        c['tileName'] = np.full(nk, d['tileName'], dtype='U%d' % max(30, len(d['tileName'])))
-        ringFlag = np.zeros(nk, dtype=bool)
-        c['flags'] = flagsAll[a:b][kp] + ringFlag                                  # :208 (flags += ringFlag: no rings here)
-        c['ringFlag'] = ringFlag
-        c['galacticLatDeg'] = gal[a:b][kp]
-        c['x'] = xs[a:b][kp]
-        c['y'] = ys[a:b][kp]
+        c['RADeg'] = RAk[a2:b2]
+        c['decDeg'] = deck[a2:b2]
+        c['SNR'] = SNRk[a2:b2]
+        c['numSigPix'] = numSigPixk[a2:b2]
+        c['template'] = templatek[a2:b2]
+        c['tileName'] = tileNamek[a2:b2]
+        c['flags'] = flagsk[a2:b2]
+        c['ringFlag'] = ringAll[a2:b2]
+        c['galacticLatDeg'] = galk[a2:b2]
+        c['x'] = xk[a2:b2]
+        c['y'] = yk[a2:b2]
         # column order as findObjects leaves it: flags is set again last there, which keeps its place
         if prefetch[k]:
+            kp = keep[a:b]
             tab._prefetched = {}
             for j, (mapLike, neg) in enumerate(prefetch[k]):
-                tab._prefetched[(id(mapLike), bool(neg))] = (got[(k, j)][kp], inside[a:b][kp], nk)
+                tab._prefetched[(id(mapLike), bool(neg))] = (got[(k, j)][kp], insidek[a2:b2], nk)
         results[k] = tab
     tm = _mark('table', tm)
     return results
@@ -631,6 +647,65 @@ def measureFluxes(catalog, filteredMapDict, diagnosticsDir, photFilteredMapDict=
                 if reportJyFluxes:
                     catalog[prefix + 'fluxJy'] = deltaTToJyPerSr(catalog[prefix + 'deltaT_c'], obsFreqGHz) * beamSolidAngle_nsr * 1.e-9
                     catalog[prefix + 'err_fluxJy'] = deltaTToJyPerSr(catalog[prefix + 'err_deltaT_c'], obsFreqGHz) * beamSolidAngle_nsr * 1.e-9
+
+
+def measureFluxesGroup(catalogList, filteredMapDictList, diagnosticsDir, photFilteredMapDictList, useInterpolator=True,
+                       ycObsFreqGHz=148.0):
+    """measureFluxes for the catalogues of a group of yc maps (the scales of a tile) with the arithmetic written once over the
+    concatenated rows - the same statements per row as measureFluxes, the same columns in the same order; anything else (other
+    units, mixed groups, tables without the values findObjectsGroup fetched ahead) goes map by map."""
+    live = [k for k, c in enumerate(catalogList) if hasattr(c, 'keys') and len(c) > 0]
+    vector = _VECTOR_GROUP and len(live) > 1
+    if vector:
+        withPhot = photFilteredMapDictList[live[0]] is not None
+        for k in live:
+            d, ph, c = filteredMapDictList[k], photFilteredMapDictList[k], catalogList[k]
+            pre = getattr(c, '_prefetched', None)
+            if d['wcs'].header['BUNIT'] != 'yc' or (ph is not None) != withPhot or pre is None or 'SNR' not in c._cols:
+                vector = False
+                break
+            need = [(id(d['data']), False)] + ([(id(ph['SNMap']), False), (id(ph['data']), False)] if withPhot else [])
+            if any(pre.get(q) is None or pre[q][2] != len(c) for q in need):
+                vector = False
+                break
+    if not vector:
+        for c, d, ph in zip(catalogList, filteredMapDictList, photFilteredMapDictList):
+            measureFluxes(c, d, diagnosticsDir, photFilteredMapDict=ph, useInterpolator=useInterpolator, ycObsFreqGHz=ycObsFreqGHz)
+        return
+    cats = [catalogList[k] for k in live]
+    offs = np.concatenate([[0], np.cumsum([len(c) for c in cats])])
+    n = int(offs[-1])
+    cat = lambda parts: np.concatenate(parts)           # noqa: E731
+    out = {}            # column -> values of all rows, in measureFluxes' column order
+    if withPhot:
+        # getSNRValues (:251-281): 0 where the position falls outside the map
+        hits = [c._prefetched[(id(photFilteredMapDictList[k]['SNMap']), False)] for k, c in zip(live, cats)]
+        inside = cat([h[1] for h in hits])
+        col = np.zeros(n)
+        col[inside] = cat([h[0] for h in hits])[inside]
+        out['fixed_SNR'] = col
+    prefixes = [''] + (['fixed_'] if withPhot else [])
+    for prefix in prefixes:
+        for key in ('deltaT_c', 'err_deltaT_c', 'y_c', 'err_y_c'):
+            out[prefix + key] = None
+    SNRs = {'': cat([c._cols['SNR'] for c in cats])}
+    if withPhot:
+        SNRs['fixed_'] = out['fixed_SNR']
+    for prefix in prefixes:
+        maps = [(filteredMapDictList[k] if prefix == '' else photFilteredMapDictList[k])['data'] for k in live]
+        mapValue = cat([c._prefetched[(id(m), False)][0] for c, m in zip(cats, maps)])
+        with np.errstate(divide='ignore', invalid='ignore'):
+            y = mapValue / 1e-4                                                    # :357-366
+            out[prefix + 'y_c'] = y
+            out[prefix + 'err_y_c'] = y / SNRs[prefix]
+            deltaTc = convertToDeltaT(mapValue, obsFrequencyGHz=ycObsFreqGHz)
+            out[prefix + 'deltaT_c'] = deltaTc
+            out[prefix + 'err_deltaT_c'] = np.abs(deltaTc / SNRs[prefix])
+    for i, c in enumerate(cats):
+        a, b = int(offs[i]), int(offs[i + 1])
+        cols = c._cols
+        for key, v in out.items():
+            cols[key] = v[a:b]
 
 
 def makeForcedPhotometryCatalog(filteredMapDict, inputCatalog, useInterpolator=True, DS9RegionsPath=None):

@@ -326,10 +326,12 @@ def _detectAndMeasure(config, jobs, stream, invertMap, measureFluxes, photFilter
                                                useInterpolator=config.parDict['useInterpolator'],
                                                measureShapes=config.parDict['measureShapes'], invertMap=invertMap,
                                                verbose=verbose)
+        if measureFluxes == True:
+            photometry.measureFluxesGroup(cats, [job[2] for job in jobs], config.diagnosticsDir, [job[3] for job in jobs],
+                                          useInterpolator=config.parDict['useInterpolator'])
         for catalog, (label, f, filteredMapDict, photFilteredMapDict, ready) in zip(cats, jobs):
             if measureFluxes == True:
-                photometry.measureFluxes(catalog, filteredMapDict, config.diagnosticsDir, photFilteredMapDict=photFilteredMapDict,
-                                         useInterpolator=config.parDict['useInterpolator'])
+                pass
             elif photFilter is not None:
                 photometry.getSNRValues(catalog, photFilteredMapDict['SNMap'], filteredMapDict['wcs'], prefix='fixed_',
                                         useInterpolator=config.parDict['useInterpolator'], invertMap=invertMap)

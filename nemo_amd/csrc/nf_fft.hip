@@ -1018,7 +1018,7 @@ __global__ void __launch_bounds__(512, (MODE == 0 ? 4 : 2)) k_fft_rows(nf::LineA
 // are Hermitian along y, so their transforms separate again (forward: with the mirror element; inverse: real / imaginary
 // part).  The pass then covers W/2 columns instead of W/2 + 1.
 template <typename T, int MODE, int SPEC>
-__global__ void __launch_bounds__((MODE == 0 && SPEC == 3 && sizeof(T) == 8) ? 512 : NF_FFT_MAXTHREADS) k_fft_cols(nf::LineArgs<T> a) {
+__device__ __forceinline__ void fft_cols_body(const nf::LineArgs<T>& a) {
     extern __shared__ __align__(16) unsigned char nf_smem[];
     cpx<T>* buf = (cpx<T>*)nf_smem;
     const nf::LinePlan<T>& p = a.plan;
@@ -1111,6 +1111,19 @@ __global__ void __launch_bounds__((MODE == 0 && SPEC == 3 && sizeof(T) == 8) ? 5
     }
 }
 
+
+// Long columns run as one wide workgroup per CU (1024 threads: at most 128 registers per lane); short ones (the tiles of a
+// survey, a few KB per column) as 256-thread workgroups, several per CU - compiled for that, the same body keeps its operands
+// in registers where the wide form spills (840 x 1440, float64 inverse with the frequency sum: 272 -> 215 us per 8 scales).
+template <typename T, int MODE, int SPEC>
+__global__ void __launch_bounds__((MODE == 0 && SPEC == 3 && sizeof(T) == 8) ? 512 : NF_FFT_MAXTHREADS) k_fft_cols(nf::LineArgs<T> a) {
+    fft_cols_body<T, MODE, SPEC>(a);
+}
+
+template <typename T, int MODE, int SPEC>
+__global__ void __launch_bounds__(256) k_fft_cols_s(nf::LineArgs<T> a) {
+    fft_cols_body<T, MODE, SPEC>(a);
+}
 
 // ------------------------------------------------------------------------------------------------------
 // The template path of a matched-filter scale with one frequency map, as ONE pass over the column tiles (float32 templates):
@@ -1744,6 +1757,12 @@ int launch_lines(const LineArgs<T>& a0, bool cols, int batch, int threads, hipSt
         NF_ATTR((k_fft_cols<T, 0, 3>));
         NF_ATTR((k_fft_cols<T, 1, 3>));
         NF_ATTR((k_fft_cols<T, 2, 3>));
+        NF_ATTR3(k_fft_cols_s, 0);
+        NF_ATTR3(k_fft_cols_s, 1);
+        NF_ATTR3(k_fft_cols_s, 2);
+        NF_ATTR((k_fft_cols_s<T, 0, 3>));
+        NF_ATTR((k_fft_cols_s<T, 1, 3>));
+        NF_ATTR((k_fft_cols_s<T, 2, 3>));
 #undef NF_ATTR3
 #undef NF_ATTR
         attrSet[which] = true;
@@ -1780,7 +1799,15 @@ int launch_lines(const LineArgs<T>& a0, bool cols, int batch, int threads, hipSt
         else NF_LAUNCH2(K, M, 2);                \
     } while (0)
     if (cols && spec == 3 && mode == 0 && sizeof(T) == 8 && threads > 512) threads = 512;   // that variant trades threads for registers
-    if (cols && spec == 3) {
+    if (cols && threads <= 256 && spec == 3) {
+        if (mode == 0) NF_LAUNCH2(k_fft_cols_s, 0, 3);
+        else if (mode == 1) NF_LAUNCH2(k_fft_cols_s, 1, 3);
+        else NF_LAUNCH2(k_fft_cols_s, 2, 3);
+    } else if (cols && threads <= 256) {
+        if (mode == 0) NF_LAUNCH(k_fft_cols_s, 0);
+        else if (mode == 1) NF_LAUNCH(k_fft_cols_s, 1);
+        else NF_LAUNCH(k_fft_cols_s, 2);
+    } else if (cols && spec == 3) {
         if (mode == 0) NF_LAUNCH2(k_fft_cols, 0, 3);
         else if (mode == 1) NF_LAUNCH2(k_fft_cols, 1, 3);
         else NF_LAUNCH2(k_fft_cols, 2, 3);

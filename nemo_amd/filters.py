@@ -109,6 +109,9 @@ def filterMapsGroup(unfilteredMapsDictList, filterParamsList, tileName, diagnost
 
 
 # ------------------------------------------------------------------------------------------------------------
+_templateSlots = {}      # MatchedFilter._runScales: (parameter set, maps) -> the template fields of a scale's record
+
+
 class _DeviceWeights(dict):
     """fRelWeights whose values are still on the device: {obsFreqGHz: float32(plane value at the peak) / float32(peak)}
     (nemo/filters.py:661-667), formed on first access from one small transfer."""
@@ -586,9 +589,13 @@ class MatchedFilter(MapFilter):
         if len(self.unfilteredMapsDictList) > _lib.NF_MF_MAXN:
             return None          # (the statement path then fails in nf_build_filter with its own '1 <= N <= 6' message)
         noiseCats = p.get('noiseModelCatalog', None)
+        # (the frequency weights depend on the tile's maps, the output units and alpha: once per tile for a bank's scales)
+        wkey = ('freqWeightsKey', p['outputUnits'], p.get('alpha', None))
+        wts = self._shared.get(wkey)
+        if wts is None:
+            wts = self._shared[wkey] = tuple(float(v) for v in self._frequencyWeights())
         return (id(self._shared), type(self).templateKind, p['outputUnits'], npar.get('noiseGridArcmin', None), npar.get('numNoiseBins', 1),
-                npar.get('RMSEstimator', None), self._trimSizePix(), None if noiseCats is None else id(noiseCats),
-                tuple(float(v) for v in self._frequencyWeights()))
+                npar.get('RMSEstimator', None), self._trimSizePix(), None if noiseCats is None else id(noiseCats), wts)
 
     @staticmethod
     def _runScales(objs, undoPixelWindow, lanes, keepFilters=None):
@@ -660,14 +667,28 @@ class MatchedFilter(MapFilter):
         snChunks = t.empty((G, nch), dtype=t.int64, device=eng.dev)       # per scale: S/N range per 1024-pixel chunk
         scales = (_lib.MfScale * G)()
         es = data.element_size()
+        # the template part of a scale's record depends on the filter's parameters and the maps' beams / bands, not on the
+        # tile: kept per (parameter set, maps) for the tiles that follow (_templateSlots holds the device tables alive)
+        mapsKey = tuple((m['beamFileName'] if isinstance(m['beamFileName'], str) else id(m['beamFileName']), m['units'], m['obsFreqGHz'])
+                        for m in first.unfilteredMapsDictList)
         for g, obj in enumerate(objs):
             sc = scales[g]
-            for i, mapDict in enumerate(obj.unfilteredMapsDictList):
-                t1, scale = obj._unitTemplate(mapDict, y0 if yc else None)
-                r, prof, slope = eng._tableDev(t1)
-                sc.r_d[i], sc.prof_d[i], sc.slope_d[i] = r.data_ptr(), prof.data_ptr(), slope.data_ptr()
-                sc.ntab[i], sc.r0[i], sc.dlnr[i], sc.amp[i], sc.sign[i] = len(t1.r), t1.r0, t1.dlnr, t1.amp, t1.sign
-                sc.templateScale[i] = scale
+            p = obj.params
+            slotKey = (id(p), type(obj).templateKind, yc, p.get('z'), p.get('M500MSun'), id(p.get('GNFWParams')), mapsKey,
+                       tuple(id(m) for m in obj.unfilteredMapsDictList) if obj.unfilteredMapsDictList is not first.unfilteredMapsDictList else None)
+            slot = _templateSlots.get(slotKey)
+            if slot is None or slot[0] is not p:
+                rows = []
+                for i, mapDict in enumerate(obj.unfilteredMapsDictList):
+                    t1, scale = obj._unitTemplate(mapDict, y0 if yc else None)
+                    r, prof, slope = eng._tableDev(t1)
+                    rows.append((r.data_ptr(), prof.data_ptr(), slope.data_ptr(), len(t1.r), t1.r0, t1.dlnr, t1.amp, t1.sign, scale, t1))
+                if len(_templateSlots) >= 4096:
+                    _templateSlots.clear()
+                slot = _templateSlots[slotKey] = (p, rows)
+            for i, row in enumerate(slot[1]):
+                (sc.r_d[i], sc.prof_d[i], sc.slope_d[i], sc.ntab[i], sc.r0[i], sc.dlnr[i], sc.amp[i], sc.sign[i],
+                 sc.templateScale[i]) = row[:9]
             sc.filt_d = cubes[g].data_ptr() if cubes[g] is not None else None
             sc.signalNorm_d = scal.data_ptr() + g * (N + 2) * 8
             sc.relWeights_d = scal.data_ptr() + (g * (N + 2) + 1) * 8

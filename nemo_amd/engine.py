@@ -844,26 +844,40 @@ class TileEngine(object):
                                          ptr(schedBoxes_d[a:e]), schedBoxes[a:e].ctypes.data_as(ctypes.POINTER(ctypes.c_int)), e - a,
                                          float(limits[k]), 1 if times60 else 0, ptr(rmap), stream_ptr()), "nf_disc_apply")
 
-    def paint_catalog(self, objs, wins, geom, profs, ntab, out=None):
+    def paint_catalog(self, objs, wins, geom, profs, ntab, out=None, geomDev=None, profsDev=None):
         """Sum of the objects' radial templates, each inside its window, accumulated in float32 in catalogue order
-        (nf_paint_catalog).  objs [n, 8] float64, wins [n, 8] int32, geom: packed haversine tables, profs [nProf, 3, ntab]."""
+        (nf_paint_catalog).  objs [n, 8] float64, wins [n, 8] int32, geom: packed haversine tables, profs [nProf, 3, ntab].
+        ``geomDev`` / ``profsDev``: device copies of ``geom`` / ``profs`` the caller keeps (an injection run paints the same
+        windows and the same profile pass after pass); the objects and their windows go up in ONE transfer."""
         t = self.t
         objs = np.ascontiguousarray(objs, dtype=np.float64).reshape(-1, 8)
         wins = np.ascontiguousarray(wins, dtype=np.int32).reshape(-1, 8)
-        geom = np.ascontiguousarray(geom, dtype=np.float64)
-        profs = np.ascontiguousarray(profs, dtype=np.float64)
         acc = 1
         if out is None:
             out = t.empty((self.H, self.W), dtype=t.float32, device=self.dev)
             acc = 0
-        if len(objs) == 0:
+        n = len(objs)
+        if n == 0:
             if not acc:
                 out.zero_()
             return out
-        o_d, w_d, g_d, p_d = to_dev(objs), to_dev(wins), to_dev(geom), to_dev(profs)
-        check(self.lib.nf_paint_catalog(ptr(out), self.H, self.W, len(objs), ptr(o_d), ptr(w_d),
-                                        wins.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), ptr(g_d), geom.size, ptr(p_d),
-                                        profs.shape[0], int(ntab), acc, stream_ptr()), "nf_paint_catalog")
+        if geomDev is None:
+            geom = np.ascontiguousarray(geom, dtype=np.float64)
+            geomDev, geomSize = to_dev(geom), geom.size
+        else:
+            geomSize = geomDev.numel()
+        if profsDev is None:
+            profs = np.ascontiguousarray(profs, dtype=np.float64)
+            profsDev = to_dev(profs)
+        nProf = profsDev.numel() // (3 * int(ntab))
+        packed = np.empty(n * 12, dtype=np.float64)           # [n, 8] float64 records, then [n, 8] int32 windows
+        packed[:n * 8] = objs.reshape(-1)
+        packed[n * 8:].view(np.int32)[:] = wins.reshape(-1)
+        p_d = to_dev(packed)
+        base = p_d.data_ptr()
+        check(self.lib.nf_paint_catalog(ptr(out), self.H, self.W, n, ctypes.c_void_p(base), ctypes.c_void_p(base + n * 64),
+                                        wins.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), ptr(geomDev), geomSize, ptr(profsDev),
+                                        nProf, int(ntab), acc, stream_ptr()), "nf_paint_catalog")
         return out
 
     def resample_bilinear(self, planes, H2, W2, yIdx, xIdx):

@@ -421,6 +421,9 @@ def _modelGeometryMany(shape, wcs, RADeg, decDeg, maxSizeDeg):
     return np.stack([x0, x1, y0, y1], axis=1), geom, offA, offC
 
 
+_catalogProfDev = {}      # id(profile array) -> (profile, radii, device [3, ntab] table) for nf_paint_catalog
+
+
 def makeModelImage(shape, wcs, catalog, beamFileName, obsFreqGHz=None, GNFWParams='default', profile='A10', cosmoModel=None,
                    applyPixelWindow=True, override=None, validAreaSection=None, minSNR=-99, TCMBAlpha=0, reportTimingInfo=False,
                    maxSizeDegMultiplier=5, useInferredSZProperties=False, _geomCache=None):
@@ -460,7 +463,12 @@ def makeModelImage(shape, wcs, catalog, beamFileName, obsFreqGHz=None, GNFWParam
         held = _modelGeometryMany(shape, wcs, RAs, decs, sizes)
         if _geomCache is not None:
             _geomCache[gkey] = held
-    winArr, geom, offA, offC = held
+    winArr, geom, offA, offC = held[:4]
+    eng = engine.TileEngine.get(shape)
+    if _geomCache is not None and len(held) == 4:
+        # (the device copy of the windows' tables stays with them)
+        held = _geomCache[gkey] = held + (engine.to_dev(np.ascontiguousarray(geom if len(geom) > 0 else np.zeros(1), dtype=np.float64)),)
+    geomDev = held[4] if len(held) > 4 else None
     objs, profTabs, profIndex = [], [], {}
     wins = np.zeros((nObj, 8), dtype=np.int64)
     wins[:, 0:4] = winArr
@@ -470,16 +478,28 @@ def makeModelImage(shape, wcs, catalog, beamFileName, obsFreqGHz=None, GNFWParam
         pid = profIndex.get(id(table.prof))
         if pid is None:
             pid = profIndex[id(table.prof)] = len(profTabs)
-            slope = np.zeros(len(table.r))
-            slope[:-1] = (table.prof[1:] - table.prof[:-1]) / (table.r[1:] - table.r[:-1])
-            profTabs.append(np.stack([table.r, table.prof, slope]))
+            profTabs.append(table)
         useF = 1.0 if (factors is not None and perObjectFactors) else 0.0
         f1, f2 = factors if factors is not None else (1.0, 1.0)
         objs.append([table.amp, table.sign, f1, f2, float(pid), useF, 0.0, 0.0])
         wins[k, 6] = pid
-    eng = engine.TileEngine.get(shape)
-    ntab = profTabs[0].shape[1]
-    modelMap = eng.paint_catalog(objs, wins, geom if len(geom) > 0 else np.zeros(1), np.array(profTabs), ntab)
+    ntab = len(profTabs[0].r)
+    # radii, profile and slopes of a profile as the painter reads them: made once per profile array and kept on the device
+    # (scaled tables of one model share their arrays, signals.scaledTable)
+    devTabs = []
+    for table in profTabs:
+        hit = _catalogProfDev.get(id(table.prof))
+        if hit is None or hit[0] is not table.prof or hit[1] is not table.r:
+            slope = np.zeros(len(table.r))
+            slope[:-1] = (table.prof[1:] - table.prof[:-1]) / (table.r[1:] - table.r[:-1])
+            if len(_catalogProfDev) >= 256:
+                _catalogProfDev.clear()
+            hit = _catalogProfDev[id(table.prof)] = (table.prof, table.r, engine.to_dev(np.stack([table.r, table.prof, slope])))
+        devTabs.append(hit[2])
+    profsDev = devTabs[0] if len(devTabs) == 1 else engine.torch().stack(devTabs)
+    modelMap = eng.paint_catalog(objs, wins, None, None, ntab, geomDev=geomDev if geomDev is not None else
+                                 engine.to_dev(np.ascontiguousarray(geom if len(geom) > 0 else np.zeros(1), dtype=np.float64)),
+                                 profsDev=profsDev.contiguous())
     if override is not None and obsFreqGHz is not None:
         # convertToDeltaT of the whole map (:1786-1788): float32 * float64 scalar -> a float64 map from here on (numpy >= 2)
         fx = float(signals.fSZ(obsFreqGHz, TCMBAlpha=TCMBAlpha, z=override['redshift']))

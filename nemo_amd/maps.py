@@ -433,15 +433,24 @@ def makeModelImage(shape, wcs, catalog, beamFileName, obsFreqGHz=None, GNFWParam
     from . import signals, catalogs
     if useInferredSZProperties:
         raise NotImplementedError("useInferredSZProperties (nemoMass -I output) is outside the hot path")
-    catalog = catalogs.getCatalogWithinImage(_holeTable(catalog), shape, wcs)
-    SNRKey = 'SNR' if 'SNR' in catalog.keys() else ('fixed_SNR' if 'fixed_SNR' in catalog.keys() else None)
-    if SNRKey is not None and len(catalog) > 0:
-        catalog = catalog[np.asarray(catalog[SNRKey]) > minSNR]
-    if validAreaSection is not None and len(catalog) > 0:
-        x0, x1, y0, y1 = validAreaSection
-        x, y = wcs.wcs2pix(np.asarray(catalog['RADeg'], dtype=np.float64), np.asarray(catalog['decDeg'], dtype=np.float64))
-        x, y = np.atleast_1d(x), np.atleast_1d(y)
-        catalog = catalog[(x >= x0) & (x < x1) & (y >= y0) & (y < y1)]
+    # (the rows that fall on this tile are the same for every frequency map of the tile: kept with the request)
+    given = catalog
+    rkey = ('rows', id(given), tuple(shape), id(wcs), minSNR, None if validAreaSection is None else tuple(validAreaSection))
+    hit = _geomCache.get(rkey) if _geomCache is not None else None
+    if hit is not None and hit[0] is given and hit[1] is wcs:
+        catalog = hit[2]
+    else:
+        catalog = catalogs.getCatalogWithinImage(_holeTable(catalog), shape, wcs)
+        SNRKey = 'SNR' if 'SNR' in catalog.keys() else ('fixed_SNR' if 'fixed_SNR' in catalog.keys() else None)
+        if SNRKey is not None and len(catalog) > 0:
+            catalog = catalog[np.asarray(catalog[SNRKey]) > minSNR]
+        if validAreaSection is not None and len(catalog) > 0:
+            x0, x1, y0, y1 = validAreaSection
+            x, y = wcs.wcs2pix(np.asarray(catalog['RADeg'], dtype=np.float64), np.asarray(catalog['decDeg'], dtype=np.float64))
+            x, y = np.atleast_1d(x), np.atleast_1d(y)
+            catalog = catalog[(x >= x0) & (x < x1) & (y >= y0) & (y < y1)]
+        if _geomCache is not None:
+            _geomCache[rkey] = (given, wcs, catalog)
     if len(catalog) == 0:
         return None
     if cosmoModel is None:

@@ -109,6 +109,7 @@ def ptr(t):
 
 _PINNED_COPY_MAX = 4 << 20
 _radiiDev = {}                # (length, content hash) -> device copy of a radial table's radii (TileEngine._tableDev)
+CHECK_NOISE_TABLES = os.environ.get('NEMO_AMD_CHECK_NOISE_TABLES', '0') == '1'      # debugging: see TileEngine.matched_filter_scales
 SCALE_BATCH = None            # scales per group of nf_matched_filter_scales (None: by tile size, Engine.scale_batch)
 _AXIS_WINDOW = os.environ.get('NEMO_AMD_AXIS_WINDOW', '1') != '0'    # 0: apply_window through the 2-D transforms always
 
@@ -553,11 +554,13 @@ class TileEngine(object):
             return min(int(v), 8)
         return 8 if self.npix <= 2.5e6 else (4 if self.npix <= 5e6 else (2 if self.npix <= 9e6 else 1))
 
-    def matched_filter_scales(self, tile, scales, lanes, noiseKey=None):
+    def matched_filter_scales(self, tile, scales, lanes, noiseKey=None, weights=None):
         """nf_matched_filter_scales: ``tile`` an _lib.MfTile, ``scales`` a ctypes array of _lib.MfScale.  The lanes' workspaces
         are kept by the engine (one set per size) and reused call after call: calls are ordered by the stream they are made
         on.  ``noiseKey`` (hashable, or None) stands for the tile's median weights and noise grid: a lane whose workspace was
-        last used under an equal key keeps its noise block tables (``noiseTablesLanes`` of the tile struct)."""
+        last used under an equal key keeps its noise block tables (``noiseTablesLanes`` of the tile struct).  The key is a
+        promise of the caller's; with NEMO_AMD_CHECK_NOISE_TABLES=1 (debugging: one device sum and a wait per call) the bits of
+        ``weights`` are summed and held beside the key, and kept tables whose weights have changed since raise."""
         t = self.t
         n = len(scales)
         lanes = max(1, min(int(lanes), n, int(self.lib.nf_matched_filter_max_lanes())))
@@ -575,6 +578,12 @@ class TileEngine(object):
         while len(work) < lanes:
             work.append(t.empty(nbytes, dtype=t.uint8, device=self.dev))
             keys.append(None)
+        if CHECK_NOISE_TABLES and noiseKey is not None and weights is not None:
+            bits = weights.contiguous().view(t.int64 if weights.element_size() == 8 else t.int32)
+            noiseKey = (noiseKey, int(bits.sum(dtype=t.int64).item()))
+            for l in range(lanes):
+                if keys[l] is not None and keys[l][0] == noiseKey[0] and keys[l] != noiseKey:
+                    raise NemoFiltError("kept noise block tables are stale: the tile's weights changed under an unchanged noiseKey")
         tile.noiseTablesLanes = sum(1 << l for l in range(min(lanes, 32)) if noiseKey is not None and keys[l] == noiseKey)
         keys[:lanes] = [None] * lanes             # (an error below leaves the lanes' tables in an unknown state)
         ptrs = (ctypes.c_void_p * lanes)(*[w.data_ptr() for w in work[:lanes]])

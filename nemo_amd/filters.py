@@ -701,7 +701,7 @@ class MatchedFilter(MapFilter):
         noiseKey = None
         if first._shared is not None and 'noiseTablesToken' in first._shared:
             noiseKey = (first._shared['noiseTablesToken'], H, W, ncy, ncx, overlap, nb, est)
-        eng.matched_filter_scales(tile, scales, lanes, noiseKey=noiseKey)
+        eng.matched_filter_scales(tile, scales, lanes, noiseKey=noiseKey, weights=medWeights)
         del keep
         _scaleEntryStats['calls'] += 1
         _scaleEntryStats['scales'] += G

@@ -143,3 +143,29 @@ def test_scale_entry_without_the_filter_cube():
                 assert fobj.filt is None
     finally:
         filters.RETURN_DEVICE_ARRAYS = keepDev
+
+
+def test_stale_noise_tables_are_caught_in_debug_mode():
+    """The noise block tables a lane keeps stand for the tile's weights under a host-side token (tileCache).  With
+    engine.CHECK_NOISE_TABLES (NEMO_AMD_CHECK_NOISE_TABLES=1) the weights' bits are summed per call: weights edited in place
+    between two calls under the same token raise instead of reusing tables made for other weights."""
+    mapsL, wcs, truth = helpers.make_tile((160, 200), freqs=(150.0,), fwhm=(1.4,), noise=(20.0,), seed=5, numSources=3, kind='clusters',
+                                          dtype=np.float64, holes=True)
+    base = {'noiseParams': {'method': 'dataMap', 'noiseGridArcmin': 15., 'numNoiseBins': 1}, 'outputUnits': 'yc'}
+    filtersList = [{'label': 's%d' % k, 'class': 'ArnaudModelMatchedFilter', 'params': dict(base, z=z, M500MSun=m)}
+                   for k, (z, m) in enumerate([(0.4, 2e14), (0.2, 4e14)])]
+    keep = (filters._SCALE_ENTRY, filters.RETURN_DEVICE_ARRAYS, engine.CHECK_NOISE_TABLES)
+    filters._SCALE_ENTRY, filters.RETURN_DEVICE_ARRAYS, engine.CHECK_NOISE_TABLES = True, True, True
+    try:
+        tileCache = {}
+        args = dict(diagnosticsDir=None, selFnDir=None, verbose=False, undoPixelWindow=True, tileCache=tileCache, lanes=1)
+        maps = helpers.product_maps(mapsL)
+        filters.filterMapsGroup(maps, filtersList[:1], 'PRIMARY', **args)
+        filters.filterMapsGroup(maps, filtersList[1:], 'PRIMARY', **args)          # same weights, same token: tables kept, no complaint
+        shared = [v for k, v in tileCache.items() if isinstance(k, tuple) and k[0] == 'tile'][0]
+        shared['medWeights'][40:60, 50:90] *= 0.5                                     # edited in place under the same token
+        with pytest.raises(engine.NemoFiltError, match="stale"):
+            filters.filterMapsGroup(maps, filtersList[:1], 'PRIMARY', **args)
+        torch.cuda.synchronize()
+    finally:
+        filters._SCALE_ENTRY, filters.RETURN_DEVICE_ARRAYS, engine.CHECK_NOISE_TABLES = keep

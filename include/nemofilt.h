@@ -291,6 +291,17 @@ int nf_paint_catalog(float* out_d, int H, int W, int nObj, const double* obj_d, 
 int nf_resample_bilinear(const float* in_d, float* out_d, int N, int H, int W, int H2, int W2, const double* yIdx_d,
                          const double* xIdx_d, void* stream);
 
+/* MapDict.loadTile of a frequency map, its weights and its three masks plus the statements of MapDict.preprocess that follow
+ * them (nemo/maps.py:83-175, 232-262) for maps resident in HBM, in one pass: the H x W clip at (y0, x0) of planes of srcH x srcW
+ * pixels; data = map with 0 where weights == 0 (:243); weights (NULL: 1 everywhere, written in wtype); surveyMask zeroed
+ * outside rows ay0..ay1-1 / columns ax0..ax1-1 of the clip (the tile's areaMaskInClipSection, :159-164; ax0 < 0: no such
+ * section), or (weights != 0) when there is no survey mask; pointSourceMask (NULL: 1); flagMask * surveyMask (NULL: 0,
+ * :259-262).  Masks are uint8. */
+int nf_load_tile(int rtype, const void* map_d, int wtype, const void* weights_d, const unsigned char* surveyMask_d,
+                 const unsigned char* psMask_d, const unsigned char* flagMask_d, int srcH, int srcW, int x0, int y0, int H, int W,
+                 int ax0, int ax1, int ay0, int ay1, void* dataOut_d, void* weightsOut_d, unsigned char* surveyOut_d,
+                 unsigned char* psOut_d, unsigned char* flagOut_d, void* stream);
+
 /* Source injection, nemo/maps.py:341-344: out = base + (weights == 0 ? 0 : model), n pixels; base / model float32 or float64
  * (NF_F32 / NF_F64), out_d float32 when both are float32, else float64 (numpy's promotion); weights_d (wType) may be NULL;
  * base_d is not modified (out_d may be base_d when the types agree). */

@@ -572,6 +572,18 @@ int nf_finalize_cached(int vtype, void* filtered, const float* cachedRms, const 
                                snChunkRange, zeroRows, S(stream));
 }
 
+int nf_load_tile(int rtype, const void* map, int wtype, const void* weights, const unsigned char* surveyMask, const unsigned char* psMask,
+                 const unsigned char* flagMask, int srcH, int srcW, int x0, int y0, int H, int W, int ax0, int ax1, int ay0, int ay1,
+                 void* dataOut, void* weightsOut, unsigned char* surveyOut, unsigned char* psOut, unsigned char* flagOut, void* stream) {
+    if (!map || !dataOut || !weightsOut || !surveyOut || !psOut || !flagOut || H < 1 || W < 1 || x0 < 0 || y0 < 0 ||
+        (long long)x0 + W > srcW || (long long)y0 + H > srcH || (rtype != NF_F32 && rtype != NF_F64) || (wtype != NF_F32 && wtype != NF_F64)) {
+        nf_set_error("nf_load_tile: bad arguments (the clip must lie inside the source map)");
+        return NF_ERR_ARG;
+    }
+    return nf::load_tile(rtype, map, wtype, weights, surveyMask, psMask, flagMask, srcW, x0, y0, H, W, ax0, ax1, ay0, ay1, dataOut, weightsOut,
+                         surveyOut, psOut, flagOut, S(stream));
+}
+
 int nf_inject_model(int baseType, const void* base, int modelType, const void* model, int wType, const void* weights, void* out,
                     long long n, void* stream) {
     if (!base || !model || !out || n < 1 || (baseType != NF_F32 && baseType != NF_F64) || (modelType != NF_F32 && modelType != NF_F64) ||

@@ -89,6 +89,9 @@ int disc_apply(int rtype, void* data, const void* bck, unsigned char* surveyMask
 int paint_catalog(float* out, int H, int W, int nObj, const double* obj, const int* win, const double* geom, const double* prof,
                   int ntab, int accumulate, hipStream_t s);
 int add_model(int rtype, void* data, const float* model, unsigned char* flagMask, long long n, int subtract, hipStream_t s);
+int load_tile(int rtype, const void* map, int wtype, const void* weights, const unsigned char* survey, const unsigned char* ps,
+              const unsigned char* flag, long long pitch, int x0, int y0, int H, int W, int ax0, int ax1, int ay0, int ay1, void* dataOut,
+              void* wOut, unsigned char* surveyOut, unsigned char* psOut, unsigned char* flagOut, hipStream_t s);
 int inject_model(int baseType, const void* base, int modelType, const void* model, int wType, const void* weights, void* out, long long n,
                  hipStream_t s);
 int finalize_cached(int vtype, void* filtered, const float* rms, const unsigned char* surveyMask, const unsigned char* psMask,

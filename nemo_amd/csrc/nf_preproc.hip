@@ -298,6 +298,53 @@ int add_model(int rtype, void* data, const float* model, unsigned char* flagMask
 }
 
 // ---------------------------------------------------------------------------------------------------
+// MapDict.loadTile of the map, its weights and its three masks, and the statements of MapDict.preprocess that follow them
+// (nemo/maps.py:83-175, 232-262), for maps that are resident in HBM - one pass instead of a dozen small ones per frequency
+// map and tile: the clip, data[weights == 0] = 0, the survey mask zeroed outside the tile's own area, flagMask * surveyMask.
+template <typename T, typename WT>
+__global__ void __launch_bounds__(256) k_load_tile(const T* __restrict__ map, const WT* __restrict__ weights,
+                                                   const unsigned char* __restrict__ survey, const unsigned char* __restrict__ ps,
+                                                   const unsigned char* __restrict__ flag, long long pitch, int x0, int y0, int H, int W,
+                                                   int ax0, int ax1, int ay0, int ay1, T* __restrict__ dataOut, WT* __restrict__ wOut,
+                                                   unsigned char* __restrict__ surveyOut, unsigned char* __restrict__ psOut,
+                                                   unsigned char* __restrict__ flagOut) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    const long long src = (long long)(y0 + y) * pitch + (x0 + x), dst = (long long)y * W + x;
+    const WT w = weights != nullptr ? weights[src] : (WT)1;
+    T v = map[src];
+    if (w == (WT)0) v = (T)0;                                   // :243
+    dataOut[dst] = v;
+    wOut[dst] = w;
+    unsigned char sm;
+    if (survey != nullptr) {
+        sm = survey[src];
+        if (ax0 >= 0 && (y < ay0 || y >= ay1 || x < ax0 || x >= ax1)) sm = 0;      // :159-164 (areaMaskInClipSection)
+    } else {
+        sm = w != (WT)0 ? 1 : 0;
+    }
+    surveyOut[dst] = sm;
+    psOut[dst] = ps != nullptr ? ps[src] : (unsigned char)1;
+    flagOut[dst] = flag != nullptr ? (unsigned char)(flag[src] * sm) : (unsigned char)0;      // :259-262
+}
+
+int load_tile(int rtype, const void* map, int wtype, const void* weights, const unsigned char* survey, const unsigned char* ps,
+              const unsigned char* flag, long long pitch, int x0, int y0, int H, int W, int ax0, int ax1, int ay0, int ay1, void* dataOut,
+              void* wOut, unsigned char* surveyOut, unsigned char* psOut, unsigned char* flagOut, hipStream_t s) {
+    dim3 g((W + 255) / 256, H), b(256);
+#define NF_LT(T, WT)                                                                                                              \
+    hipLaunchKernelGGL((k_load_tile<T, WT>), g, b, 0, s, (const T*)map, (const WT*)weights, survey, ps, flag, pitch, x0, y0, H, W, ax0, \
+                       ax1, ay0, ay1, (T*)dataOut, (WT*)wOut, surveyOut, psOut, flagOut)
+    if (rtype == NF_F64 && wtype == NF_F64) NF_LT(double, double);
+    else if (rtype == NF_F64) NF_LT(double, float);
+    else if (wtype == NF_F64) NF_LT(float, double);
+    else NF_LT(float, float);
+#undef NF_LT
+    NF_CHECK_LAUNCH("k_load_tile");
+    return NF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Source injection (nemo/maps.py:341-344): modelMap[weights == 0] = 0; data = data + modelMap - with numpy's promotion
 // (float32 + float32 stays float32; a float64 operand makes the sum float64).  `base` is left as it is: an injection run
 // paints thousands of catalogues into the same preprocessed tile.

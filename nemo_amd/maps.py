@@ -28,6 +28,9 @@ _UNSUPPORTED_KEYS = ['CMBSimSeed', 'applyBeamConvolution', 'smoothKernel', 'exte
 _DEVICE_KEYS = ['injectSources', 'maskPointSourcesFromCatalog', 'subtractModelFromCatalog', 'maskAndFillFromCatalog']
 
 
+_FUSED_LOAD = os.environ.get('NEMO_AMD_FUSED_LOAD', '1') != '0'      # 0: MapDict.preprocess loads a tile statement by statement
+
+
 def _is_tensor(x):
     return hasattr(x, 'is_cuda')
 
@@ -84,23 +87,8 @@ class MapDict(dict):
             return data, wcs
         return data
 
-    def preprocess(self, tileName='PRIMARY', diagnosticsDir=None):
-        """nemo/maps.py:178-480, the steps that apply to plain (map, weights, masks) inputs."""
-        for k in _UNSUPPORTED_KEYS:
-            if k in self and self[k] not in (None, False):
-                raise NotImplementedError("MapDict key '%s' (nemo/maps.py:252-262,294-323,346-379) is not part of this build" % (k))
-        onDevice = any(k in self and self[k] is not None for k in _DEVICE_KEYS)
-        # An injection run preprocesses the same tile thousands of times with nothing changed but the catalogue to paint in
-        # (maps.sourceInjectionTest): what comes before the catalogue steps is kept in HBM, per tile, in the dictionary the
-        # run hung on its maps ('_preprocCache'), and is never written to afterwards.
-        cache = self.get('_preprocCache', None) if onDevice else None
-        ckey = ('tile', tileName, self.get('label', None), self.get('obsFreqGHz', None))
-        if cache is not None and ckey in cache:
-            data, weights, wcs, surveyMask, psMask, flagMask = cache[ckey]
-            data, surveyMask, psMask, flagMask = self._catalogueSteps(data, weights, wcs, surveyMask, psMask, flagMask, tileName,
-                                                                      sharedInputs=True)
-            self._setPreprocessed(data, weights, wcs, surveyMask, psMask, flagMask, tileName)
-            return
+    def _loadTileStatements(self, tileName, onDevice):
+        """The map, its weights and its masks for ``tileName``, statement by statement (nemo/maps.py:232-262)."""
         data, wcs = self.loadTile('mapFileName', tileName, returnWCS=True)
         if onDevice:
             data = engine.to_dev(data)
@@ -138,6 +126,78 @@ class MapDict(dict):
         else:
             flagMask = np.zeros(tuple(data.shape), dtype=np.uint8) if not _is_tensor(data) else \
                 engine.torch().zeros(tuple(data.shape), dtype=engine.torch().uint8, device=data.device)
+        return data, weights, wcs, surveyMask, psMask, flagMask
+
+    def _loadTileFused(self, tileName):
+        """_loadTileStatements in ONE pass (nf_load_tile) when the map, its weights and its masks are device tensors of the
+        plain kinds (2-D float32 / float64 planes, uint8 masks, no calibration factor); None otherwise."""
+        if 'calibFactor' in self.keys():
+            return None
+        t = engine.torch()
+        src = self.get('mapData')
+        if not (_is_tensor(src) and src.is_cuda and src.ndim == 2 and src.dtype in (t.float32, t.float64) and src.is_contiguous()):
+            return None
+        w = self.get('weightsData')
+        if w is None and self.get('weightsFileName') is not None:
+            return None
+        if w is not None and not (_is_tensor(w) and w.is_cuda and tuple(w.shape) == tuple(src.shape) and w.is_contiguous() and
+                                  w.dtype in (t.float32, t.float64)):
+            return None
+        masks = []
+        for k in ('surveyMask', 'pointSourceMask', 'flagMask'):
+            m = self.get(k)
+            if m is not None and not (_is_tensor(m) and m.is_cuda and m.dtype == t.uint8 and tuple(m.shape) == tuple(src.shape) and
+                                      m.is_contiguous()):
+                return None
+            masks.append(m)
+        srcH, srcW = src.shape
+        x0, x1, y0, y1 = 0, srcW, 0, srcH
+        area = (-1, -1, -1, -1)
+        wcs = self['wcs']
+        if self.tileCoordsDict is not None and tileName in self.tileCoordsDict:
+            x0, x1, y0, y1 = [int(v) for v in self.tileCoordsDict[tileName]['clippedSection']]
+            if x0 < 0 or y0 < 0 or x1 > srcW or y1 > srcH:
+                return None              # (a section beyond the map: slicing has its own rules for that)
+            area = tuple(int(v) for v in self.tileCoordsDict[tileName]['areaMaskInClipSection'])
+            wcs = self.tileCoordsDict[tileName].get('wcs', wcs)
+        H, W = y1 - y0, x1 - x0
+        if H < 1 or W < 1 or min(area) < 0 and area != (-1, -1, -1, -1):
+            return None
+        dev = src.device
+        data = t.empty((H, W), dtype=src.dtype, device=dev)
+        weights = t.empty((H, W), dtype=w.dtype if w is not None else src.dtype, device=dev)
+        surveyMask, psMask, flagMask = (t.empty((H, W), dtype=t.uint8, device=dev) for _ in range(3))
+        eng = engine
+        # areaMaskInClipSection = (minX, maxX, minY, maxY): rows outside minY..maxY-1 and columns outside minX..maxX-1 are zeroed
+        ax0, ax1, ay0, ay1 = area
+        eng.check(eng._lib.load().nf_load_tile(eng.prec_of(src), eng.ptr(src), eng.prec_of(weights), eng.ptr(w), eng.ptr(masks[0]),
+                                               eng.ptr(masks[1]), eng.ptr(masks[2]), srcH, srcW, x0, y0, H, W, ax0, ax1, ay0, ay1,
+                                               eng.ptr(data), eng.ptr(weights), eng.ptr(surveyMask), eng.ptr(psMask), eng.ptr(flagMask),
+                                               eng.stream_ptr()), "nf_load_tile")
+        return data, weights, wcs, surveyMask, psMask, flagMask
+
+    def preprocess(self, tileName='PRIMARY', diagnosticsDir=None):
+        """nemo/maps.py:178-480, the steps that apply to plain (map, weights, masks) inputs."""
+        for k in _UNSUPPORTED_KEYS:
+            if k in self and self[k] not in (None, False):
+                raise NotImplementedError("MapDict key '%s' (nemo/maps.py:252-262,294-323,346-379) is not part of this build" % (k))
+        onDevice = any(k in self and self[k] is not None for k in _DEVICE_KEYS)
+        # An injection run preprocesses the same tile thousands of times with nothing changed but the catalogue to paint in
+        # (maps.sourceInjectionTest): what comes before the catalogue steps is kept in HBM, per tile, in the dictionary the
+        # run hung on its maps ('_preprocCache'), and is never written to afterwards.
+        cache = self.get('_preprocCache', None) if onDevice else None
+        ckey = ('tile', tileName, self.get('label', None), self.get('obsFreqGHz', None))
+        if cache is not None and ckey in cache:
+            data, weights, wcs, surveyMask, psMask, flagMask = cache[ckey]
+            data, surveyMask, psMask, flagMask = self._catalogueSteps(data, weights, wcs, surveyMask, psMask, flagMask, tileName,
+                                                                      sharedInputs=True)
+            self._setPreprocessed(data, weights, wcs, surveyMask, psMask, flagMask, tileName)
+            return
+        fused = self._loadTileFused(tileName) if _FUSED_LOAD else None
+        if fused is not None:
+            data, weights, wcs, surveyMask, psMask, flagMask = fused
+        else:
+            data, weights, wcs, surveyMask, psMask, flagMask = self._loadTileStatements(tileName, onDevice)
         if self.get('RADecSection') is not None:
             RAMin, RAMax, decMin, decMax = self['RADecSection']
             x0, y0 = wcs.wcs2pix(RAMax, decMin)

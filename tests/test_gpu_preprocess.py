@@ -233,3 +233,49 @@ def test_subtract_model_and_inject_sources(dtype):
     gfm = md['flagMask'].cpu().numpy()
     assert fm.sum() > 100
     assert (gfm != fm).sum() <= 4            # model > 1 uK decided within the FFT's rounding of the threshold
+
+
+@pytest.mark.parametrize("dtype,wdtype", [(np.float64, np.float64), (np.float32, np.float32), (np.float64, np.float32)])
+def test_fused_tile_load_equals_statements(dtype, wdtype):
+    """MapDict.preprocess through nf_load_tile (one pass: clip, data[weights == 0] = 0, survey mask zeroed outside the tile's own
+    area, flagMask * surveyMask) against the statement-by-statement path, bit for bit: with every mask given, with none, with
+    a tile section and without, weights given or absent."""
+    torch = engine.torch()
+    rng = np.random.default_rng(3)
+    Hs, Ws = 150, 260
+    m = rng.standard_normal((Hs, Ws)).astype(dtype)
+    w = rng.random((Hs, Ws)).astype(wdtype)
+    w[rng.random((Hs, Ws)) < 0.1] = 0
+    sm = (rng.random((Hs, Ws)) < 0.9).astype(np.uint8)
+    ps = (rng.random((Hs, Ws)) < 0.95).astype(np.uint8)
+    fl = (rng.random((Hs, Ws)) < 0.2).astype(np.uint8) * rng.integers(1, 200, (Hs, Ws)).astype(np.uint8)
+    wcs = None
+    tiles = {'T0': {'clippedSection': [17, 201, 9, 131], 'areaMaskInClipSection': [20, 150, 11, 100]}}
+    for given in (('w', 'sm', 'ps', 'fl'), (), ('w',), ('sm', 'fl')):
+        for tcd, tileName in ((tiles, 'T0'), (None, 'PRIMARY')):
+            d = {'mapData': torch.as_tensor(m, device='cuda'), 'wcs': wcs, 'obsFreqGHz': 150.0, 'units': 'uK', 'label': 'x'}
+            if 'w' in given:
+                d['weightsData'] = torch.as_tensor(w, device='cuda')
+            if 'sm' in given:
+                d['surveyMask'] = torch.as_tensor(sm, device='cuda')
+            if 'ps' in given:
+                d['pointSourceMask'] = torch.as_tensor(ps, device='cuda')
+            if 'fl' in given:
+                d['flagMask'] = torch.as_tensor(fl, device='cuda')
+            out = {}
+            keep = pmaps._FUSED_LOAD
+            try:
+                for mode in (True, False):
+                    pmaps._FUSED_LOAD = mode
+                    md = pmaps.MapDict(dict(d), tileCoordsDict=tcd)
+                    md.preprocess(tileName=tileName)
+                    out[mode] = {k: md[k] for k in ('data', 'weights', 'surveyMask', 'pointSourceMask', 'flagMask')}
+            finally:
+                pmaps._FUSED_LOAD = keep
+            for k in out[True]:
+                a, b = out[True][k], out[False][k]
+                assert tuple(a.shape) == tuple(b.shape), (given, tileName, k)
+                assert a.dtype == b.dtype, (given, tileName, k, a.dtype, b.dtype)
+                assert torch.equal(a, b), (given, tileName, k)
+            # the sources are left as they were
+            assert np.array_equal(d['mapData'].cpu().numpy(), m)

@@ -504,7 +504,10 @@ class TileEngine(object):
         g64 = tuple(np.ascontiguousarray(g, dtype=np.float64) for g in geom)
         key = hash(b"".join(g.tobytes() for g in g64))
         if key not in self._geom:
-            self._geom = {key: tuple(to_dev(g) for g in g64)}
+            # one upload for the three tables (views of it)
+            packed = to_dev(np.concatenate(g64))
+            offs = np.concatenate([[0], np.cumsum([len(g) for g in g64])])
+            self._geom = {key: tuple(packed[int(offs[i]):int(offs[i + 1])] for i in range(len(g64)))}
         self._geomLast = (geom, self._geom[key])
         return self._geom[key]
 

@@ -443,6 +443,21 @@ def main():
                                "note": "per-entry-point table from one untimed survey step after the warm-up, run one scale at a time "
                                        "on one stream, detection included (all entry points record events there; in the timed region only the dominant "
                                        "one does); hbm_frac_wall = algorithmic GB per step / timed wall per step / peak"}
+            # SURVEY.md 8(d)'s own accounting of the step (full complex transforms, every stage fused perfectly): per pixel, once
+            # per tile N(r + 3c) + Nc + N(N+1)/2 * 5r, per scale N(4 + 3c) + N(N+1)/2 * r + Nc + 4N + 2[N(c + 4) + 2c] + r + 4 + 33 +
+            # (8 + 6c) + 12 with r / c the bytes of a real / complex number of the map precision (fp64 N=1: 112 + 345 per scale)
+            r_, c_ = (8.0, 16.0) if args.dtype == 'f64' else (4.0, 8.0)
+            pairs = N * (N + 1) / 2.0
+            once = N * (r_ + 3 * c_) + N * c_ + pairs * 5 * r_
+            perScale = (N * (4 + 3 * c_) + pairs * r_ + N * c_ + 4 * N + 2 * (N * (c_ + 4) + 2 * c_) + r_ + 4 + 33 + (8 + 6 * c_) + 12)
+            surveyGB = shape[0] * shape[1] * T * (once + S * perScale) / 1e9
+            if not inject:
+                out["pipeline"]["survey_8d"] = {"alg_GB_per_step": round(surveyGB, 2),
+                                                "achieved": round(surveyGB / (elapsed / args.steps), 1), "unit": "GB/s",
+                                                "frac": round(surveyGB / (elapsed / args.steps) / HBM_PEAK_GBS, 4),
+                                                "note": "SURVEY.md 8(d)'s accounting (full complex transforms, perfect fusion: %.0f B per pixel "
+                                                        "once + %.0f B per pixel and scale) over the timed wall time; the half-stored "
+                                                        "transforms this build runs move fewer bytes (alg_GB_per_step above)" % (once, perScale)}
             # the quantity the north star sets its target on - the FFT + filter build / apply path - as one fixed block: every
             # transform entry point, the filter build and the two axis filters of the pixel-window undo, from the survey step
             fa = {k: v for k, v in kernels.items() if k.startswith(('fft_', 'axis_filter', 'build_filter', 'apply_filter', 'window_mul',

@@ -167,6 +167,13 @@ def vstack(tables):
             if k not in seen:
                 seen.add(k)
                 keys.append(k)
+    if all(ks == keySets[0] for ks in keySets) and all(t._nameSpec is None or out._nameSpec is not None for t in tables):
+        # the usual case - every table has the same columns (the scales of a run): the column dictionaries directly
+        for k in keys:
+            if k == 'name' and out._nameSpec is not None:
+                continue
+            out._cols[k] = np.concatenate([t._cols[k] for t in tables])
+        return out
     for k in keys:
         if k == 'name' and out._nameSpec is not None:
             continue

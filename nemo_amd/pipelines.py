@@ -326,13 +326,11 @@ def _detectAndMeasure(config, jobs, stream, invertMap, measureFluxes, photFilter
                                                useInterpolator=config.parDict['useInterpolator'],
                                                measureShapes=config.parDict['measureShapes'], invertMap=invertMap,
                                                verbose=verbose)
-        if measureFluxes == True:
+        if measureFluxes == True:                                                  # nemo/pipelines.py:299-311
             photometry.measureFluxesGroup(cats, [job[2] for job in jobs], config.diagnosticsDir, [job[3] for job in jobs],
                                           useInterpolator=config.parDict['useInterpolator'])
-        for catalog, (label, f, filteredMapDict, photFilteredMapDict, ready) in zip(cats, jobs):
-            if measureFluxes == True:
-                pass
-            elif photFilter is not None:
+        elif photFilter is not None:
+            for catalog, (label, f, filteredMapDict, photFilteredMapDict, ready) in zip(cats, jobs):
                 photometry.getSNRValues(catalog, photFilteredMapDict['SNMap'], filteredMapDict['wcs'], prefix='fixed_',
                                         useInterpolator=config.parDict['useInterpolator'], invertMap=invertMap)
         if stream is not None:

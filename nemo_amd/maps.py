@@ -435,6 +435,36 @@ def _modelObjects(catalog, beam, obsFreqGHz, GNFWParams, profile, override, TCMB
     return out
 
 
+def _modelObjectsUniform(catalog, beam, obsFreqGHz, GNFWParams, profile, override, TCMBAlpha, cosmoModel):
+    """_modelObjects for the catalogues whose rows share ONE radial table - an ``override`` model (nemo/maps.py:1752-1758) or point
+    sources (:1833-1840) - without a Python statement per row: (RADeg[], decDeg[], base table, maxSizeDeg, factors, amp[]) with
+    amp[k] the float32-rounded amplitude signals.scaledTable would give row k; None for any other catalogue."""
+    from . import signals
+    keys = catalog.keys()
+    RAs, decs = np.asarray(catalog['RADeg'], dtype=np.float64), np.asarray(catalog['decDeg'], dtype=np.float64)
+    if 'y_c' in keys or 'true_y_c' in keys:
+        if override is None:
+            return None
+        kind = {'A10': 'arnaud', 'B12': 'battaglia'}.get(profile)
+        if kind is None:
+            raise Exception("Didn't understand profile - should be A10 or B12.")
+        gp = 'default' if GNFWParams in (None, 'default') else GNFWParams
+        z, M500 = override['redshift'], override['M500']
+        theta500Arcmin = signals.calcTheta500Arcmin(z, M500, cosmoModel)
+        maxSizeDeg = 5 * (theta500Arcmin / 60)
+        base = signals.clusterModelTable(kind, beam, z, M500, gp, 1.0, maxSizeDeg, baseOnly=True)
+        factors = None
+        if obsFreqGHz is not None:
+            factors = (float(signals.fSZ(obsFreqGHz, TCMBAlpha=TCMBAlpha, z=z)), signals.TCMB * 1e6)
+        amplitudes = np.asarray(catalog['y_c'], dtype=np.float64) * 1e-4
+    else:
+        base = signals.templateTables('beam', beam, {}, amplitude=1.0)
+        maxSizeDeg, factors = 1.0, None
+        amplitudes = np.asarray(catalog['deltaT_c'], dtype=np.float64)
+    amps = (base.ampExact * amplitudes).astype(np.float32).astype(np.float64)          # signals.scaledTable, row by row
+    return RAs, decs, base, maxSizeDeg, factors, amps
+
+
 def modelWindow(shape, wcs, RADeg, decDeg, maxSizeDeg):
     """Pixel window of the box of +- maxSizeDeg around an object that signals._paintSignalMap clips before painting into an
     existing map (nemo/signals.py:675-680; the rounding rule of the clip is this build's, as for RADecSection)."""
@@ -516,15 +546,22 @@ def makeModelImage(shape, wcs, catalog, beamFileName, obsFreqGHz=None, GNFWParam
     if cosmoModel is None:
         cosmoModel = signals.fiducialCosmoModel
     beam = signals._asBeam(beamFileName)
-    objects = _modelObjects(catalog, beam, obsFreqGHz, GNFWParams, profile, override, TCMBAlpha, maxSizeDegMultiplier, cosmoModel)
     perObjectFactors = override is None          # the override branch converts the summed map instead (:1786-1788)
+    uniform = _modelObjectsUniform(catalog, beam, obsFreqGHz, GNFWParams, profile, override, TCMBAlpha, cosmoModel)
+    if uniform is not None:
+        RAs, decs, base, maxSizeDeg, factors, amps = uniform
+        objects = None
+        nObj = len(RAs)
+        sizes = np.full(nObj, float(maxSizeDeg))
+    else:
+        objects = _modelObjects(catalog, beam, obsFreqGHz, GNFWParams, profile, override, TCMBAlpha, maxSizeDegMultiplier, cosmoModel)
+        nObj = len(objects)
+        RAs = np.array([o[0] for o in objects], dtype=np.float64)
+        decs = np.array([o[1] for o in objects], dtype=np.float64)
+        sizes = np.array([o[3] for o in objects], dtype=np.float64)
     # windows and haversine tables of ALL objects in a few numpy statements (modelWindow / signals.paintGeometry element for
     # element); the same catalogue on the same tile - the frequency maps of a tile, pass after pass of a mask catalogue - is
     # served from the cache
-    nObj = len(objects)
-    RAs = np.array([o[0] for o in objects], dtype=np.float64)
-    decs = np.array([o[1] for o in objects], dtype=np.float64)
-    sizes = np.array([o[3] for o in objects], dtype=np.float64)
     gkey = ('many', tuple(shape), wcs._crval1, wcs._crpix1, wcs._crpix2, wcs._cdelt1, wcs._cdelt2, RAs.tobytes(), decs.tobytes(),
             sizes.tobytes())
     held = _geomCache.get(gkey) if _geomCache is not None else None
@@ -538,20 +575,28 @@ def makeModelImage(shape, wcs, catalog, beamFileName, obsFreqGHz=None, GNFWParam
         # (the device copy of the windows' tables stays with them)
         held = _geomCache[gkey] = held + (engine.to_dev(np.ascontiguousarray(geom if len(geom) > 0 else np.zeros(1), dtype=np.float64)),)
     geomDev = held[4] if len(held) > 4 else None
-    objs, profTabs, profIndex = [], [], {}
     wins = np.zeros((nObj, 8), dtype=np.int64)
     wins[:, 0:4] = winArr
     wins[:, 4] = offA
     wins[:, 5] = offC
-    for k, (RADeg, decDeg, table, maxSizeDeg, factors) in enumerate(objects):
-        pid = profIndex.get(id(table.prof))
-        if pid is None:
-            pid = profIndex[id(table.prof)] = len(profTabs)
-            profTabs.append(table)
+    if uniform is not None:
+        # one table for every row: the records in a few array statements
         useF = 1.0 if (factors is not None and perObjectFactors) else 0.0
         f1, f2 = factors if factors is not None else (1.0, 1.0)
-        objs.append([table.amp, table.sign, f1, f2, float(pid), useF, 0.0, 0.0])
-        wins[k, 6] = pid
+        objs = np.zeros((nObj, 8))
+        objs[:, 0], objs[:, 1], objs[:, 2], objs[:, 3], objs[:, 5] = amps, base.sign, f1, f2, useF
+        profTabs = [base]
+    else:
+        objs, profTabs, profIndex = [], [], {}
+        for k, (RADeg, decDeg, table, maxSizeDeg, factors) in enumerate(objects):
+            pid = profIndex.get(id(table.prof))
+            if pid is None:
+                pid = profIndex[id(table.prof)] = len(profTabs)
+                profTabs.append(table)
+            useF = 1.0 if (factors is not None and perObjectFactors) else 0.0
+            f1, f2 = factors if factors is not None else (1.0, 1.0)
+            objs.append([table.amp, table.sign, f1, f2, float(pid), useF, 0.0, 0.0])
+            wins[k, 6] = pid
     ntab = len(profTabs[0].r)
     # radii, profile and slopes of a profile as the painter reads them: made once per profile array and kept on the device
     # (scaled tables of one model share their arrays, signals.scaledTable)

@@ -580,6 +580,10 @@ int nf_load_tile(int rtype, const void* map, int wtype, const void* weights, con
         nf_set_error("nf_load_tile: bad arguments (the clip must lie inside the source map)");
         return NF_ERR_ARG;
     }
+    if (H > 65535) {
+        nf_set_error("nf_load_tile: more than 65535 rows in one tile (one workgroup row per tile row)");
+        return NF_ERR_SIZE;
+    }
     return nf::load_tile(rtype, map, wtype, weights, surveyMask, psMask, flagMask, srcW, x0, y0, H, W, ax0, ax1, ay0, ay1, dataOut, weightsOut,
                          surveyOut, psOut, flagOut, S(stream));
 }

@@ -231,6 +231,7 @@ __global__ void __launch_bounds__(256) k_relabel(DetBatch b, long long n) {
                 if (p < n) labels[p] = 0;
             }
         }
+        __syncthreads();      // (every wavefront has read the flag before thread 0 rewrites it)
         if (dirty != nullptr && threadIdx.x == 0) dirty[blockIdx.x] = 0;
         return;
     }
@@ -253,7 +254,7 @@ long long label_chunk_flags_offset(int H, int W) {
 
 // the five labelling passes for the nb maps of `b` (one launch each); clearWords > 0: b.stats[m] is cleared on the way
 static int label_batch(int vtype, const DetBatch& b, int nb, double threshold, int negate, int H, int W, long long clearWords,
-                       hipStream_t s) {
+                       hipStream_t s, bool relabel = true) {
     const long long n = (long long)H * W;
     if (n >= 2147483647LL) {
         nf_set_error("label_components: map too large for 32-bit pixel indices");
@@ -267,7 +268,7 @@ static int label_batch(int vtype, const DetBatch& b, int nb, double threshold, i
     hipLaunchKernelGGL(k_ccl_merge, g, t, 0, s, b, H, W);
     hipLaunchKernelGGL(k_ccl_flatten_count, g, t, 0, s, b, n);
     hipLaunchKernelGGL(k_number_roots, g, t, 0, s, b, n);
-    hipLaunchKernelGGL(k_relabel, g, t, 0, s, b, n);
+    if (relabel) hipLaunchKernelGGL(k_relabel, g, t, 0, s, b, n);      // (else: k_object_sums<.., true> does it on its way)
     NF_CHECK_LAUNCH("label_components");
     return NF_OK;
 }
@@ -328,14 +329,34 @@ __device__ __forceinline__ unsigned long long ordered_key(double v) {
 // One workgroup per 1024-pixel chunk (chunkFG, from the labelling pass, when the caller has it: a chunk without foreground
 // costs one flag); a thread takes 4 consecutive pixels and flushes one entry per run of equal labels within a row.
 // The record table of a map: 6 doubles per label, then the 9 integer limbs, the maximum key and the argmax of every label.
-template <typename VT>
+// RELABEL (label_and_stats): the labelling's last pass rides along - a pixel's label is its root's (k_number_roots wrote the
+// roots' labels in the launch before; roots are not rewritten here), written to `labels` and summed in the same visit, the
+// kept-labels bookkeeping of k_relabel included.  Same labels, same records; one launch less in the chain.
+template <typename VT, bool RELABEL>
 __global__ void __launch_bounds__(256) k_object_sums(DetBatch b, int negate, int H, int W, int maxId) {
     const int* __restrict__ chunkFG = b.chunkFG[blockIdx.y];
-    if (chunkFG != nullptr && !chunkFG[blockIdx.x]) return;
     const long long n = (long long)H * W, p0 = (long long)blockIdx.x * NF_SCAN_CHUNK + threadIdx.x * 4;
+    int* __restrict__ labels = b.labels[blockIdx.y];
+    if (RELABEL) {
+        int* __restrict__ dirty = b.dirty[blockIdx.y];
+        if (!chunkFG[blockIdx.x]) {
+            if (dirty == nullptr || dirty[blockIdx.x]) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (p0 + j < n) labels[p0 + j] = 0;
+            }
+            // (every thread has read the flag before thread 0 rewrites it)
+            __syncthreads();
+            if (dirty != nullptr && threadIdx.x == 0) dirty[blockIdx.x] = 0;
+            return;
+        }
+        if (dirty != nullptr && threadIdx.x == 0) dirty[blockIdx.x] = 1;
+    } else if (chunkFG != nullptr && !chunkFG[blockIdx.x]) {
+        return;
+    }
     if (p0 >= n) return;
     const VT* __restrict__ sn = (const VT*)b.sn[blockIdx.y];
-    const int* __restrict__ labels = b.labels[blockIdx.y];
+    const int* __restrict__ parent = b.work[blockIdx.y];
     double* __restrict__ stats = b.stats[blockIdx.y];
     unsigned long long* __restrict__ limbs = (unsigned long long*)(stats + ((size_t)maxId + 1) * NF_STAT_STRIDE);
     unsigned long long* __restrict__ maxKey = limbs + ((size_t)maxId + 1) * NF_LIMB_WORDS;
@@ -344,7 +365,14 @@ __global__ void __launch_bounds__(256) k_object_sums(DetBatch b, int negate, int
     double cnt = 0, mx = 0;
     unsigned __int128 sv = 0, svy = 0, svx = 0;
     for (int j = 0; j < 4 && p0 + j < n; ++j) {
-        int id = labels[p0 + j];
+        int id;
+        if (RELABEL) {
+            const int r = parent[p0 + j];
+            id = r < 0 ? 0 : labels[r];
+            if (r != (int)(p0 + j)) labels[p0 + j] = id;
+        } else {
+            id = labels[p0 + j];
+        }
         if (id > maxId) id = 0;        // (a record table with room for maxId labels: the caller repeats with more room)
         if (id != cur) {
             if (cur > 0) {
@@ -427,14 +455,20 @@ __global__ void k_stats_finish(DetBatch b, int numObjects) {
 }
 
 // the sums of the nb maps of `b` (one launch per pass); b.stats[m] holds (numObjects+1) * 17 doubles
-static int stats_batch(int vtype, const DetBatch& b, int nb, int negate, int H, int W, int numObjects, hipStream_t s) {
+static int stats_batch(int vtype, const DetBatch& b, int nb, int negate, int H, int W, int numObjects, hipStream_t s, bool relabel = false) {
     const long long n = (long long)H * W;
     dim3 g(nf_div_up(n, NF_SCAN_CHUNK), nb), t(256);
     if (vtype == NF_F64) {
-        hipLaunchKernelGGL(k_object_sums<double>, g, t, 0, s, b, negate, H, W, numObjects);
+        if (relabel)
+            hipLaunchKernelGGL((k_object_sums<double, true>), g, t, 0, s, b, negate, H, W, numObjects);
+        else
+            hipLaunchKernelGGL((k_object_sums<double, false>), g, t, 0, s, b, negate, H, W, numObjects);
         hipLaunchKernelGGL(k_object_argmax<double>, g, t, 0, s, b, negate, n, numObjects);
     } else {
-        hipLaunchKernelGGL(k_object_sums<float>, g, t, 0, s, b, negate, H, W, numObjects);
+        if (relabel)
+            hipLaunchKernelGGL((k_object_sums<float, true>), g, t, 0, s, b, negate, H, W, numObjects);
+        else
+            hipLaunchKernelGGL((k_object_sums<float, false>), g, t, 0, s, b, negate, H, W, numObjects);
         hipLaunchKernelGGL(k_object_argmax<float>, g, t, 0, s, b, negate, n, numObjects);
     }
     hipLaunchKernelGGL(k_stats_finish, dim3(grid_for((long long)numObjects + 1, 256), nb), dim3(256), 0, s, b, numObjects);
@@ -479,9 +513,9 @@ int label_and_stats_batch(int vtype, int nb, const void* const* sn, double thres
             b.count[i] = work[m0 + i] + n + nblocks;
             b.chunkFG[i] = work[m0 + i] + n + nblocks + 1;
         }
-        int rc = label_batch(vtype, b, c, threshold, negate, H, W, clearWords, s);
+        int rc = label_batch(vtype, b, c, threshold, negate, H, W, clearWords, s, false);
         if (rc != NF_OK) return rc;
-        rc = stats_batch(vtype, b, c, negate, H, W, maxObjects, s);
+        rc = stats_batch(vtype, b, c, negate, H, W, maxObjects, s, true);
         if (rc != NF_OK) return rc;
     }
     return NF_OK;

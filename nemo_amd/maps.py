@@ -161,7 +161,7 @@ class MapDict(dict):
             area = tuple(int(v) for v in self.tileCoordsDict[tileName]['areaMaskInClipSection'])
             wcs = self.tileCoordsDict[tileName].get('wcs', wcs)
         H, W = y1 - y0, x1 - x0
-        if H < 1 or W < 1 or min(area) < 0 and area != (-1, -1, -1, -1):
+        if H < 1 or W < 1 or H > 65535 or min(area) < 0 and area != (-1, -1, -1, -1):
             return None
         dev = src.device
         data = t.empty((H, W), dtype=src.dtype, device=dev)

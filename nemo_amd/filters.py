@@ -289,7 +289,8 @@ class MapFilter(object):
         self._geom = None
         self._dFilt = None
         if shared is not None:
-            shared[('initSnapshot', type(self))] = dict(self.__dict__)
+            # (without the references back to the tile cache: a cycle would keep the tile's tensors until the cyclic collector runs)
+            shared[('initSnapshot', type(self))] = {k: v for k, v in self.__dict__.items() if k not in ('_shared', '_tileCache')}
 
     # -- geometry ---------------------------------------------------------------------------------------------
     def makeRadiansMap(self):

@@ -1,0 +1,20 @@
+import sys, os, gc
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, bench
+from nemo_amd import pipelines, _lib
+pipelines.initDistributed(); torch.cuda.set_device(0); _lib.load()
+mode = sys.argv[1]
+if mode == 'c3':
+    mapsList, wcs, tileDefs = bench.make_workload_tiled((840, 1440), 8, 2, 1234, 'f64')
+    config = bench.make_config(mapsList, 16, tileDefs)
+else:
+    mapsList, wcs, truth = bench.make_workload((4096, 4096), 1234, 'f64')
+    config = bench.make_config(mapsList, 15)
+config.rank, config.size = 0, 1
+for k in range(41):
+    bench.run_step(config)
+    if k in (2, 10, 20, 40):
+        torch.cuda.synchronize()
+        a = torch.cuda.memory_allocated() / 1e9
+        n = gc.collect()
+        print(mode, 'step', k, 'reserved GB %.2f allocated GB %.2f, after gc.collect (%d objects) %.2f' % (torch.cuda.memory_reserved() / 1e9, a, n, torch.cuda.memory_allocated() / 1e9), flush=True)

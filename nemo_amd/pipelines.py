@@ -463,7 +463,10 @@ def _filterMapsAndMakeCatalogs(config, rootOutDir=None, useCachedFilters=False, 
             for f, filteredMapDict, filterObj, lastOfGroup in filteredScales():
                 label = f['label'] + "#" + tileName
                 catalogDict[label] = {}
-                if f['label'] == photFilter and filterObj is not None:
+                if f['label'] == photFilter and filterObj is not None and not (useCachedFilters == True and tileName in config.cachedFilters):
+                    # (a pass that took its filter from the kept object keeps that object: replacing it with this pass's - whose
+                    # tile cache refers to the kept one - would chain every pass's tile state to the next, thousands of them in
+                    # an injection run)
                     config.cachedFilters[tileName] = filterObj
                 if f['label'] == photFilter and useCachedRMSMap == False and 'RMSMap' in filteredMapDict:
                     # kept in HBM for later passes with useCachedRMSMap (the reference reloads selFn/RMSMap_<photFilter>.fits,

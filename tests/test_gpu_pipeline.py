@@ -270,7 +270,8 @@ def test_passes_leave_no_device_memory_behind():
     import gc
     mapsL, wcs, truth = helpers.make_tile(SHAPE, freqs=(150.0, 98.0), fwhm=(1.4, 2.1), noise=(12.0, 16.0), seed=3, numSources=5,
                                           kind='clusters')
-    config = _config(helpers.product_maps(mapsL))
+    # (detection on the calling thread: with the worker thread the moment its last buffers go is not the caller's to see)
+    config = _config(helpers.product_maps(mapsL), asyncDetection=False)
     gc.collect()
     gc.disable()
     try:
@@ -280,6 +281,30 @@ def test_passes_leave_no_device_memory_behind():
             del cat
             torch.cuda.synchronize()
             used.append(torch.cuda.memory_allocated())
+        assert used[5] <= used[2] + (1 << 20), used
+    finally:
+        gc.enable()
+
+
+def test_cached_refilter_passes_leave_no_device_memory_behind():
+    """The re-filter mode of an injection run (cached filter + cached noise map) pass after pass: the kept filter object
+    stays the first pass's - a pass's tile state is not chained to the next through config.cachedFilters."""
+    import gc
+    mapsL, wcs, truth = helpers.make_tile(SHAPE, seed=8, numSources=5, kind='clusters')
+    config = _config(helpers.product_maps(mapsL), asyncDetection=False)
+    config.parDict['mapFilters'] = [f for f in config.parDict['mapFilters'] if f['label'] == config.parDict['photFilter']]
+    pipelines.filterMapsAndMakeCatalogs(config, verbose=False)
+    kept = config.cachedFilters['PRIMARY']
+    gc.collect()
+    gc.disable()
+    try:
+        used = []
+        for k in range(6):
+            cat = pipelines.filterMapsAndMakeCatalogs(config, useCachedFilters=True, useCachedRMSMap=True, verbose=False)
+            del cat
+            torch.cuda.synchronize()
+            used.append(torch.cuda.memory_allocated())
+        assert config.cachedFilters['PRIMARY'] is kept
         assert used[5] <= used[2] + (1 << 20), used
     finally:
         gc.enable()

@@ -29,4 +29,5 @@ for k in range(41):
         torch.cuda.synchronize()
         a = torch.cuda.memory_allocated() / 1e9
         n = gc.collect()
-        print(mode, 'step', k, 'reserved GB %.2f allocated GB %.2f, after gc.collect (%d objects) %.2f' % (torch.cuda.memory_reserved() / 1e9, a, n, torch.cuda.memory_allocated() / 1e9), flush=True)
+        import psutil
+        print(mode, 'step', k, 'reserved GB %.2f allocated GB %.2f, after gc.collect (%d objects) %.2f, host RSS GB %.2f' % (torch.cuda.memory_reserved() / 1e9, a, n, torch.cuda.memory_allocated() / 1e9, psutil.Process().memory_info().rss / 1e9), flush=True)

@@ -64,6 +64,9 @@ CASES = [
     ((160, 200), (150.0,), (1.4,), (20.0,), 'beam', 'BeamMatchedFilter', 'uK', np.float32, {}),
     ((200, 240), (150.0,), (1.4,), (20.0,), 'arnaud', 'ArnaudModelMatchedFilter', 'yc', np.float64,
      {'bckSub': True, 'bckSubScaleArcmin': 6.0}),
+    # the tile shape of the two-frequency survey configuration (C3): radix-7 / 5 / 3 columns in 256-thread workgroups
+    ((840, 1440), (150.0, 98.0), (1.4, 2.1), (15.0, 20.0), 'arnaud', 'ArnaudModelMatchedFilter', 'yc', np.float64,
+     {'noiseParams': {'method': 'dataMap', 'noiseGridArcmin': 40., 'numNoiseBins': 1}}),
 ]
 
 

@@ -67,6 +67,9 @@ CASES = [
     # the tile shape of the two-frequency survey configuration (C3): radix-7 / 5 / 3 columns in 256-thread workgroups
     ((840, 1440), (150.0, 98.0), (1.4, 2.1), (15.0, 20.0), 'arnaud', 'ArnaudModelMatchedFilter', 'yc', np.float64,
      {'noiseParams': {'method': 'dataMap', 'noiseGridArcmin': 40., 'numNoiseBins': 1}}),
+    # the tile shape of the DR6-style configuration (C5): three maps, 80' noise cells
+    ((480, 3240), (94.1, 145.3, 225.0), (2.1, 1.4, 1.0), (20.0, 15.0, 40.0), 'arnaud', 'ArnaudModelMatchedFilter', 'yc',
+     np.float64, {'noiseParams': {'method': 'dataMap', 'noiseGridArcmin': 80., 'numNoiseBins': 1}}),
 ]
 
 

@@ -239,11 +239,10 @@ def makeName(RADeg, decDeg, prefix='ACT-CL'):
     return prefix + " J" + _raField(float(RADeg)) + _decField(float(decDeg))
 
 
-def makeNames(RADeg, decDeg, prefix='ACT-CL'):
-    """makeName for arrays: the same string route, written out in one loop (no helper calls per object)."""
+def _makeNamesStrings(RAs, decs, head):
+    """makeName for lists of floats: the reference's string route, written out in one loop (no helper calls per object)."""
     out = []
-    head = prefix + " J"
-    for ra, dec in zip(np.asarray(RADeg, dtype=np.float64).tolist(), np.asarray(decDeg, dtype=np.float64).tolist()):
+    for ra, dec in zip(RAs, decs):
         hours = (ra / 360) * 24
         sh = "%.10f" % (hours)
         mins = float(sh[sh.index("."):]) * 60
@@ -257,6 +256,46 @@ def makeNames(RADeg, decDeg, prefix='ACT-CL'):
         dm = float(s[s.index("."):]) * 60
         sdm = str(dm)
         out.append(head + raPart + sDeg + ("0" + sdm[:1] if dm < 10 else sdm[:2]))
+    return out
+
+
+def makeNames(RADeg, decDeg, prefix='ACT-CL'):
+    """makeName for arrays.  The digits the string route cuts out of its decimal strings are computed as numbers - hours and
+    minutes rounded to ten decimals as "%.10f" rounds them, fields truncated as the slices truncate them - and one format
+    statement per object puts them together; an object whose value lies within 1e-6 of a place where a digit changes (or
+    outside the ordinary ranges: |dec| below 1e-3 deg, minutes below 1e-3, RA outside 0..360) goes through the strings
+    themselves, so every name is the string route's, character for character (tests/test_cpu_boundary.py)."""
+    RA = np.atleast_1d(np.asarray(RADeg, dtype=np.float64))
+    dec = np.atleast_1d(np.asarray(decDeg, dtype=np.float64))
+    head = prefix + " J"
+    n = len(RA)
+    if n < 16:
+        return _makeNamesStrings(RA.tolist(), dec.tolist(), head)
+    with np.errstate(invalid='ignore', over='ignore'):
+        hours = (RA / 360) * 24
+        R = np.rint(hours * 1e10)
+        ok = np.isfinite(R) & (hours >= 0) & (hours < 24)
+        Ri = np.where(ok, R, 0).astype(np.int64)
+        HH = Ri // 10 ** 10
+        mins = ((Ri % 10 ** 10) / 1e10) * 60                  # float(".dddddddddd") * 60
+        t = mins * 10
+        ok &= np.abs(t - np.rint(t)) > 1e-5                   # away from the places where the tenth of a minute changes
+        Mi = np.rint(mins * 1e10).astype(np.int64)
+        MM = Mi // 10 ** 10
+        tenth = (Mi // 10 ** 9) % 10
+        ad = np.abs(dec)
+        ok &= np.isfinite(dec) & (ad > 1e-3) & (ad < 90)
+        D = np.floor(np.where(ok, ad, 0.0))
+        dm = (np.where(ok, ad, 0.0) - D) * 60
+        ok &= (np.abs(dm - np.rint(dm)) > 1e-6) & (dm > 1e-3)
+        DM = np.floor(dm).astype(np.int64)
+        Di = D.astype(np.int64)
+    sign = np.where(dec > 0, '+', '-').tolist()
+    out = [head + "%02d%02d.%d%s%02d%02d" % f for f in zip(HH.tolist(), MM.tolist(), tenth.tolist(), sign, Di.tolist(), DM.tolist())]
+    bad = np.flatnonzero(~ok)
+    if len(bad) > 0:
+        for i, name in zip(bad.tolist(), _makeNamesStrings(RA[bad].tolist(), dec[bad].tolist(), head)):
+            out[i] = name
     return out
 
 

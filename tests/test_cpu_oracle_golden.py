@@ -61,6 +61,36 @@ def test_names_match_reference():
     assert list(t['name']) == [r[2] for r in rows]
 
 
+def test_vector_names_equal_string_route():
+    """catalogs.makeNames computes the digits of a name as numbers and sends every object that lies near a place where a digit
+    changes through the reference's string route: the names of 100 000 random positions and of positions placed on and beside
+    those places (whole hours, tenths of a minute of RA, whole arcminutes and degrees of declination, +-1e-14 .. 1e-5 away)
+    equal makeName's character for character."""
+    from nemo_amd import catalogs
+    rng = np.random.default_rng(1)
+    RA, dec = rng.uniform(0, 360, 100000), rng.uniform(-90, 90, 100000)
+    advRA, advDec = [], []
+    for h in range(24):
+        for m10 in (0, 1, 5, 99, 100, 333, 599):
+            for e in (0, 1e-13, -1e-13, 1e-9, -1e-9, 3e-8, -3e-8, 1e-6, -1e-6):
+                advRA.append(min(max((h + m10 / 600.0) * 15.0 + e, 0.0), 359.9999999))
+    for d in range(-89, 90):
+        for m in (0, 1, 30, 59):
+            for e in (0, 1e-14, -1e-14, 1e-10, -1e-10, 1e-7, -1e-7, 1e-5, -1e-5):
+                advDec.append(d + (1 if d >= 0 else -1) * m / 60.0 + e)
+    advDec += [0.0, 1e-3, -1e-3, 2e-4, -2e-4, 0.5, -0.5, 9.999999, -9.999999, 10.0, -10.0, 89.99999]
+    advDec = [v for v in advDec if v == 0.0 or abs(v) >= 1e-4]         # (below 1e-4 str() has no decimal point: both routes raise)
+    k = max(len(advRA), len(advDec))
+    RA = np.concatenate([RA, np.resize(np.array(advRA), k)])
+    dec = np.concatenate([dec, np.resize(np.array(advDec), k)])
+    got = catalogs.makeNames(RA, dec)
+    assert got == [catalogs.makeName(r, d) for r, d in zip(RA.tolist(), dec.tolist())]
+    with pytest.raises(ValueError):
+        catalogs.makeNames(np.full(20, 10.0), np.full(20, 1e-5))
+    with pytest.raises(ValueError):
+        catalogs.makeName(10.0, 1e-5)
+
+
 def test_gnfw_profile_matches_reference():
     """Line-of-sight GNFW integral (nemo/gnfw.py:142-195): the product follows the reference's algorithm (quad table at
     100 log-spaced impact parameters, cubic interp1d in log-log, power-law ends) and must reproduce the reference's own

@@ -56,6 +56,8 @@ struct LineArgs {
     long long sumStride;     // plane pitch of in / mul for the sum (elements)
     int storeLo, storeHi;    // columns kernel: only the elements (rows) storeLo <= e < storeHi are stored (storeHi == 0: all)
     int lineBase;            // rows kernel: first line of this launch (lines lineBase .. nLines - 1)
+    int rowSwap64;           // rows kernel, pairMode 2: row y of the input plane lies at row ((y & 63) << 6) | (y >> 6) (H = 4096;
+                             //   what the two-pass column transform k_cols2p_* leaves)
     int colPair;             // columns kernel, float32: strides, types and table alignment allow two adjacent columns per thread
     int usePlaneScale;       // halfIn: plane pl of the sum (nSum > 1) / batch entry b (nSum <= 1) is also multiplied by planeScale[pl / b]
     double planeScale[NF_PLANE_SCALES];
@@ -99,6 +101,7 @@ struct Plan2D {
     LinePlan<T> row, col;
     int rowsPerWG, colsPerWG, threadsRow, tbRow, threadsCol;
     int useReal;    // real-data fast paths enabled (NF_FFT_REAL=0 switches them off)
+    const cpx<T>* tw4096 = nullptr;   // H == 4096: exp(-2 pi i k / 4096), the twiddles of the two-pass column transform (else NULL)
     int packNyq;    // columns 0 and W/2 of half spectra share one complex column (NF_FFT_PACK_NYQ=0 switches it off)
     std::vector<unsigned short> revRow, revCol;   // host copies of row.rev / col.rev (digit-reversed position of index k)
     bool packOk() const;

@@ -768,8 +768,10 @@ __device__ __forceinline__ void stage_in_pairs_inv(cpx<T>* __restrict__ buf, con
     for (int line = G.tl; line < G.nl; line += G.TL) {
         const int rowA = 2 * (G.line0 + line);
         const bool haveB = rowA + 1 < a.realH;
-        const cpx<T>* inA = (const cpx<T>*)G.inP + (unsigned)rowA * (unsigned)a.realW;
-        const cpx<T>* inB = inA + (haveB ? (unsigned)a.realW : 0u);
+        // (rowSwap64: the two-pass column transform left row y at row ((y & 63) << 6) | (y >> 6); rowA is even, so rowA + 1 lies 64 rows on)
+        const unsigned physA = a.rowSwap64 ? (((unsigned)rowA & 63u) << 6) | ((unsigned)rowA >> 6) : (unsigned)rowA;
+        const cpx<T>* inA = (const cpx<T>*)G.inP + physA * (unsigned)a.realW;
+        const cpx<T>* inB = inA + (haveB ? (a.rowSwap64 ? 64u : 1u) * (unsigned)a.realW : 0u);
         cpx<T>* __restrict__ lb = buf + line * p.mPad;
         if (!BLUE) {
             // each stored mode k <= n/2 is loaded once and feeds both line elements k and n - k (the conjugate)
@@ -1123,6 +1125,182 @@ __global__ void __launch_bounds__((MODE == 0 && SPEC == 3 && sizeof(T) == 8) ? 5
 template <typename T, int MODE, int SPEC>
 __global__ void __launch_bounds__(256) k_fft_cols_s(nf::LineArgs<T> a) {
     fft_cols_body<T, MODE, SPEC>(a);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// 4096-long columns in TWO passes of 64-point transforms (4096 = 64 x 64) over tiles of 32 adjacent columns.
+// A 4096-long column is 64 KB (fp64): the single-pass kernel fits two of them in LDS - 32-byte runs per row, one workgroup per
+// CU whose load / butterfly / store phases overlap nothing (2.3-2.9 TB/s).  Here a workgroup holds 64 rows x 32 columns
+// (512-byte runs, 32 KB of LDS, 256 threads: five workgroups per CU) and each pass streams at nearly the rate of a copy
+// (tools/col2pass.cpp); the plane is read and written twice, which still beats the one slow pass when the load carries the
+// symmetrised filter (the matched filter's data inverse).
+//   n = 64 a + r1, k = k1 + 64 k2:   Y[r1][k1] = w4096^(r1 k1) * sum_a x[64 a + r1] w64^(a k1)     (first pass, one workgroup per r1)
+//                                    X[k1 + 64 k2] = sum_r1 Y[r1][k1] w64^(r1 k2)                  (second pass, one per k1)
+// The first pass reads rows r1 + 64 a of `in` through the SPEC 3 load of k_fft_cols (filter, plane factor, window, packed
+// column 0 / W/2) and writes Y[r1][k1] to row r1 + 64 k1 of `out`; the second pass reads rows 64 k1 + r1 and writes X[k1 + 64 k2]
+// IN PLACE to row 64 k1 + k2: transformed row y lies at row ((y & 63) << 6) | (y >> 6), which the row pass that follows is told
+// (LineArgs::rowSwap64) - it reads whole rows, in any order at the same cost.  A thread: radix-8 butterfly, twiddle, one LDS
+// exchange, radix-8 butterfly.  tw[i] = exp(-2 pi i * i / 4096).
+#define NF_C2P_CT 32
+template <typename T>
+__device__ __forceinline__ void c2p_core(cpx<T>* __restrict__ lds, cpx<T>* x, const cpx<T>* __restrict__ tw, int c, int j) {
+    Dft<T, 8>::run(x, nullptr);
+#pragma unroll
+    for (int p = 1; p < 8; ++p) x[p] = cmul(x[p], tw[64 * j * p]);
+#pragma unroll
+    for (int p = 0; p < 8; ++p) lds[(j * 8 + p) * NF_C2P_CT + c] = x[p];
+    __syncthreads();
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) x[jj] = lds[(jj * 8 + j) * NF_C2P_CT + c];
+    Dft<T, 8>::run(x, nullptr);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(NF_C2P_CT * 8) k_cols2p_first(nf::LineArgs<T> a, const cpx<T>* __restrict__ tw) {
+    __shared__ cpx<T> lds[64 * NF_C2P_CT];
+    // (tile 0, whose first lane has the packed column's extra fetches, is dealt out first; then tiles side by side, row group after row group)
+    int tile = 0, r1 = (int)blockIdx.x;
+    if (blockIdx.x >= 64u) {
+        const unsigned rest = blockIdx.x - 64u, nt = (unsigned)a.nTiles - 1u;
+        tile = 1 + (int)(rest % nt);
+        r1 = (int)(rest / nt);
+    }
+    const int c = threadIdx.x & (NF_C2P_CT - 1), j = threadIdx.x / NF_C2P_CT;
+    const bool ok = tile * NF_C2P_CT + c < a.nLines;
+    // (lanes beyond the last column repeat its loads and store nothing: no branch around the loads, which stay one batch)
+    const int col = ok ? tile * NF_C2P_CT + c : a.nLines - 1;
+    Geo G;
+    G.inP = (const char*)a.in + (size_t)blockIdx.y * (size_t)a.inBatchStride * sizeof(cpx<T>);
+    cpx<T>* __restrict__ outP = (cpx<T>*)a.out + (size_t)blockIdx.y * (size_t)a.outBatchStride;
+    cpx<T> x[8];
+    unsigned off[8];
+    // every operand of the load in ONE batch of independent fetches (data, symmetrised filter, window), the arithmetic after them
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const unsigned e = (unsigned)(r1 + 64 * (j + 8 * m));
+        off[m] = (unsigned)col * (unsigned)a.inLineStride + e * (unsigned)a.inElemStride;
+        x[m] = ((const cpx<T>*)G.inP)[off[m]];
+    }
+    // fused_ops_herm for one half-stored plane (k_fft_cols, SPEC 3: the same order of roundings)
+    double f[8];
+    if (a.mulSym != nullptr) {
+        const double* __restrict__ ms = a.mulSym + (size_t)blockIdx.y * (size_t)a.mulBatchStride;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) f[m] = ms[off[m]];
+    } else {
+#pragma unroll
+        for (int m = 0; m < 8; ++m) f[m] = 1.0;
+    }
+    double wy[8], wl = 1.0;
+    const bool win = a.winElem != nullptr;
+    if (win) {
+        wl = a.winLine[col];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) wy[m] = a.winElem[r1 + 64 * (j + 8 * m)];
+    }
+    if (a.usePlaneScale) {
+        const double ps = a.planeScale[blockIdx.y & (NF_PLANE_SCALES - 1)];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) f[m] *= ps;
+    }
+    if (win) {
+#pragma unroll
+        for (int m = 0; m < 8; ++m) f[m] *= wy[m] * wl;
+    }
+    const T sgn = (T)a.conjInSign;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        x[m].x = (T)((double)x[m].x * f[m]);
+        x[m].y = (T)((double)(x[m].y * sgn) * f[m]);
+    }
+    if (a.packNyq && col == 0) {
+        // columns 0 and W/2 as ONE complex column z0 + i zN (see k_fft_cols): this one lane of tile 0 fetches both columns again
+        // and applies fused_ops_herm's own order of roundings, (value x filter x plane factor) x window - four elements per batch
+        // of loads (one lane's sequential fetches would otherwise be the tail of the whole launch)
+        const unsigned colN = (unsigned)(a.realW / 2);
+        const double* __restrict__ ms = a.mulSym ? a.mulSym + (size_t)blockIdx.y * (size_t)a.mulBatchStride : nullptr;
+        const double ps = a.usePlaneScale ? a.planeScale[blockIdx.y & (NF_PLANE_SCALES - 1)] : 1.0;
+        const double wlN = win ? a.winLine[colN] : 1.0;
+#pragma unroll
+        for (int m0 = 0; m0 < 8; m0 += 4) {
+            cpx<T> z0[4], zN[4];
+            double g0[4], gN[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const unsigned offN = off[m0 + u] + colN * (unsigned)a.inLineStride;
+                z0[u] = ((const cpx<T>*)G.inP)[off[m0 + u]];
+                zN[u] = ((const cpx<T>*)G.inP)[offN];
+                g0[u] = ms ? ms[off[m0 + u]] : 1.0;
+                gN[u] = ms ? ms[offN] : 1.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (a.usePlaneScale) {
+                    g0[u] *= ps;
+                    gN[u] *= ps;
+                }
+                double re0 = (double)z0[u].x * g0[u], im0 = (double)(z0[u].y * sgn) * g0[u];
+                double reN = (double)zN[u].x * gN[u], imN = (double)(zN[u].y * sgn) * gN[u];
+                if (win) {
+                    const double w0 = wy[m0 + u] * wl, wN = wy[m0 + u] * wlN;
+                    re0 *= w0;
+                    im0 *= w0;
+                    reN *= wN;
+                    imN *= wN;
+                }
+                x[m0 + u].x = (T)re0 - (T)imN;
+                x[m0 + u].y = (T)im0 + (T)reN;
+            }
+        }
+    }
+    c2p_core<T>(lds, x, tw, c, j);
+    if (!ok) return;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int k1 = j + 8 * q;
+        if (r1 * k1 != 0) x[q] = cmul(x[q], tw[r1 * k1]);
+        outP[(unsigned)(r1 + 64 * k1) * (unsigned)a.outElemStride + (unsigned)col * (unsigned)a.outLineStride] = x[q];
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(NF_C2P_CT * 8) k_cols2p_second(nf::LineArgs<T> a, const cpx<T>* __restrict__ tw) {
+    __shared__ cpx<T> lds[64 * NF_C2P_CT];
+    const int tile = (int)(blockIdx.x % (unsigned)a.nTiles), k1 = (int)(blockIdx.x / (unsigned)a.nTiles);
+    const int c = threadIdx.x & (NF_C2P_CT - 1), j = threadIdx.x / NF_C2P_CT;
+    const bool ok = tile * NF_C2P_CT + c < a.nLines;
+    const int col = ok ? tile * NF_C2P_CT + c : a.nLines - 1;
+    cpx<T>* __restrict__ outP = (cpx<T>*)a.out + (size_t)blockIdx.y * (size_t)a.outBatchStride;
+    cpx<T> x[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+        x[m] = outP[(unsigned)(64 * k1 + j + 8 * m) * (unsigned)a.outElemStride + (unsigned)col * (unsigned)a.outLineStride];
+    c2p_core<T>(lds, x, tw, c, j);
+    if (!ok) return;
+    const T r = (T)a.scale, ri = r * (T)a.conjOutSign;
+    if (a.packNyq && col == 0) {
+        // inverse of the packed column: the two real columns come back as real and imaginary part
+        const unsigned colN = (unsigned)(a.realW / 2);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            cpx<T> v0, vN;
+            v0.x = x[q].x * r;
+            v0.y = (T)0;
+            vN.x = x[q].y * ri;
+            vN.y = (T)0;
+            cpx<T>* orow = outP + (unsigned)(64 * k1 + j + 8 * q) * (unsigned)a.outElemStride;
+            orow[0] = v0;
+            orow[colN * (unsigned)a.outLineStride] = vN;
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            cpx<T> v = x[q];
+            v.x *= r;
+            v.y *= ri;
+            outP[(unsigned)(64 * k1 + j + 8 * q) * (unsigned)a.outElemStride + (unsigned)col * (unsigned)a.outLineStride] = v;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1873,6 +2051,18 @@ int Plan2D<T>::init(int H_, int W_) {
     threadsCol = std::max(threadsCol, colsPerWG);
     useReal = env_int("NF_FFT_REAL", 1);
     packNyq = env_int("NF_FFT_PACK_NYQ", 1);
+    tw4096 = nullptr;
+    if (H == 4096 && (W % 2) == 0 && (double)H * W < 2147483648.0) {
+        // twiddles of the two-pass column transform (k_cols2p_*): exp(-2 pi i k / 4096), rounded once from long double
+        std::vector<cpx<T>> tw(4096);
+        for (int k = 0; k < 4096; ++k) {
+            const long double ang = -2.0L * 3.14159265358979323846264338327950288L * (long double)k / 4096.0L;
+            tw[k].x = (T)cosl(ang);
+            tw[k].y = (T)sinl(ang);
+        }
+        rc = upload<T>(tw, &tw4096);
+        if (rc) return rc;
+    }
     return NF_OK;
 }
 
@@ -1888,6 +2078,8 @@ template <typename T>
 void Plan2D<T>::destroy() {
     free_line_plan<T>(&row);
     free_line_plan<T>(&col);
+    if (tw4096) (void)hipFree((void*)tw4096);
+    tw4096 = nullptr;
 }
 
 template <typename T>
@@ -2063,7 +2255,24 @@ int Plan2D<T>::inverse_half(const void* in, void* work, void* out, int outType, 
             a.nLines = (hi + 1) / 2;
         }
     }
-    int rc = launch_lines<T>(c, true, batch, threadsCol, stream);
+    int rc;
+    static const int twoPass = env_int("NF_FFT_COLS_2PASS", 1);
+    if (twoPass && tw4096 != nullptr && c.nSum <= 1 && c.storeHi == 0) {
+        // 4096-long columns: two passes of 64-point transforms (k_cols2p_first / _second), rows of `work` left in swapped order
+        c.nTiles = nf_div_up(c.nLines, NF_C2P_CT);
+        const double npixTotal = ((double)c.nLines + (c.packNyq ? 1.0 : 0.0)) * c.plan.n * batch;
+        ProfScope ps(sizeof(T) == 8 ? PT_FFT_COLS_F64 : PT_FFT_COLS_F32, stream,
+                     npixTotal * (2.0 * sizeof(cpx<T>) + (c.mulSym ? 8.0 : 0.0)));
+        const dim3 grid((unsigned)c.nTiles * 64u, (unsigned)batch);
+        hipLaunchKernelGGL((k_cols2p_first<T>), grid, dim3(NF_C2P_CT * 8), 0, stream, c, tw4096);
+        NF_CHECK_LAUNCH("k_cols2p_first");
+        hipLaunchKernelGGL((k_cols2p_second<T>), grid, dim3(NF_C2P_CT * 8), 0, stream, c, tw4096);
+        NF_CHECK_LAUNCH("k_cols2p_second");
+        a.rowSwap64 = 1;
+        rc = NF_OK;
+    } else {
+        rc = launch_lines<T>(c, true, batch, threadsCol, stream);
+    }
     if (rc) return rc;
     return launch_lines<T>(a, false, batch, threadsRow, stream);
 }

@@ -207,6 +207,42 @@ def test_half_stored_spectra(shape, dtype, N):
         assert np.array_equal(part[lo:hi], gotSum[lo:hi]), (lo, hi)
 
 
+@pytest.mark.parametrize("W", [80, 64, 4])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("N", [1, 2])
+def test_two_pass_columns_of_4096_rows(W, dtype, N):
+    """nf_fft2_inverse_half with 4096-long columns and one plane per output map: the column pass runs as two passes of
+    64-point transforms (k_cols2p_first / k_cols2p_second, rows handed to the row pass in swapped order).  Against numpy on
+    the full spectra: symmetrised filter, window, per-plane factors, the packed column 0 / W/2, a partial last column tile
+    (W = 80: 40 columns in tiles of 32)."""
+    shape = (4096, W)
+    H = 4096
+    rng = np.random.default_rng(77)
+    eng = _eng(shape)
+    x = rng.standard_normal((N,) + shape).astype(dtype)
+    tol = 1e-12 if dtype == np.float64 else 3e-5
+    out = 'f64' if dtype == np.float64 else 'f32'
+    dx = engine.to_dev(x)
+    Fh = eng.fft(dx, half=True)
+    Fh[..., W // 2 + 1:] = float('nan')
+    Fd = enmap.fft(x.astype(np.float64))
+    filt = rng.standard_normal((N,) + shape).astype(np.float32)
+    dfilt = engine.to_dev(filt)
+    win = np.sinc(np.fft.fftfreq(H))[:, None] * np.sinc(np.fft.fftfreq(W))[None, :]
+    ps = rng.uniform(-3, 3, N)
+    ref = np.real(enmap.ifft(Fd * win * filt * ps[:, None, None], normalize=False))
+    got = _np(eng.ifft(Fh, out=out, filt=dfilt, window=1.0, half=True, planeScale=ps))
+    assert got.shape == x.shape
+    assert np.abs(got - ref).max() <= tol * np.abs(ref).max()
+    # no filter, no window: the plain round trip
+    got = _np(eng.ifft(Fh, out=out, unitary=True, half=True))
+    assert np.abs(got - x).max() <= (1e-12 if dtype == np.float64 else 2e-5)
+    # filter alone
+    ref = np.real(enmap.ifft(Fd * filt, normalize=False))
+    got = _np(eng.ifft(Fh, out=out, filt=dfilt, half=True))
+    assert np.abs(got - ref).max() <= tol * np.abs(ref).max()
+
+
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_gaussian_filter_and_background(dtype):
     shape = (211, 256)

@@ -1321,6 +1321,252 @@ __device__ __forceinline__ float tf_filter_value(CT c, double rhs) {
     return (float)((double)inv * rhs);
 }
 
+// ---- the template path of a one-frequency scale with 4096-long columns in THREE passes (round 3, after k_cols2p_*) ----
+// k_template_cols does the whole path in one pass but as one 128 KB workgroup per CU whose pointwise phase waits for memory
+// latency (213 us per scale at 4096^2).  With the column transforms split 64 x 64 the same work is three streaming passes:
+//   k_template2p_first   row spectra -> Y[r1][k1] (first pass of the forward transform), into `work`
+//   k_template2p_middle  one workgroup per (column tile, k1): second pass of the forward transform - the workgroup then holds the
+//                        spectrum at the modes k = k1 + 64 k2 of its columns -, filter and mirror-mode filter, symmetrised filter
+//                        (and the cube where wanted) to HBM, product with plane factor and window, and the FIRST pass of the
+//                        inverse transform over k2 (the layout a thread holds after one 64-point transform is the layout the next
+//                        one starts from), twiddled, in place
+//   k_template2p_last    second pass of the inverse transform, only the wanted rows stored (natural order, in place)
+// The packed column 0 / W/2 needs Z[k] and Z[-k] together: the workgroups of tile 0 also transform column 0 of the mirror block
+// k1' = (64 - k1) mod 64.  Per element the arithmetic of k_template_cols' pointwise phase; the transforms round differently
+// (another factorisation), within float32 round-off.
+__device__ __forceinline__ void c2p_block(unsigned bx, int nTiles, int& tile, int& blk) {
+    // tile 0 (extra work for the packed column) is dealt out first; then tiles side by side, row group after row group
+    tile = 0;
+    blk = (int)bx;
+    if (bx >= 64u) {
+        const unsigned rest = bx - 64u, nt = (unsigned)nTiles - 1u;
+        tile = 1 + (int)(rest % nt);
+        blk = (int)(rest / nt);
+    }
+}
+
+__global__ void __launch_bounds__(NF_C2P_CT * 8) k_template2p_first(nf::LineArgs<float> af, cpx<float>* __restrict__ work, long long workBatchStride,
+                                                                    const cpx<float>* __restrict__ tw) {
+    __shared__ cpx<float> lds[64 * NF_C2P_CT];
+    int tile, r1;
+    c2p_block(blockIdx.x, af.nTiles, tile, r1);
+    const int c = threadIdx.x & (NF_C2P_CT - 1), j = threadIdx.x / NF_C2P_CT;
+    const bool ok = tile * NF_C2P_CT + c < af.nLines;
+    const int col = ok ? tile * NF_C2P_CT + c : af.nLines - 1;
+    const cpx<float>* __restrict__ inP = (const cpx<float>*)af.in + (size_t)blockIdx.y * (size_t)af.inBatchStride;
+    cpx<float>* __restrict__ outP = work + (size_t)blockIdx.y * (size_t)workBatchStride;
+    cpx<float> x[8];
+    unsigned off[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        off[m] = (unsigned)col * (unsigned)af.inLineStride + (unsigned)(r1 + 64 * (j + 8 * m)) * (unsigned)af.inElemStride;
+        x[m] = inP[off[m]];
+    }
+    const float sgn = (float)af.conjInSign;
+    if (af.packNyq && col == 0) {
+        // forward: columns 0 and W/2 of the row spectra are real, z = c0 + i cN
+        const unsigned colN = (unsigned)(af.realW / 2);
+        cpx<float> zN[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) zN[m] = inP[off[m] + colN * (unsigned)af.inLineStride];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) x[m].y = zN[m].x;
+    } else {
+#pragma unroll
+        for (int m = 0; m < 8; ++m) x[m].y *= sgn;
+    }
+    c2p_core<float>(lds, x, tw, c, j);
+    if (!ok) return;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int k1 = j + 8 * q;
+        if (r1 * k1 != 0) x[q] = cmul(x[q], tw[r1 * k1]);
+        outP[(unsigned)(r1 + 64 * k1) * (unsigned)af.realW + (unsigned)col] = x[q];
+        // (a second copy of the packed column in column W/2, which no pass reads as data: the middle pass works in place, and the
+        //  workgroup of block k1 needs column 0 of block 64 - k1 as THIS pass left it)
+        if (af.packNyq && col == 0) outP[(unsigned)(r1 + 64 * k1) * (unsigned)af.realW + (unsigned)(af.realW / 2)] = x[q];
+    }
+}
+
+template <typename CT>
+__global__ void __launch_bounds__(NF_C2P_CT * 8) k_template2p_middle(nf::LineArgs<float> af, nf::LineArgs<float> ai, nf::TemplateFuse tf,
+                                                                     cpx<float>* __restrict__ work, long long workBatchStride,
+                                                                     const cpx<float>* __restrict__ tw) {
+    __shared__ cpx<float> lds[64 * NF_C2P_CT];
+    __shared__ cpx<float> zmir[64];
+    int tile, k1;
+    c2p_block(blockIdx.x, af.nTiles, tile, k1);
+    const int c = threadIdx.x & (NF_C2P_CT - 1), j = threadIdx.x / NF_C2P_CT;
+    const bool ok = tile * NF_C2P_CT + c < af.nLines;
+    const unsigned col = (unsigned)(ok ? tile * NF_C2P_CT + c : af.nLines - 1);
+    const unsigned W = (unsigned)af.realW, colN = W / 2, n = 4096u;
+    cpx<float>* __restrict__ wp = work + (size_t)blockIdx.y * (size_t)workBatchStride;
+    // the noise power at the thread's modes and mirror modes, the window factors and the Y values: one batch of fetches
+    const CT* __restrict__ cov = (const CT*)tf.cov;
+    const unsigned xm = col == 0u ? 0u : W - col;
+    const bool win = ai.winElem != nullptr;
+    cpx<float> x[8];
+    CT c1[8], c2[8];
+    double wy[8], wl = 1.0;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) x[m] = wp[(unsigned)(64 * k1 + j + 8 * m) * W + col];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const unsigned e = (unsigned)(k1 + 64 * (j + 8 * q)), em = e == 0u ? 0u : n - e;
+        c1[q] = cov[(size_t)e * W + col];
+        c2[q] = cov[(size_t)em * W + xm];
+    }
+    if (win) {
+        wl = ai.winLine[col];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) wy[q] = ai.winElem[k1 + 64 * (j + 8 * q)];
+    }
+    c2p_core<float>(lds, x, tw, c, j);      // x[q] = Z[k1 + 64 (j + 8 q)] of this column
+    const bool packed0 = af.packNyq && tile == 0;
+    if (packed0) {
+        // column 0 of the mirror block k1' = (64 - k1) mod 64: Z[-k] of the packed column
+        const int k1m = (64 - k1) & 63;
+        cpx<float> y[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            y[m].x = 0.0f;
+            y[m].y = 0.0f;
+            if (c == 0) y[m] = wp[(unsigned)(64 * k1m + j + 8 * m) * W + colN];      // (the first pass's copy of column 0)
+        }
+        __syncthreads();
+        c2p_core<float>(lds, y, tw, c, j);
+        if (c == 0) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) zmir[j + 8 * q] = y[q];
+        }
+        __syncthreads();
+    }
+    const float r = (float)af.scale, ri = r * (float)af.conjOutSign, h = 0.5f;
+    const float cj = (float)ai.conjInSign;
+    const size_t npix = (size_t)af.realH * (size_t)W;
+    double* __restrict__ sym = tf.sym + (size_t)blockIdx.y * npix;
+    float* __restrict__ filt = tf.filt[blockIdx.y & (NF_TF_MAXBATCH - 1)];
+    const double ps = ai.usePlaneScale ? ai.planeScale[blockIdx.y & (NF_PLANE_SCALES - 1)] : 1.0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const unsigned k2 = (unsigned)(j + 8 * q), e = (unsigned)k1 + 64u * k2, em = e == 0u ? 0u : n - e;
+        const cpx<float> z = x[q];
+        if (packed0 && col == 0u) {
+            // columns 0 and W/2 as they leave the forward pass (k_fft_cols' unpacking), each with its mirror row in its own column
+            const cpx<float> zm = zmir[k1 != 0 ? 63u - k2 : ((64u - k2) & 63u)];
+            cpx<float> g0, gN, g0m, gNm;
+            g0.x = h * (z.x + zm.x) * r;
+            g0.y = h * (z.y - zm.y) * ri;
+            gN.x = h * (z.y + zm.y) * r;
+            gN.y = -h * (z.x - zm.x) * ri;
+            g0m.x = h * (zm.x + z.x) * r;
+            g0m.y = h * (zm.y - z.y) * ri;
+            gNm.x = h * (zm.y + z.y) * r;
+            gNm.y = -h * (zm.x - z.x) * ri;
+            const size_t p0 = (size_t)e * W, p0m = (size_t)em * W, pN = p0 + colN, pNm = p0m + colN;
+            const float a1 = tf_filter_value<CT>(c1[q], tf.w0 * (double)hypotf(g0.x, g0.y));
+            const float a2 = p0m == p0 ? a1 : tf_filter_value<CT>(c2[q], tf.w0 * (double)hypotf(g0m.x, g0m.y));
+            const float b1 = tf_filter_value<CT>(cov[pN], tf.w0 * (double)hypotf(gN.x, gN.y));
+            const float b2 = pNm == pN ? b1 : tf_filter_value<CT>(cov[pNm], tf.w0 * (double)hypotf(gNm.x, gNm.y));
+            const double s0 = 0.5 * ((double)a1 + (double)a2), sN = 0.5 * ((double)b1 + (double)b2);
+            if (filt != nullptr) {
+                filt[p0] = a1;
+                filt[pN] = b1;
+            }
+            sym[p0] = s0;
+            sym[pN] = sN;
+            double f0 = s0, fN = sN;
+            if (ai.usePlaneScale) {
+                f0 *= ps;
+                fN *= ps;
+            }
+            double re0 = 0.0, im0 = 0.0, reN = 0.0, imN = 0.0;
+            re0 += (double)g0.x * f0;
+            im0 += (double)(g0.y * cj) * f0;
+            reN += (double)gN.x * fN;
+            imN += (double)(gN.y * cj) * fN;
+            if (win) {
+                const double w0_ = wy[q] * wl, wN_ = wy[q] * ai.winLine[colN];
+                re0 *= w0_;
+                im0 *= w0_;
+                reN *= wN_;
+                imN *= wN_;
+            }
+            const float x0 = (float)re0, y0 = (float)im0, xN = (float)reN, yN = (float)imN;
+            x[q].x = x0 - yN;
+            x[q].y = y0 + xN;
+        } else {
+            cpx<float> v = z;
+            v.x *= r;
+            v.y *= ri;                                        // the spectrum value as the forward pass would store it
+            const size_t pp = (size_t)e * W + col, pm = (size_t)em * W + xm;
+            const double rhs = tf.w0 * (double)hypotf(v.x, v.y);
+            const float o1 = tf_filter_value<CT>(c1[q], rhs);
+            const float o2 = pm != pp ? tf_filter_value<CT>(c2[q], rhs) : o1;
+            const double sv = 0.5 * ((double)o1 + (double)o2);
+            if (ok) {
+                if (filt != nullptr) {
+                    filt[pp] = o1;
+                    if (pm != pp) filt[pm] = o2;
+                }
+                sym[pp] = sv;
+            }
+            double f = sv;
+            if (ai.usePlaneScale) f *= ps;
+            if (win) f *= wy[q] * wl;
+            x[q].x = (float)((double)v.x * f);
+            x[q].y = (float)((double)(v.y * cj) * f);
+        }
+    }
+    // first pass of the inverse transform over k2 (index a = j + 8 q, which is where the values are), twiddled by w^(k1 o1)
+    __syncthreads();
+    c2p_core<float>(lds, x, tw, c, j);
+    if (!ok) return;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int o1 = j + 8 * q;
+        if (k1 * o1 != 0) x[q] = cmul(x[q], tw[k1 * o1]);
+        wp[(unsigned)(64 * k1 + o1) * W + col] = x[q];
+    }
+}
+
+__global__ void __launch_bounds__(NF_C2P_CT * 8) k_template2p_last(nf::LineArgs<float> ai, cpx<float>* __restrict__ work, long long workBatchStride,
+                                                                   const cpx<float>* __restrict__ tw) {
+    __shared__ cpx<float> lds[64 * NF_C2P_CT];
+    const int tile = (int)(blockIdx.x % (unsigned)ai.nTiles), o1 = (int)(blockIdx.x / (unsigned)ai.nTiles);
+    const int c = threadIdx.x & (NF_C2P_CT - 1), j = threadIdx.x / NF_C2P_CT;
+    const bool ok = tile * NF_C2P_CT + c < ai.nLines;
+    const unsigned col = (unsigned)(ok ? tile * NF_C2P_CT + c : ai.nLines - 1);
+    const unsigned W = (unsigned)ai.realW;
+    cpx<float>* __restrict__ wp = work + (size_t)blockIdx.y * (size_t)workBatchStride;
+    cpx<float> x[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) x[m] = wp[(unsigned)(o1 + 64 * (j + 8 * m)) * W + col];
+    c2p_core<float>(lds, x, tw, c, j);
+    if (!ok) return;
+    const float r = (float)ai.scale, ri = r * (float)ai.conjOutSign;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int e = o1 + 64 * (j + 8 * q);
+        if (ai.storeHi != 0 && (e < ai.storeLo || e >= ai.storeHi)) continue;
+        cpx<float>* orow = wp + (unsigned)e * W;
+        if (ai.packNyq && col == 0u) {
+            cpx<float> v0, vN;
+            v0.x = x[q].x * r;
+            v0.y = 0.0f;
+            vN.x = x[q].y * ri;
+            vN.y = 0.0f;
+            orow[0] = v0;
+            orow[W / 2] = vN;
+        } else {
+            cpx<float> v = x[q];
+            v.x *= r;
+            v.y *= ri;
+            orow[col] = v;
+        }
+    }
+}
+
 template <typename CT, int MODE>
 __global__ void __launch_bounds__(NF_FFT_MAXTHREADS) k_template_cols(nf::LineArgs<float> af, nf::LineArgs<float> ai, nf::TemplateFuse tf) {
     extern __shared__ __align__(16) unsigned char nf_smem[];
@@ -2372,7 +2618,25 @@ int Plan2D<T>::template_filter(const void* rowsOut, int batch, const TemplateFus
         int nCubes = 0;
         for (int b = 0; b < batch; ++b) nCubes += tf.filt[b] != nullptr;
         const double covB = covType == NF_F32 ? 4.0 : 8.0;
-        {
+        static const int threePass = env_int("NF_TEMPLATE_2PASS", 1);
+        if (threePass && tw4096 != nullptr && cf.packNyq) {
+            // 4096-long columns: the path as three streaming passes (k_template2p_*), see there
+            cf.nTiles = nf_div_up(cf.nLines, NF_C2P_CT);
+            ci.nTiles = cf.nTiles;
+            ProfScope ps(PT_FFT_COLS_F32, stream,
+                         (double)H * W * (batch * (4.0 + covB + 4.0) + nCubes * 4.0) + (double)(ci.storeHi > 0 ? ci.storeHi - ci.storeLo : H) * (W / 2 + 1) * 8.0 * batch);
+            const dim3 grid((unsigned)cf.nTiles * 64u, (unsigned)batch), block(NF_C2P_CT * 8);
+            const long long wbs = (long long)H * W;
+            hipLaunchKernelGGL(k_template2p_first, grid, block, 0, stream, cf, (cpx<float>*)work, wbs, (const cpx<float>*)tw4096);
+            NF_CHECK_LAUNCH("k_template2p_first");
+            if (covType == NF_F64)
+                hipLaunchKernelGGL((k_template2p_middle<double>), grid, block, 0, stream, cf, ci, tf, (cpx<float>*)work, wbs, (const cpx<float>*)tw4096);
+            else
+                hipLaunchKernelGGL((k_template2p_middle<float>), grid, block, 0, stream, cf, ci, tf, (cpx<float>*)work, wbs, (const cpx<float>*)tw4096);
+            NF_CHECK_LAUNCH("k_template2p_middle");
+            hipLaunchKernelGGL(k_template2p_last, grid, block, 0, stream, ci, (cpx<float>*)work, wbs, (const cpx<float>*)tw4096);
+            NF_CHECK_LAUNCH("k_template2p_last");
+        } else {
             // algorithmic bytes: the row spectra and the noise power in; the symmetrised filter, the wanted cubes and the stored rows out
             ProfScope ps(PT_FFT_COLS_F32, stream,
                          (double)H * W * (batch * (4.0 + covB + 4.0) + nCubes * 4.0) + (double)(ci.storeHi > 0 ? ci.storeHi - ci.storeLo : H) * (W / 2 + 1) * 8.0 * batch);

@@ -169,3 +169,36 @@ def test_stale_noise_tables_are_caught_in_debug_mode():
         torch.cuda.synchronize()
     finally:
         filters._SCALE_ENTRY, filters.RETURN_DEVICE_ARRAYS, engine.CHECK_NOISE_TABLES = keep
+
+
+@pytest.mark.parametrize("kind,cls,units,dtype", [('arnaud', 'ArnaudModelMatchedFilter', 'yc', np.float64),
+                                                  ('beam', 'BeamMatchedFilter', 'uK', np.float64),
+                                                  ('arnaud', 'ArnaudModelMatchedFilter', 'yc', np.float32)])
+def test_scale_entry_long_columns_in_streaming_passes(kind, cls, units, dtype):
+    """4096-long columns (the headline tile's): the template path of a one-frequency scale runs as three streaming passes
+    (k_template2p_*) and the data inverse's column transform as two (k_cols2p_*), both 64 x 64 factorisations of the column
+    transform.  The statement-by-statement path transforms the templates with the single-pass column kernels, so the two agree
+    to float32 round-off of the template spectra (not bit for bit): filter cube, normalisation, filtered map, S/N map; the noise
+    map and the masks follow from those.  160 columns: three column tiles, the last one partial, with the packed column 0 / W/2."""
+    shape = (4096, 160)
+    srcKind = 'clusters' if kind == 'arnaud' else 'sources'
+    mapsL, wcs, truth = helpers.make_tile(shape, freqs=(150.0,), fwhm=(1.4,), noise=(20.0,), seed=9, numSources=6, kind=srcKind,
+                                          dtype=dtype, holes=True)
+    base = {'noiseParams': {'method': 'dataMap', 'noiseGridArcmin': 20., 'numNoiseBins': 1}, 'outputUnits': units}
+    filtersList = []
+    for k, (z, m) in enumerate([(0.4, 2e14), (0.2, 4e14), (0.8, 1e14)]):
+        p = dict(base)
+        p.update({'z': z, 'M500MSun': m})
+        filtersList.append({'label': 'scale%d' % k, 'class': cls, 'params': p})
+    if kind == 'beam':
+        filtersList = filtersList[:2]
+    ref = _run(mapsL, filtersList, True, 1, False)
+    tol = 2e-6 if dtype == np.float64 else 2e-5
+    for lanes, batch in ((1, 1), (2, 2), (1, 8)):
+        got = _run(mapsL, filtersList, True, lanes, True, batch)
+        for g, r in zip(got, ref):
+            assert abs(g['signalNorm'] / r['signalNorm'] - 1) < tol, (g['signalNorm'], r['signalNorm'])
+            assert np.abs(g['filt'] - r['filt']).max() <= tol * np.abs(r['filt']).max()
+            assert np.array_equal(g['surveyMask'], r['surveyMask'])
+            for key in ('data', 'SNMap', 'RMSMap'):
+                assert np.abs(g[key].astype(np.float64) - r[key]).max() <= 5 * tol * np.abs(r[key]).max(), (key, lanes, batch)

@@ -5,12 +5,17 @@ FETCH_SIZE is doubled (gfx950 tallies 128-byte read requests at 64 B, MI355X_MIC
 used as reported.  Counters report KiB."""
 import csv, glob, json, re, sys, collections
 
-TAGS = [('fft_cols_f64', ['k_fft_cols<double'], None), ('fft_rows_f64', ['k_fft_rows<double'], None),
-        ('fft_cols_f32', ['k_fft_cols<float', 'k_template_cols'], None), ('fft_rows_f32', ['k_fft_rows<float'], None),
+# (tag, kernels of the entry point, kernels whose launches count its calls - None: every launch is a call)
+TAGS = [('fft_cols_f64', ['k_fft_cols<double', 'k_cols2p_first<double', 'k_cols2p_second<double'], ['k_fft_cols<double', 'k_cols2p_first<double']),
+        ('fft_rows_f64', ['k_fft_rows<double'], None),
+        # (4096-long columns: the column pass of a filtered inverse is two launches, the template path of a scale three)
+        ('fft_cols_f32', ['k_fft_cols<float', 'k_template_cols', 'k_template2p_', 'k_cols2p_first<float', 'k_cols2p_second<float'],
+         ['k_fft_cols<float', 'k_template_cols', 'k_template2p_first', 'k_cols2p_first<float']),
+        ('fft_rows_f32', ['k_fft_rows<float'], None),
         # the pixel-window undo as two 1-D circular filters (nf_axis_filter): one kernel per axis
         ('axis_filter_cols', [r'k_line_filter<\w+, ?(true|1)'], None), ('axis_filter_rows', [r'k_line_filter<\w+, ?(false|0)'], None),
         # one nf_noise_map call = (breaks, first scale of a tile and lane only) + block_stats + window_rms0 + block_core + block_classes + windows + paint_blocks
-        ('noise_map', ['k_noise_'], 'k_noise_windows')]
+        ('noise_map', ['k_noise_'], ['k_noise_windows'])]
 
 
 def load(d, counter):
@@ -31,7 +36,7 @@ for tag, pats, callKernel in TAGS:
     if callKernel is None:
         calls = sum(len(fetch[k]) for k in names)
     else:
-        calls = sum(len(fetch[k]) for k in names if callKernel in k)
+        calls = sum(len(fetch[k]) for k in names if any(c in k for c in callKernel))
     f = sum(sum(fetch[k]) for k in names) * 1024 * 2 / 1e9 / calls
     w = sum(sum(write.get(k, [])) for k in names) * 1024 / 1e9 / calls
     res[tag] = {'kernels': [k[:90] for k in names], 'calls': calls, 'fetch_GB_corrected': round(f, 4), 'write_GB': round(w, 4),

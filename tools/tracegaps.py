@@ -7,6 +7,13 @@ starts = [e[0] for e in ev if 'cross_power' in e[3]]
 s0 = starts[-(int(sys.argv[2]) if len(sys.argv) > 2 else 1)]       # argv[2]: tiles per step (one cross_power per tile)
 sel = [e for e in ev if e[0] >= s0]
 span = (max(e[1] for e in sel) - s0) / 1e6
+if len(sys.argv) > 3 and sys.argv[3] == 'between':
+    # a whole step in the middle of the run, from its first kernel to the next step's first kernel (the idle tail included)
+    k = int(sys.argv[2])
+    s0, s1 = starts[-2 * k], starts[-k]
+    sel = [e for e in ev if s0 <= e[0] < s1]
+    span = (s1 - s0) / 1e6
+    print('step of %.2f ms: last kernel ends at %.2f ms' % (span, (max(e[1] for e in sel) - s0) / 1e6))
 byq = collections.defaultdict(float)
 for e in sel:
     byq[e[2]] += (e[1] - e[0]) / 1e6

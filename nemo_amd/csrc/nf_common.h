@@ -81,6 +81,8 @@ __device__ __forceinline__ cpx<T> cmulnegi(cpx<T> a) {
 
 static inline int nf_div_up(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+static const int kMaxLds = 160 * 1024;      // LDS of a gfx950 CU: the most a line-transform workgroup may ask for
+
 // float64 <-> unsigned 64-bit key with the same order (integer atomicMax / atomicMin on doubles)
 __device__ __forceinline__ unsigned long long nf_ordered_key(double v) {
     unsigned long long b = (unsigned long long)__double_as_longlong(v);

@@ -84,6 +84,12 @@ struct LineArgs {
     const double* apodElem;  // optional per-element apodisation factors (length n)
 };
 
+// nf_linefilt.hip: the rows line filter with fused first / middle / last stages (plain radices up to 8, >= 2 stages)
+template <typename T>
+int launch_line_filter_rows_fused(const LineArgs<T>& a, int batch, int threads, size_t lds, hipStream_t stream);
+template <typename T>
+int launch_line_filter_cols_fused(const LineArgs<T>& a, int batch, int threads, size_t lds, hipStream_t stream);
+
 // The template path of one matched-filter scale with ONE frequency map as a single column pass (k_template_cols): what the
 // column kernel needs beside the two transforms' own arguments
 #define NF_TF_MAXE 16          // elements of a tile a thread carries through the pointwise step (n * tile width / threads)

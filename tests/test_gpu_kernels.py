@@ -1,6 +1,8 @@
 """GPU parity tests, one per C-ABI entry point (include/nemofilt.h), against numpy / scipy - the libraries the
 reference itself calls for these primitives.  Tolerances: bit-exact for integer / index
 work and for the kernels that reproduce scipy's accumulation order; 1e-12 relative for fp64 FFTs, 2e-5 for fp32."""
+import os
+
 import numpy as np
 import pytest
 from scipy import ndimage, interpolate
@@ -700,3 +702,22 @@ def test_label_and_stats_batch_equals_map_by_map(vdtype):
                     assert n == 0
                 assert np.array_equal(a[1:n + 1], R[k, 1:n + 1])
                 assert np.array_equal(_np(labA), _np(labs[k]))
+
+
+@pytest.mark.gpu
+def test_fused_line_filter_equals_staged_kernel_bit_for_bit():
+    """nf_axis_filter runs k_line_filter_rows_fused / _cols_fused (first stage from global memory, last forward stage x transfer
+    function x first inverse stage in one step, last stage to global memory) where k_line_filter staged everything through LDS:
+    the same arithmetic per element, so the same bits - on every shape of tools/linefilt_ab.py (4096^2, the survey tile shapes,
+    odd widths, float32 and float64, with and without the zero reference).  The switch is read once per process: two processes
+    per axis, digests compared."""
+    import subprocess, sys
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "linefilt_ab.py")
+    for axis in (0, 1):
+        outs = []
+        for fused in ("0", "1"):
+            env = dict(os.environ, NF_LF_FUSED=fused, NF_LF_FUSED_COLS=fused)
+            r = subprocess.run([sys.executable, tool, str(axis), "digest"], env=env, capture_output=True, text=True, timeout=110)
+            assert r.returncode == 0, r.stderr[-2000:]
+            outs.append(r.stdout.strip().splitlines())
+        assert len(outs[0]) >= 8 and outs[0] == outs[1], (axis, outs)

@@ -13,7 +13,8 @@ TAGS = [('fft_cols_f64', ['k_fft_cols<double', 'k_cols2p_first<double', 'k_cols2
          ['k_fft_cols<float', 'k_template_cols', 'k_template2p_first', 'k_cols2p_first<float']),
         ('fft_rows_f32', ['k_fft_rows<float'], None),
         # the pixel-window undo as two 1-D circular filters (nf_axis_filter): one kernel per axis
-        ('axis_filter_cols', [r'k_line_filter<\w+, ?(true|1)'], None), ('axis_filter_rows', [r'k_line_filter<\w+, ?(false|0)'], None),
+        ('axis_filter_cols', [r'k_line_filter<\w+, ?(true|1)', 'k_line_filter_cols_fused'], None),
+        ('axis_filter_rows', [r'k_line_filter<\w+, ?(false|0)', 'k_line_filter_rows_fused'], None),
         # one nf_noise_map call = (breaks, first scale of a tile and lane only) + block_stats + window_rms0 + block_core + block_classes + windows + paint_blocks
         ('noise_map', ['k_noise_'], ['k_noise_windows'])]
 

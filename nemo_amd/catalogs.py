@@ -607,26 +607,48 @@ def _makeOptimalCatalogForcedRef(catalogDict, constraintsList=[]):
 
 
 def removeDuplicates(tab):
-    """nemo/catalogs.py:704-749: keep the highest-SNR member of every group closer than XMATCH_RADIUS_DEG."""
-    if len(tab) == 1:
+    """nemo/catalogs.py:704-749: keep the highest-SNR member of every group closer than XMATCH_RADIUS_DEG.  Returns (table sorted
+    by RADeg, number of rows that had a neighbour, their names).  With several GPUs every rank runs this on the gathered
+    catalogue of all ranks after every pass: from GPU_XMATCH_MIN_ROWS rows on the all-pairs test runs on the device
+    (engine.xmatch_self: counts and best partners of all rows; the host decides as before when a separation is too close to the
+    radius to call), and the kept rows are taken from the table once, by index."""
+    n = len(tab)
+    if n == 1:
         return tab, 1, []
     ra, dec = np.asarray(tab['RADeg'], dtype=float), np.asarray(tab['decDeg'], dtype=float)
-    i, j = _pairsWithin(ra, dec, ra, dec, XMATCH_RADIUS_DEG)
-    other = i != j
-    mask = np.zeros(len(tab), dtype=bool)          # nearest OTHER row closer than the radius (match_coordinates_sky, :722-723)
-    mask[i[other]] = True
-    if mask.sum() == 0:
+    dupIdx = keepDup = None
+    if n >= GPU_XMATCH_MIN_ROWS:
+        from . import engine
+        if engine.gpu_ready():
+            res = engine.xmatch_self(ra, dec, tab['SNR'], XMATCH_RADIUS_DEG)
+            if res is not None:
+                # partners of a row (itself included) closer than the radius, and the first of them with the highest SNR: a row
+                # with a partner other than itself is a duplicate (match_coordinates_sky, :722-723), and its partners are
+                # duplicates too, so the best partner inside the table of duplicates (:731-741) is the best partner here
+                count, best = res[0], res[1]
+                dupIdx = np.flatnonzero(count > 1)
+                keepDup = np.unique(best[dupIdx])
+    if dupIdx is None:
+        i, j = _pairsWithin(ra, dec, ra, dec, XMATCH_RADIUS_DEG)
+        other = i != j
+        mask = np.zeros(n, dtype=bool)             # nearest OTHER row closer than the radius
+        mask[i[other]] = True
+        dupIdx = np.flatnonzero(mask)
+        if len(dupIdx) > 0:
+            di, dj = _pairsWithin(ra[dupIdx], dec[dupIdx], ra[dupIdx], dec[dupIdx], XMATCH_RADIUS_DEG, inclusive=True)
+            count, best = _bestPerGroup(di, dj, np.asarray(tab['SNR'])[dupIdx], len(dupIdx))
+            best = np.where(best < 0, np.arange(len(dupIdx)), best)
+            keepDup = dupIdx[np.unique(best)]
+    if len(dupIdx) == 0:
         return tab, 0, []
-    dupTab, noDupTab = tab[mask], tab[~mask]
-    di, dj = _pairsWithin(dupTab['RADeg'], dupTab['decDeg'], dupTab['RADeg'], dupTab['decDeg'], XMATCH_RADIUS_DEG,
-                          inclusive=True)
-    count, best = _bestPerGroup(di, dj, dupTab['SNR'], len(dupTab))
-    best = np.where(best < 0, np.arange(len(dupTab)), best)
-    keepMask = np.zeros(len(dupTab), dtype=bool)
-    keepMask[best] = True
-    keepTab = vstack([dupTab[keepMask], noDupTab])
-    keepTab.sort('RADeg')
-    return keepTab, len(dupTab), list(dupTab['name']) if 'name' in dupTab.keys() else []
+    # vstack([duplicates kept, rows without neighbour]) sorted by RADeg (stable), as one selection of rows
+    isDup = np.zeros(n, dtype=bool)
+    isDup[dupIdx] = True
+    idx = np.concatenate([keepDup, np.flatnonzero(~isDup)])
+    idx = idx[np.lexsort([tab['RADeg'][idx]])]
+    keepTab = tab[idx]
+    dupNames = list(tab[dupIdx]['name']) if 'name' in tab.keys() else []
+    return keepTab, len(dupIdx), dupNames
 
 
 # ------------------------------------------------------------------------------------------------------------

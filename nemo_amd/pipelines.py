@@ -119,17 +119,29 @@ def _gatherCatalogs(optimalCatalog, config):
     if len(optimalCatalog) > 0:
         extra = [k for k in optimalCatalog.keys() if k not in _GATHER_COLS + ['name', 'template', 'tileName']
                  and np.asarray(optimalCatalog[k]).dtype.kind in 'fiub']
-    # agree on the extra columns (a rank with no detections has none to offer): keep those every non-empty rank has
-    offers = [None] * config.size
-    dist.all_gather_object(offers, (extra, 'name' in optimalCatalog.keys()) if len(optimalCatalog) > 0 else None)
-    common, carryNames = None, True
-    for o in offers:
-        if o is not None:
-            common = list(o[0]) if common is None else [k for k in common if k in o[0]]
-            carryNames = carryNames and o[1]
-    extra = common or []
-    cols = _GATHER_COLS + extra
+    # Row counts of all ranks - and, in the same exchange, what each rank offers beside the fixed columns: whether it carries
+    # names and a digest of its extra column names.  When every rank has rows and all digests agree (the usual pass) the columns
+    # are settled; otherwise the ranks exchange the lists themselves (a rank with no detections has none to offer: the columns
+    # kept are those every non-empty rank has).
     n = len(optimalCatalog)
+    import hashlib
+    digest = int(hashlib.sha1('\0'.join(extra).encode()).hexdigest()[:15], 16)
+    metas = [torch.zeros(3, dtype=torch.int64, device=dev) for _ in range(config.size)]
+    dist.all_gather(metas, torch.tensor([n, 1 if 'name' in optimalCatalog.keys() else 0, digest], dtype=torch.int64, device=dev))
+    metas = torch.stack(metas).cpu().tolist()                             # one transfer, one synchronisation
+    counts = [int(m[0]) for m in metas]
+    if all(c > 0 for c in counts) and all(m[2] == metas[0][2] for m in metas):
+        carryNames = all(m[1] == 1 for m in metas)
+    else:
+        offers = [None] * config.size
+        dist.all_gather_object(offers, (extra, 'name' in optimalCatalog.keys()) if n > 0 else None)
+        common, carryNames = None, True
+        for o in offers:
+            if o is not None:
+                common = list(o[0]) if common is None else [k for k in common if k in o[0]]
+                carryNames = carryNames and o[1]
+        extra = common or []
+    cols = _GATHER_COLS + extra
     rows = np.zeros((n, len(cols) + 2), dtype=np.float64)
     if n > 0:
         for j, k in enumerate(cols):
@@ -138,9 +150,6 @@ def _gatherCatalogs(optimalCatalog, config):
         tileIndex = {l: i for i, l in enumerate(config.allTileNames)}
         rows[:, len(cols)] = [labelIndex.get(t, -1) for t in np.asarray(optimalCatalog['template']).astype(str).tolist()]
         rows[:, len(cols) + 1] = [tileIndex[t] for t in np.asarray(optimalCatalog['tileName']).astype(str).tolist()]
-    counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(config.size)]
-    dist.all_gather(counts, torch.tensor([n], dtype=torch.int64, device=dev))
-    counts = [int(c) for c in torch.cat(counts).cpu().tolist()]          # one transfer, one synchronisation
     nmax = max(counts)
     if nmax == 0:
         return catalogs.Table(names=('SNR', 'RADeg', 'decDeg'))

@@ -198,6 +198,12 @@ assert len(dedup) == 4 and nDup == 2 and 9.0 in list(dedup['SNR']) and 7.0 not i
 # an empty rank still takes part in the exchange
 empty = pipelines._gatherCatalogs(catalogs.Table(names=('SNR', 'RADeg', 'decDeg')) if rank == 1 else tab, cfg)
 assert len(empty) == 3
+# ranks that offer different extra columns (their digests differ in the counts exchange): only the common ones travel
+tab2 = tab.copy()
+if rank == 1:
+    tab2['fixed_SNR'] = np.ones(len(tab2))
+mixed = pipelines._gatherCatalogs(tab2, cfg)
+assert len(mixed) == 5 and 'fixed_SNR' not in mixed.keys() and 'y_c' in mixed.keys() and mixed['y_c'][3] == 1.0
 parts = startUp.assignTiles(cfg.allTileNames, [3, 2, 1], size)
 assert sorted(parts[0] + parts[1]) == cfg.allTileNames
 dist.barrier()

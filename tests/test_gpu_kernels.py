@@ -721,3 +721,39 @@ def test_fused_line_filter_equals_staged_kernel_bit_for_bit():
             assert r.returncode == 0, r.stderr[-2000:]
             outs.append(r.stdout.strip().splitlines())
         assert len(outs[0]) >= 8 and outs[0] == outs[1], (axis, outs)
+
+
+@pytest.mark.gpu
+def test_remove_duplicates_on_the_device_equals_the_host_path():
+    """catalogs.removeDuplicates (every rank runs it on the gathered catalogue of all ranks after each pass) takes its partner
+    counts and best partners from nf_xmatch_self from GPU_XMATCH_MIN_ROWS rows on: same table, same duplicate count and names as
+    the host's sweep - groups of coincident rows, equal SNRs, equal right ascensions, lazy and given names."""
+    from nemo_amd import catalogs as C
+    engine.require_gpu()
+    rng = np.random.default_rng(17)
+    for trial, n in enumerate((1024, 3000, 5224)):
+        ra, dec = rng.uniform(20, 30, n), rng.uniform(-5, 5, n)
+        m = n // 6
+        src, dst = rng.integers(0, n, m), rng.integers(0, n, m)
+        ra[dst] = ra[src] + rng.choice([0, 1e-3, -2e-3, 0.01, 0.03], m)
+        dec[dst] = dec[src] + rng.choice([0, 5e-3, -0.01, 0.02], m)
+        tab = C.Table()
+        tab['RADeg'], tab['decDeg'], tab['SNR'] = ra, dec, np.round(rng.uniform(4, 8, n), 1)
+        tab['x'] = rng.uniform(0, 1, n)
+        tab['template'] = np.array(['t%d' % (k % 7) for k in range(n)], dtype='U30')
+        if trial % 2 == 0:
+            tab.setLazyNames('ACT-CL', False)
+        else:
+            tab['name'] = np.array(['obj%05d' % k for k in range(n)], dtype='U30')
+        assert engine.gpu_ready()
+        got = C.removeDuplicates(tab.copy())
+        keep = C.GPU_XMATCH_MIN_ROWS
+        C.GPU_XMATCH_MIN_ROWS = 1 << 30
+        try:
+            want = C.removeDuplicates(tab.copy())
+        finally:
+            C.GPU_XMATCH_MIN_ROWS = keep
+        assert got[1] == want[1] > 0 and got[2] == want[2]
+        assert got[0].keys() == want[0].keys()
+        for k in want[0].keys():
+            assert np.array_equal(got[0][k], want[0][k]), (n, k)

@@ -458,6 +458,7 @@ def selectFromCatalog(catalog, constraintsList):
 
 # ------------------------------------------------------------------------------------------------------------
 GPU_XMATCH_MIN_ROWS = 1024
+GPU_XMATCH_MAX_ROWS = 65536      # the device test is all pairs (n^2 / 2 chords): beyond this the host's sorted sweep (n log n) takes over
 
 
 def _unitVectors(RADeg, decDeg):
@@ -586,7 +587,7 @@ def _makeOptimalCatalogForcedRef(catalogDict, constraintsList=[]):
     allCatalogs = vstack(allCatalogs)
     n = len(allCatalogs)
     toRemove = None
-    if n >= GPU_XMATCH_MIN_ROWS:
+    if GPU_XMATCH_MIN_ROWS <= n <= GPU_XMATCH_MAX_ROWS:
         # the all-pairs test is a few tens of microseconds on the device the maps were filtered on; identical outcome
         # (tests/test_gpu_kernels.py::test_xmatch_self), and the host path below decides when a chord is too close to call
         from . import engine
@@ -617,7 +618,7 @@ def removeDuplicates(tab):
         return tab, 1, []
     ra, dec = np.asarray(tab['RADeg'], dtype=float), np.asarray(tab['decDeg'], dtype=float)
     dupIdx = keepDup = None
-    if n >= GPU_XMATCH_MIN_ROWS:
+    if GPU_XMATCH_MIN_ROWS <= n <= GPU_XMATCH_MAX_ROWS:
         from . import engine
         if engine.gpu_ready():
             res = engine.xmatch_self(ra, dec, tab['SNR'], XMATCH_RADIUS_DEG)

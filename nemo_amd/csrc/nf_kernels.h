@@ -39,6 +39,7 @@ int build_filter(int covType, int sigType, const void* cov, const void* S, const
                  long long npix, hipStream_t s, int halfH = 0, int halfW = 0);
 int build_filter_sym(int covType, int sigType, const void* cov, const void* S, const WeightVec& w, float* filt, double* sym, int N,
                      int H, int W, hipStream_t s);
+bool build_filter_shares_inverse(int nb, int N);     // the batch form inverts a mode's covariance once for all nb entries
 int build_filter_sym_batch(int covType, int sigType, const void* cov, const void* S, const WeightVec& w, const BatchPtrs& filt, int nb,
                            double* sym, int N, int H, int W, hipStream_t s);
 int finalize_batch(int vtype, const FinalizeBatch& fb, int nb, const unsigned char* surveyMask, const unsigned char* psMask, int H, int W,

@@ -11,6 +11,8 @@
 #include "nf_common.h"
 #include "nf_kernels.h"
 
+#include <cstdlib>
+
 namespace nf {
 
 static inline int grid_for(long long n, int threads) {
@@ -229,6 +231,140 @@ __global__ void k_build_filter_sym(const T* __restrict__ cov, const cpx<TS>* __r
     }
 }
 
+// The scales of a tile share the noise covariance and the weights: the N x N inverse of a mode is the same for every batch
+// entry, only the signal spectrum differs.  k_build_filter_sym (blockIdx.z = entry) reads and inverts the covariance of a mode
+// and of its mirror once per entry; here a thread inverts both once and walks the entries (N <= 3: the two inverses stay in
+// registers).  build_mode's statements, split at the point where the right-hand side enters: the same bits.
+template <typename T, int N>
+__device__ __forceinline__ void invert_mode(const T* __restrict__ cov, long long npix, long long p, T (&B)[N][N], bool& singular) {
+    singular = false;
+    if (N == 1) {
+        const T a = cov[p];
+        singular = a == (T)0;
+        B[0][0] = singular ? (T)0 : (T)1 / a;
+        return;
+    }
+    T A[N][N];
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            A[i][j] = cov[((long long)i * N + j) * npix + p];
+            B[i][j] = (i == j) ? (T)1 : (T)0;
+        }
+#pragma unroll
+    for (int c = 0; c < N; ++c) {
+        int piv = c;
+        T best = fabs(A[c][c]);
+#pragma unroll
+        for (int r = c + 1; r < N; ++r) {
+            T v = fabs(A[r][c]);
+            if (v > best) {
+                best = v;
+                piv = r;
+            }
+        }
+        if (best == (T)0) singular = true;
+#pragma unroll
+        for (int r = c + 1; r < N; ++r) {
+            if (r == piv) {
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    T t = A[c][j];
+                    A[c][j] = A[r][j];
+                    A[r][j] = t;
+                    t = B[c][j];
+                    B[c][j] = B[r][j];
+                    B[r][j] = t;
+                }
+            }
+        }
+        T rp = (T)1 / A[c][c];
+#pragma unroll
+        for (int r = c + 1; r < N; ++r) {
+            T f = A[r][c] * rp;
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                if (j > c) A[r][j] -= f * A[c][j];
+                B[r][j] -= f * B[c][j];
+            }
+        }
+    }
+#pragma unroll
+    for (int c = N - 1; c >= 0; --c) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            T v = B[c][j];
+#pragma unroll
+            for (int k = c + 1; k < N; ++k) v -= A[c][k] * B[k][j];
+            B[c][j] = v / A[c][c];
+        }
+    }
+}
+
+template <typename T, typename TS, int N>
+__device__ __forceinline__ void apply_mode(const T (&B)[N][N], bool singular, const cpx<TS>* __restrict__ S, const nf::WeightVec& w,
+                                           long long npix, long long ps, float* out) {
+    double rhs[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        cpx<TS> s = S[(long long)i * npix + ps];
+        TS mag = (sizeof(TS) == 4) ? (TS)hypotf((float)s.x, (float)s.y) : (TS)hypot((double)s.x, (double)s.y);
+        rhs[i] = w.v[i] * (double)mag;
+    }
+    if (N == 1) {
+        out[0] = singular ? 0.0f : (float)((double)B[0][0] * rhs[0]);
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < N; ++j) acc += (double)B[i][j] * rhs[j];
+        out[i] = singular ? 0.0f : (float)acc;
+    }
+}
+
+template <typename T, typename TS, int N>
+__global__ void k_build_filter_sym_shared(const T* __restrict__ cov, const cpx<TS>* __restrict__ S0, nf::WeightVec w,
+                                          nf::BatchPtrs fp, double* __restrict__ sym0, int H, int W, int nb) {
+    const int hw = W / 2 + 1;
+    const long long npix = (long long)H * W;
+    for (int y = blockIdx.y; y < H; y += gridDim.y) {
+        const int ym = y == 0 ? 0 : H - y;
+        for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < hw; x += gridDim.x * blockDim.x) {
+            const int xm = x == 0 ? 0 : W - x;
+            const long long p = (long long)y * W + x, pm = (long long)ym * W + xm;
+            const bool selfColumn = xm == x;                  // the mirror lies in this column (stored as it is)
+            T B1[N][N], B2[N][N];
+            bool s1, s2 = false;
+            invert_mode<T, N>(cov, npix, p, B1, s1);
+            if (pm != p) invert_mode<T, N>(cov, npix, pm, B2, s2);
+            for (int z = 0; z < nb; ++z) {
+                const cpx<TS>* __restrict__ S = S0 + (long long)z * N * npix;
+                double* __restrict__ sym = sym0 + (long long)z * N * npix;
+                float* __restrict__ filt = (float*)fp.p[z];
+                float o1[N], o2[N];
+                apply_mode<T, TS, N>(B1, s1, S, w, npix, p, o1);
+                if (pm == p) {
+#pragma unroll
+                    for (int i = 0; i < N; ++i) o2[i] = o1[i];
+                } else {
+                    apply_mode<T, TS, N>(B2, s2, S, w, npix, selfColumn ? pm : p, o2);
+                }
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    if (filt != nullptr) {
+                        filt[(long long)i * npix + p] = o1[i];
+                        if (!selfColumn) filt[(long long)i * npix + pm] = o2[i];
+                    }
+                    sym[(long long)i * npix + p] = 0.5 * ((double)o1[i] + (double)o2[i]);
+                }
+            }
+        }
+    }
+}
+
 template <typename T, typename TS>
 static int build_filter_n(const void* cov, const void* S, const WeightVec& w, float* filt, int N, long long npix, hipStream_t s,
                           int halfH, int halfW) {
@@ -258,9 +394,32 @@ static int build_filter_n(const void* cov, const void* S, const WeightVec& w, fl
     return NF_OK;
 }
 
+// NF_BUILD_SHARED=0: one inverse per entry (k_build_filter_sym) always
+bool build_filter_shares_inverse(int nb, int N) {
+    static const int shared = getenv("NF_BUILD_SHARED") ? atoi(getenv("NF_BUILD_SHARED")) : 1;
+    return shared && nb > 1 && N <= 3;
+}
+
 template <typename T, typename TS>
 static int build_filter_sym_n(const void* cov, const void* S, const WeightVec& w, const BatchPtrs& fp, int nb, double* sym, int N, int H,
                               int W, hipStream_t s) {
+    if (build_filter_shares_inverse(nb, N)) {
+        // one inverse per mode for all entries (64-thread workgroups: the grid has no z to fill the chip with)
+        dim3 gs(nf_div_up(W / 2 + 1, 64), H < 4096 ? H : 4096, 1), bs(64);
+#define NF_BFSH(NN)                                                                                                            \
+    case NN:                                                                                                                   \
+        hipLaunchKernelGGL((k_build_filter_sym_shared<T, TS, NN>), gs, bs, 0, s, (const T*)cov, (const cpx<TS>*)S, w, fp, sym, H, W, nb); \
+        break;
+        switch (N) {
+            NF_BFSH(1)
+            NF_BFSH(2)
+            NF_BFSH(3)
+            default: break;
+        }
+#undef NF_BFSH
+        NF_CHECK_LAUNCH("k_build_filter_sym_shared");
+        return NF_OK;
+    }
     dim3 g(nf_div_up(W / 2 + 1, 256), H < 4096 ? H : 4096, nb), b(256);
 #define NF_BFS(NN)                                                                                                             \
     case NN:                                                                                                                   \

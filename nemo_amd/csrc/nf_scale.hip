@@ -239,8 +239,10 @@ int run_group(nf_plan* plan, const nf_mf_tile& t, const nf_mf_scale* sc, int nb,
             fp.p[b] = sc[b].filt_d;
             nCubes += sc[b].filt_d != nullptr;
         }
+        // (the covariance of a mode is read once for all entries where the build shares its inverse, once per entry otherwise)
+        const int covReads = nf::build_filter_shares_inverse(nb, N) ? 1 : nb;
         nf::ProfScope ps(nf::PT_BUILD_FILTER, st,
-                         (double)npix * (nb * ((double)N * N * (t.covType == NF_F32 ? 4.0 : 8.0) + N * 4.0 + N * 4.0) + nCubes * N * 4.0));
+                         (double)npix * (covReads * (double)N * N * (t.covType == NF_F32 ? 4.0 : 8.0) + nb * (N * 4.0 + N * 4.0) + nCubes * N * 4.0));
         NF_TRY(nf::build_filter_sym_batch(t.covType, NF_F32, t.noiseCov_d, F, wv, fp, nb, filtSym, N, H, W, st));
     }
     nf::BatchPtrs normOut, relOut;
